@@ -1,0 +1,410 @@
+"""CPU ORACLE for the ResUNet hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker / the timed CPU baseline.  The product path
+(``brats2019_amd``) never imports it and fails loudly when the HIP library is missing.
+
+What it is: a from-scratch restatement, in plain ``torch.nn.functional`` calls and closed-form
+numpy, of the one path the build accelerates -- ``model.UNet.forward`` and the Dice/BCE criterion
+of lachinov/brats2019.  The arithmetic of that path lives in a third-party dependency that is not
+vendored under /root/reference: **PyTorch** (README pins torch 1.2.0; this image has
+2.10.0+rocm7.0 CPU).  The op semantics used here (cross-correlation Conv3d, GroupNorm with biased
+variance and eps 1e-5, trilinear ``align_corners=False`` scale 2, LeakyReLU 0.01) are identical
+between those versions for these arguments, so the oracle is "torch CPU executing the reference's
+op sequence".
+
+Parity pin: the reference has no tests and no golden vectors, so this oracle is
+pinned by ``tests/golden/*.npz`` -- outputs of the reference's own ``model.py`` / ``loss.py``
+imported in the build container by ``tests/golden/make_golden.py`` (committed).
+``tests/test_oracle_golden.py`` checks every function below against those files.
+
+Each function cites the reference lines (into /root/reference) it follows.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LEAKY_SLOPE = 1e-2      # model.py:93-94,352
+GN_GROUPS = 8           # model.py:95-96,338
+GN_EPS = 1e-5           # nn.GroupNorm default
+IN_CHANNELS = 4         # model.py:336 (hard-coded in_channels=4)
+
+# the only configuration the reference ships (main.py:56-59, export_onnx_group_norm.py:23-26)
+DEFAULT_CFG = dict(depth=4, encoder_layers=[1, 2, 2, 4], decoder_layers=[1, 1, 1, 1],
+                   number_of_channels=[16, 32, 64, 128], number_of_outputs=3)
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory (model.py:309-404) -- key order == reference state_dict() order
+# --------------------------------------------------------------------------------------
+def _residual_keys(prefix, cin_down, c):
+    """Keys of one ``Residual`` (model.py:81-97): downsample first (registered first when it is a
+    Module, model.py:87), then conv1, conv2, norm1, norm2."""
+    keys = []
+    if cin_down is not None:
+        keys.append((prefix + "downsample.0.weight", (c, cin_down, 2, 2, 2)))      # model.py:361-363
+    keys += [
+        (prefix + "conv1.conv1.weight", (c, c, 3, 3, 3)),                          # model.py:72-73,89
+        (prefix + "conv2.conv1.weight", (c, c, 3, 3, 3)),                          # model.py:91
+        (prefix + "norm1.weight", (c,)), (prefix + "norm1.bias", (c,)),            # model.py:95
+        (prefix + "norm2.weight", (c,)), (prefix + "norm2.bias", (c,)),            # model.py:96
+    ]
+    return keys
+
+
+def state_dict_spec(depth=4, encoder_layers=(1, 2, 2, 4), decoder_layers=(1, 1, 1, 1),
+                    number_of_channels=(16, 32, 64, 128), number_of_outputs=3):
+    """Ordered ``[(key, shape)]`` exactly as ``model.UNet(...).state_dict()`` yields it.
+
+    Registration order in ``UNet.__init__`` (model.py:320-357): encoder_convs, upsampling,
+    decoder_convs, decoder_convs1x1, (empty lists), conv_input, norm_input, conv_first, conv_output.
+    """
+    ch = list(number_of_channels)
+    spec = []
+    for i in range(depth - 1):                                                      # model.py:374-377
+        for j in range(encoder_layers[i + 1]):
+            spec += _residual_keys("encoder_convs.%d.%d." % (i, j), ch[i] if j == 0 else None, ch[i + 1])
+    for i in range(depth - 1):                                                      # model.py:397-404
+        spec.append(("upsampling.%d.1.weight" % i, (ch[i], ch[i + 1], 1, 1, 1)))
+    for i in range(depth):                                                          # model.py:379-395
+        for j in range(decoder_layers[i]):
+            spec += _residual_keys("decoder_convs.%d.%d." % (i, j), None, ch[i])
+    for i in range(depth):
+        spec.append(("decoder_convs1x1.%d.weight" % i, (ch[i], 2 * ch[i], 1, 1, 1)))
+    spec.append(("conv_input.weight", (ch[0], IN_CHANNELS, 3, 3, 3)))               # model.py:336
+    spec += [("norm_input.weight", (ch[0],)), ("norm_input.bias", (ch[0],))]        # model.py:338
+    for j in range(encoder_layers[0]):                                              # model.py:340-345
+        spec += _residual_keys("conv_first.%d." % j, None, ch[0])
+    spec.append(("conv_output.weight", (number_of_outputs, ch[0], 3, 3, 3)))        # model.py:348
+    spec.append(("conv_output.bias", (number_of_outputs,)))
+    return spec
+
+
+def make_params(seed=1337, **cfg):
+    """Synthetic weights per SURVEY.md section 8(d): Conv3d ~ N(0, sqrt(2/((1+0.01^2) fan_in))) (the
+    distribution of weight_init.py:23), conv bias ~ N(0,1) (weight_init.py:27), GN gamma ~ U(.5,1.5),
+    beta ~ U(-.5,.5); drawn from one ``numpy.random.default_rng(seed)`` in state-dict key order.
+    Returns ``OrderedDict[str, np.ndarray(float32)]``."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for key, shape in state_dict_spec(**cfg):
+        if len(shape) == 5:
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            std = math.sqrt(2.0 / ((1.0 + LEAKY_SLOPE ** 2) * fan_in))
+            v = rng.standard_normal(shape) * std
+        elif key.endswith("conv_output.bias"):
+            v = rng.standard_normal(shape)
+        elif key.endswith(".weight"):
+            v = rng.uniform(0.5, 1.5, shape)
+        else:
+            v = rng.uniform(-0.5, 0.5, shape)
+        out[key] = v.astype(np.float32)
+    return out
+
+
+def make_input(n, d, h, w, seed=1337):
+    """x ~ N(0,1) float32 ``[n,4,d,h,w]`` (real inputs are per-channel z-scored, test.py:103-113)."""
+    rng = np.random.default_rng(seed + 1)
+    return rng.standard_normal((n, IN_CHANNELS, d, h, w)).astype(np.float32)
+
+
+def make_target(n, d, h, w, seed=1337):
+    """Nested WT>=TC>=ET binary masks from one uniform field (dataloader.py:208-212 nesting)."""
+    rng = np.random.default_rng(seed + 2)
+    u = rng.random((n, 1, d, h, w))
+    return np.concatenate([u > 0.70, u > 0.80, u > 0.90], axis=1).astype(np.float32)
+
+
+def to_torch(params, requires_grad=False):
+    out = OrderedDict()
+    for k, v in params.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).clone() if isinstance(v, np.ndarray) else v.clone()
+        out[k] = t.requires_grad_(requires_grad)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# ops (each the stock torch op the reference calls at the cited line)
+# --------------------------------------------------------------------------------------
+def conv3x3x3(x, w, bias=None):
+    """model.py:72-73 (`conv`), :336 (conv_input), :348 (conv_output, with bias): k=3, s=1, p=1."""
+    return F.conv3d(x, w, bias, stride=1, padding=1)
+
+
+def conv2x2x2_s2(x, w):
+    """model.py:361-363: downsample Conv3d(kernel_size=2, stride=2, bias=False)."""
+    return F.conv3d(x, w, None, stride=2, padding=0)
+
+
+def conv1x1x1(x, w):
+    """model.py:393,401: 1x1x1 Conv3d, bias=False."""
+    return F.conv3d(x, w, None)
+
+
+def group_norm(x, gamma, beta):
+    """model.py:95-96,338: nn.GroupNorm(8, C), eps 1e-5, affine."""
+    return F.group_norm(x, GN_GROUPS, gamma, beta, GN_EPS)
+
+
+def leaky_relu(x):
+    """model.py:93-94,352: LeakyReLU(1e-2)."""
+    return F.leaky_relu(x, LEAKY_SLOPE)
+
+
+def trilinear_up2(x):
+    """model.py:12-14: F.interpolate(scale_factor=2, mode='trilinear') (align_corners=False)."""
+    return F.interpolate(x, scale_factor=2, mode="trilinear")
+
+
+def residual(p, prefix, x):
+    """model.py:99-117 Residual.forward: x=down(x)?; LReLU(GN(conv)) twice; x + out (no act after)."""
+    if prefix + "downsample.0.weight" in p:
+        x = conv2x2x2_s2(x, p[prefix + "downsample.0.weight"])
+    out = conv3x3x3(x, p[prefix + "conv1.conv1.weight"])
+    out = leaky_relu(group_norm(out, p[prefix + "norm1.weight"], p[prefix + "norm1.bias"]))
+    out = conv3x3x3(out, p[prefix + "conv2.conv1.weight"])
+    out = leaky_relu(group_norm(out, p[prefix + "norm2.weight"], p[prefix + "norm2.bias"]))
+    return x + out
+
+
+def unet_forward(p, x, depth=4, encoder_layers=(1, 2, 2, 4), decoder_layers=(1, 1, 1, 1), taps=None, **_):
+    """model.py:407-433 UNet.forward (without its gc.collect()).  ``x``: ``[N,4,D,H,W]`` tensor;
+    returns sigmoid probabilities ``[N,n_out,D,H,W]``.  ``taps`` (optional dict) receives named
+    intermediates for per-layer checks."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    c = conv3x3x3(x, p["conv_input.weight"])                                   # :412
+    c = group_norm(c, p["norm_input.weight"], p["norm_input.bias"])            # :413 (no activation)
+    tap("norm_input", c)
+    for j in range(encoder_layers[0]):                                         # :414
+        c = residual(p, "conv_first.%d." % j, c)
+    tap("conv_first", c)
+    skips = []
+    for i in range(depth - 1):                                                 # :416-418
+        skips.append(c)
+        for j in range(encoder_layers[i + 1]):
+            c = residual(p, "encoder_convs.%d.%d." % (i, j), c)
+        tap("enc%d" % i, c)
+    for i in reversed(range(depth - 1)):                                       # :420-426
+        c = conv1x1x1(trilinear_up2(c), p["upsampling.%d.1.weight" % i])       # :399-402
+        c = leaky_relu(c)                                                      # :422
+        c = torch.cat([skips[i], c], dim=1)                                    # :424 skip first
+        c = conv1x1x1(c, p["decoder_convs1x1.%d.weight" % i])                  # :425
+        for j in range(decoder_layers[i]):                                     # :426
+            c = residual(p, "decoder_convs.%d.%d." % (i, j), c)
+        tap("dec%d" % i, c)
+    logits = conv3x3x3(c, p["conv_output.weight"], p["conv_output.bias"])     # :429
+    tap("logits", logits)
+    return torch.sigmoid(logits)                                               # :431
+
+
+def dice_loss_joint(pred, gt, priority=1.0):
+    """loss.py:105-122: sums over batch and space jointly (dim=(0,2))."""
+    n, c = pred.shape[:2]
+    pr = pred.reshape(n, c, -1)
+    g = gt.reshape(n, c, -1)
+    inter = (pr * g).sum(dim=(0, 2)) + 1e-6
+    union = (pr ** 2 + g).sum(dim=(0, 2)) + 2e-6
+    return priority * (1.0 - torch.mean(2.0 * inter / union))
+
+
+def bce_loss(pred, gt, bg_weight=1.0):
+    """loss.py:70-79."""
+    loss = gt * torch.log(pred + 1e-6) + bg_weight * (1.0 - gt) * torch.log((1.0 + 1e-6) - pred)
+    return -torch.mean(loss)
+
+
+def criterion(pred, gt, bg_weight=1e-2, priority=1.0):
+    """train.py:203-205 with the criterion list of main.py:126-128: (Dice + BCE(bg 1e-2)) / 2."""
+    return (dice_loss_joint(pred, gt, priority) + bce_loss(pred, gt, bg_weight)) / 2.0
+
+
+def forward_backward(params_np, x_np, g_np, bg_weight=1e-2, threads=None, **cfg):
+    """One training forward + criterion + backward (train.py:201-210) on CPU via autograd.
+    Returns (probs ndarray, loss float, OrderedDict of grad ndarrays; dead params -> None)."""
+    if threads:
+        torch.set_num_threads(threads)
+    p = to_torch(params_np, requires_grad=True)
+    x = torch.from_numpy(x_np)
+    g = torch.from_numpy(g_np)
+    probs = unet_forward(p, x, **cfg)
+    loss = criterion(probs, g, bg_weight)
+    loss.backward()
+    grads = OrderedDict((k, None if v.grad is None else v.grad.numpy()) for k, v in p.items())
+    return probs.detach().numpy(), float(loss), grads
+
+
+# --------------------------------------------------------------------------------------
+# closed forms in float64 numpy -- independent cross-checks of the
+# formulas the HIP kernels implement; small sizes only
+# --------------------------------------------------------------------------------------
+def np_trilinear_matrix(n):
+    """Appendix A5: the 2n x n per-axis matrix of scale-2 linear interpolation, align_corners=False
+    (model.py:13)."""
+    m = np.zeros((2 * n, n))
+    for k in range(n):
+        m[2 * k, max(k - 1, 0)] += 0.25
+        m[2 * k, k] += 0.75
+        m[2 * k + 1, k] += 0.75
+        m[2 * k + 1, min(k + 1, n - 1)] += 0.25
+    return m
+
+
+def np_trilinear_up2(x):
+    x = np.asarray(x, np.float64)
+    for ax in (-3, -2, -1):
+        m = np_trilinear_matrix(x.shape[ax])
+        x = np.moveaxis(np.tensordot(m, np.moveaxis(x, ax, 0), axes=(1, 0)), 0, ax)
+    return x
+
+
+def np_trilinear_up2_bwd(dy):
+    dy = np.asarray(dy, np.float64)
+    for ax in (-3, -2, -1):
+        m = np_trilinear_matrix(dy.shape[ax] // 2).T
+        dy = np.moveaxis(np.tensordot(m, np.moveaxis(dy, ax, 0), axes=(1, 0)), 0, ax)
+    return dy
+
+
+def np_group_norm(x, gamma, beta, groups=GN_GROUPS, eps=GN_EPS):
+    """Appendix A3 forward; returns (y, mean[n,g], rstd[n,g])."""
+    x = np.asarray(x, np.float64)
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, -1)
+    mu = xg.mean(-1)
+    var = ((xg - mu[..., None]) ** 2).mean(-1)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xh = ((xg - mu[..., None]) * rstd[..., None]).reshape(x.shape)
+    bshape = (1, c) + (1,) * (x.ndim - 2)
+    return xh * np.asarray(gamma, np.float64).reshape(bshape) + np.asarray(beta, np.float64).reshape(bshape), mu, rstd
+
+
+def np_group_norm_bwd(x, gamma, dy, groups=GN_GROUPS, eps=GN_EPS):
+    """Appendix A3 backward; returns (dx, dgamma, dbeta)."""
+    x = np.asarray(x, np.float64)
+    dy = np.asarray(dy, np.float64)
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, -1)
+    mu = xg.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(((xg - mu) ** 2).mean(-1, keepdims=True) + eps)
+    xh = ((xg - mu) * rstd)
+    bshape = (1, c) + (1,) * (x.ndim - 2)
+    dyt = (dy * np.asarray(gamma, np.float64).reshape(bshape)).reshape(n, groups, -1)
+    dx = rstd * (dyt - dyt.mean(-1, keepdims=True) - xh * (dyt * xh).mean(-1, keepdims=True))
+    xh = xh.reshape(x.shape)
+    red = (0,) + tuple(range(2, x.ndim))
+    return dx.reshape(x.shape), (dy * xh).sum(red), dy.sum(red)
+
+
+def np_dice_bce_sums(p, g, bg_weight=1e-2):
+    """Appendix A7 phase 1: per-class (I_c, U_c) WITHOUT epsilons and the BCE sum, float64."""
+    p32 = np.asarray(p, np.float32)
+    p = p32.astype(np.float64)
+    g = np.asarray(g, np.float64)
+    red = (0,) + tuple(range(2, p.ndim))
+    inter = (p * g).sum(red)
+    union = (p * p + g).sum(red)
+    # the two log arguments are formed in float32 exactly as loss.py:76-77 forms them (matters only
+    # at saturated p: float32(1+1e-6) - 1 = 9.54e-7, not 1e-6)
+    a = (p32 + np.float32(1e-6)).astype(np.float64)
+    b = (np.float32(1.0 + 1e-6) - p32).astype(np.float64)
+    bce = (g * np.log(a) + bg_weight * (1 - g) * np.log(b)).sum()
+    return inter, union, bce
+
+
+def np_criterion_from_sums(inter, union, bce, count, priority=1.0):
+    """loss value from GLOBAL sums (epsilons added after any cross-rank reduce)."""
+    dice = priority * (1.0 - np.mean(2.0 * (inter + 1e-6) / (union + 2e-6)))
+    return 0.5 * (dice + (-bce / count)), dice, -bce / count
+
+
+def np_criterion_grad(p, g, inter, union, count, bg_weight=1e-2, priority=1.0):
+    """Appendix A7: d[(Dice+BCE)/2]/dp given GLOBAL sums and GLOBAL element count."""
+    p32 = np.asarray(p, np.float32)
+    p = p32.astype(np.float64)
+    g = np.asarray(g, np.float64)
+    c = p.shape[1]
+    bshape = (1, c) + (1,) * (p.ndim - 2)
+    i_c = (inter + 1e-6).reshape(bshape)
+    u_c = (union + 2e-6).reshape(bshape)
+    d_dice = -priority * (2.0 / c) * (g * u_c - 2.0 * p * i_c) / (u_c * u_c)
+    a = (p32 + np.float32(1e-6)).astype(np.float64)          # float32-formed, see np_dice_bce_sums
+    b = (np.float32(1.0 + 1e-6) - p32).astype(np.float64)
+    d_bce = -(g / a - bg_weight * (1 - g) / b) / count
+    return 0.5 * (d_dice + d_bce)
+
+
+def np_adam_amsgrad_step(w, g, m, v, vmax, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-6):
+    """torch.optim.Adam(amsgrad=True, weight_decay=wd) single-tensor update (main.py:133-137:
+    lr 2e-5, wd 1e-6, amsgrad) -- L2 decay added to the gradient.  ``step`` is 1-based.
+    float64 in, float64 out; returns (w, m, v, vmax)."""
+    g = g + weight_decay * w
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    vmax = np.maximum(vmax, v)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = np.sqrt(vmax) / math.sqrt(bc2) + eps
+    return w - (lr / bc1) * m / denom, m, v, vmax
+
+
+def step_lr(base_lr, step, step_size=16000, gamma=0.5):
+    """StepLR(step_size=16000, gamma=0.5) stepped per iteration (main.py:139-142, train.py:222-223)."""
+    return base_lr * gamma ** (step // step_size)
+
+
+# --------------------------------------------------------------------------------------
+# evaluation yardstick (metrics.py:108-133) and tiling helpers (loader_helper.py:34-97)
+# --------------------------------------------------------------------------------------
+def dice_metric(pred, gt):
+    """metrics.Dice.update semantics (metrics.py:108-133): threshold 0.5; per sample and channel
+    2*sum(p*g)/sum(p+g) over space, NaN -> 1; mean over the batch.  Returns [C]."""
+    p = (np.asarray(pred) > 0.5).astype(np.float64)
+    g = (np.asarray(gt) > 0.5).astype(np.float64)
+    red = tuple(range(2, p.ndim))
+    num = 2.0 * (p * g).sum(red)
+    den = (p + g).sum(red)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = num / den
+    d[np.isnan(d)] = 1.0
+    return d.mean(axis=0)
+
+
+def tile_indices(position, center_shape, border):
+    """loader_helper.py:34-40 get_indices: tile = centre block `position` grown by `border`."""
+    index_min = [p * c - b for p, c, b in zip(position, center_shape, border)]
+    index_max = [(p + 1) * c + b for p, c, b in zip(position, center_shape, border)]
+    return index_min, index_max
+
+
+def tile_copy(data, tile_shape, index_min, index_max):
+    """loader_helper.py:42-80 copy: zero-padded extract of data[..., min:max] into a tile."""
+    tile = np.zeros(tuple(data.shape[:2]) + tuple(tile_shape), data.dtype)
+    src, dst = [], []
+    for a in range(3):
+        lo = max(index_min[a], 0)
+        hi = min(index_max[a], data.shape[2 + a])
+        src.append(slice(lo, hi))
+        dst.append(slice(lo - index_min[a], hi - index_min[a]))
+    tile[(slice(None), slice(None)) + tuple(dst)] = data[(slice(None), slice(None)) + tuple(src)]
+    return tile
+
+
+def tile_copy_back(data, tile, center_shape, index_min, index_max, border):
+    """loader_helper.py:82-97 copy_back: paste the tile's centre block into data (clipped)."""
+    src, dst = [], []
+    for a in range(3):
+        lo = index_min[a] + border[a]
+        hi = min(index_max[a] - border[a], data.shape[2 + a])
+        dst.append(slice(lo, hi))
+        src.append(slice(border[a], border[a] + (hi - lo)))
+    data[(slice(None), slice(None)) + tuple(dst)] = tile[(slice(None), slice(None)) + tuple(src)]
+    return data

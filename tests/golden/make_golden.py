@@ -1,0 +1,404 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz (+ one tiny checkpoint) by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+
+It imports /root/reference/{model,loss,loader_helper,metrics,train}.py unmodified, feeds them seeded
+synthetic inputs (inputs/weights come from numpy RNGs so both sides can regenerate them), and stores
+the reference's OUTPUTS.  Fixtures are data -- no reference source text is stored.  The blank
+``types.ModuleType`` entries below only satisfy ``import nibabel`` / ``SimpleITK`` / ``tensorboardX``
+at the top of loader_helper.py / metrics.py / train.py (absent in this image); none of their
+functionality is used or faked.
+"""
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import resunet_oracle as O  # noqa: E402  (inputs/weights only: data, not algorithm)
+
+for _name in ("nibabel", "SimpleITK", "tensorboardX"):
+    if _name not in sys.modules:
+        try:
+            __import__(_name)
+        except Exception:
+            _m = types.ModuleType(_name)
+            if _name == "tensorboardX":
+                _m.SummaryWriter = object
+            sys.modules[_name] = _m
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import model as ref_model      # noqa: E402
+    import loss as ref_loss        # noqa: E402
+    import loader_helper as ref_lh  # noqa: E402
+    import metrics as ref_metrics  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def t(a, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).requires_grad_(grad)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-22s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024, len(arrays)))
+
+
+def quiet_unet(**cfg):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return ref_model.UNet(cfg["depth"], cfg["encoder_layers"], cfg["decoder_layers"],
+                              cfg["number_of_channels"], cfg["number_of_outputs"])
+
+
+# ------------------------------------------------------------------ (1) per-op known answers
+def gen_ops():
+    out = {}
+    r = rng(11)
+
+    def conv_case(tag, cin, cout, shape, bias):
+        x = r.standard_normal((2, cin) + shape).astype(np.float32)
+        m = ref_model.conv(cin, cout) if not bias else None
+        if bias:   # head: model.py:348 constructs nn.Conv3d(k=3,s=1,p=1,bias=True) directly
+            conv = torch.nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True)
+        else:
+            conv = m.conv1
+        w = (r.standard_normal(tuple(conv.weight.shape)) * 0.1).astype(np.float32)
+        conv.weight.data = t(w)
+        if bias:
+            b = r.standard_normal((cout,)).astype(np.float32)
+            conv.bias.data = t(b)
+            out[tag + "_b"] = b
+        xt = t(x, True)
+        y = (conv if bias else m)(xt)
+        dy = r.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(t(dy))
+        out[tag + "_x"], out[tag + "_w"], out[tag + "_dy"] = x, w, dy
+        out[tag + "_y"] = y.detach().numpy()
+        out[tag + "_dx"] = xt.grad.numpy()
+        out[tag + "_dw"] = conv.weight.grad.numpy()
+        if bias:
+            out[tag + "_db"] = conv.bias.grad.numpy()
+
+    conv_case("c3_4_16", 4, 16, (8, 9, 10), False)
+    conv_case("c3_16_16", 16, 16, (8, 8, 16), False)
+    conv_case("c3_32_32", 32, 32, (6, 8, 16), False)
+    conv_case("c3_16_3b", 16, 3, (8, 10, 12), True)
+
+    def plain_conv_case(tag, cin, cout, k, s, shape):
+        conv = torch.nn.Conv3d(cin, cout, kernel_size=k, stride=s, bias=False)   # model.py:361-363 / :393,401
+        x = r.standard_normal((2, cin) + shape).astype(np.float32)
+        w = (r.standard_normal(tuple(conv.weight.shape)) * 0.2).astype(np.float32)
+        conv.weight.data = t(w)
+        xt = t(x, True)
+        y = conv(xt)
+        dy = r.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(t(dy))
+        out[tag + "_x"], out[tag + "_w"], out[tag + "_dy"] = x, w, dy
+        out[tag + "_y"], out[tag + "_dx"], out[tag + "_dw"] = y.detach().numpy(), xt.grad.numpy(), conv.weight.grad.numpy()
+
+    plain_conv_case("c2s2_16_32", 16, 32, 2, 2, (8, 12, 16))
+    plain_conv_case("c1_32_16", 32, 16, 1, 1, (6, 10, 12))
+    plain_conv_case("c1_128_64", 128, 64, 1, 1, (4, 4, 8))
+
+    def gn_case(tag, c, shape):
+        gn = torch.nn.GroupNorm(num_groups=8, num_channels=c)                     # model.py:95-96
+        x = (r.standard_normal((2, c) + shape) * 1.7 + 0.3).astype(np.float32)
+        gamma = r.uniform(0.5, 1.5, c).astype(np.float32)
+        beta = r.uniform(-0.5, 0.5, c).astype(np.float32)
+        gn.weight.data, gn.bias.data = t(gamma), t(beta)
+        xt = t(x, True)
+        y = gn(xt)
+        dy = r.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(t(dy))
+        xg = x.astype(np.float64).reshape(2, 8, -1)
+        out[tag + "_x"], out[tag + "_gamma"], out[tag + "_beta"], out[tag + "_dy"] = x, gamma, beta, dy
+        out[tag + "_y"], out[tag + "_dx"] = y.detach().numpy(), xt.grad.numpy()
+        out[tag + "_dgamma"], out[tag + "_dbeta"] = gn.weight.grad.numpy(), gn.bias.grad.numpy()
+        out[tag + "_mean"] = xg.mean(-1)
+        out[tag + "_rstd"] = 1.0 / np.sqrt(xg.var(-1) + 1e-5)
+
+    gn_case("gn16", 16, (6, 8, 10))
+    gn_case("gn128", 128, (4, 4, 4))
+
+    # LeakyReLU(0.01, inplace) (model.py:93-94) incl. backward-from-output
+    x = r.standard_normal((2, 4, 5, 6, 7)).astype(np.float32)
+    xt = t(x, True)
+    y = torch.nn.LeakyReLU(1e-2, inplace=True)(xt * 1.0)
+    dy = r.standard_normal(x.shape).astype(np.float32)
+    y.backward(t(dy))
+    out["lrelu_x"], out["lrelu_dy"], out["lrelu_y"], out["lrelu_dx"] = x, dy, y.detach().numpy(), xt.grad.numpy()
+
+    # Trilinear x2 on odd sizes (model.py:7-14)
+    x = r.standard_normal((2, 3, 5, 6, 7)).astype(np.float32)
+    xt = t(x, True)
+    y = ref_model.Trilinear(scale=2)(xt)
+    dy = r.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(t(dy))
+    out["up_x"], out["up_dy"], out["up_y"], out["up_dx"] = x, dy, y.detach().numpy(), xt.grad.numpy()
+
+    # Sigmoid (model.py:351,431)
+    x = (r.standard_normal((2, 3, 4, 5, 6)) * 3).astype(np.float32)
+    out["sig_x"], out["sig_y"] = x, torch.nn.Sigmoid()(t(x)).numpy()
+    save("ops.npz", **out)
+
+
+# ------------------------------------------------------------------ (2) Residual blocks
+def gen_residual():
+    out = {}
+    r = rng(12)
+    for tag, cin, c, shape in (("res16", None, 16, (8, 8, 16)), ("res32d", 16, 32, (8, 12, 16))):
+        down = None
+        if cin is not None:
+            down = torch.nn.Sequential(torch.nn.Conv3d(cin, c, kernel_size=2, stride=2, bias=False))  # model.py:359-364
+        blk = ref_model.Residual(in_channels=c, out_channels=c, stride=1, downsample=down)
+        sd = blk.state_dict()
+        for k in sd:
+            shp = tuple(sd[k].shape)
+            if len(shp) == 5:
+                v = r.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))
+            elif k.endswith("weight"):
+                v = r.uniform(0.5, 1.5, shp)
+            else:
+                v = r.uniform(-0.5, 0.5, shp)
+            sd[k] = t(v)
+            out["%s_p_%s" % (tag, k)] = sd[k].numpy()
+        blk.load_state_dict(sd)
+        x = r.standard_normal((2, cin if cin else c) + shape).astype(np.float32)
+        xt = t(x, True)
+        y = blk(xt)
+        dy = r.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(t(dy))
+        out[tag + "_x"], out[tag + "_dy"], out[tag + "_y"], out[tag + "_dx"] = x, dy, y.detach().numpy(), xt.grad.numpy()
+        for k, p in blk.named_parameters():
+            out["%s_g_%s" % (tag, k)] = p.grad.numpy()
+    save("residual.npz", **out)
+
+
+# ------------------------------------------------------------------ (3) criterion
+def gen_loss():
+    out = {}
+    r = rng(13)
+    p = r.uniform(0.001, 0.999, (2, 3, 8, 8, 8)).astype(np.float32)
+    p[0, 0, 0, 0, :4] = [0.0, 1.0, 1e-7, 1 - 1e-7]          # saturated probabilities (log(p+1e-6) edge)
+    u = r.random((2, 1, 8, 8, 8))
+    g = np.concatenate([u > 0.7, u > 0.8, u > 0.9], 1).astype(np.float32)
+    out["p"], out["g"] = p, g
+    for tag, crit in (("dice", [ref_loss.Dice_loss_joint(index=0, priority=1)]),
+                      ("bce", [ref_loss.BCE_Loss(index=0, bg_weight=1e-2)]),
+                      ("bce_w1", [ref_loss.BCE_Loss(index=0, bg_weight=1)]),
+                      ("crit", [ref_loss.Dice_loss_joint(index=0, priority=1), ref_loss.BCE_Loss(index=0, bg_weight=1e-2)])):
+        pt = t(p, True)
+        vals = [c([pt], [t(g)]) for c in crit]
+        lv = sum(vals) / len(vals)                          # train.py:203-205
+        lv.backward()
+        out[tag + "_loss"] = np.float64(lv.item())
+        out[tag + "_dp"] = pt.grad.numpy()
+    # metrics.Dice yardstick (metrics.py:101-133)
+    m = ref_metrics.Dice(classes=4)
+    m.reset() if hasattr(m, "reset") else None
+    m.update([t(g)], [t(p)])
+    out["metric_dice"] = np.asarray(m.get(), np.float64)
+    save("loss.npz", **out)
+
+
+# ------------------------------------------------------------------ (4,5) whole net
+def load_ref_unet(cfg, seed):
+    net = quiet_unet(**cfg)
+    params = O.make_params(seed, **cfg)
+    keys = list(net.state_dict().keys())
+    assert keys == list(params.keys()), "oracle.state_dict_spec order != reference state_dict order"
+    net.load_state_dict({k: t(v) for k, v in params.items()})
+    return net, params
+
+
+def gn_stats_hooks(net, store):
+    hooks = []
+    for name, mod in net.named_modules():
+        if isinstance(mod, torch.nn.GroupNorm):
+            def hook(m, inp, outp, name=name):
+                x = inp[0].detach().double()
+                n = x.shape[0]
+                xg = x.reshape(n, 8, -1)
+                store[name] = np.stack([xg.mean(-1).numpy(), (1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5)).numpy()])
+            hooks.append(mod.register_forward_hook(hook))
+    return hooks
+
+
+def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward):
+    out = {"seed": np.int64(seed), "shape": np.asarray((n,) + dhw, np.int64)}
+    net, params = load_ref_unet(cfg, seed)
+    x = O.make_input(n, *dhw, seed=seed)
+    g = O.make_target(n, *dhw, seed=seed)
+    stats = {}
+    hooks = gn_stats_hooks(net, stats)
+    if with_backward:
+        net.train()
+        probs = net([t(x)])[0]                                                 # model.py:407: list in, list out
+        crit = [ref_loss.Dice_loss_joint(index=0, priority=1), ref_loss.BCE_Loss(index=0, bg_weight=1e-2)]   # main.py:126-128
+        vals = [c([probs], [t(g)]) for c in crit]
+        lv = sum(vals) / len(vals)                                             # train.py:203-205
+        lv.backward()                                                          # train.py:210
+        out["loss"] = np.float64(lv.item())
+        out["loss_dice"], out["loss_bce"] = np.float64(vals[0].item()), np.float64(vals[1].item())
+        dead = []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                dead.append(k)
+                continue
+            gflat = p.grad.numpy().ravel()
+            out["gnorm_" + k] = np.float64(np.sqrt((gflat.astype(np.float64) ** 2).sum()))
+            out["gsamp_" + k] = gflat[:: max(1, gflat.size // 16)][:16].copy()
+            if gflat.size <= 4096:
+                out["gfull_" + k] = p.grad.numpy().copy()
+        out["dead_params"] = np.asarray(dead)
+        probs = probs.detach()
+    else:
+        net.eval()
+        with torch.no_grad():
+            probs = net([t(x)])[0]
+    for h in hooks:
+        h.remove()
+    pn = probs.numpy()
+    mask = pn > 0.5
+    out["mask_sha256"] = np.asarray(hashlib.sha256(np.packbits(mask.ravel()).tobytes()).hexdigest())
+    out["mask_count"] = np.int64(mask.sum())
+    out["near_half_1e-5"] = np.int64((np.abs(pn - 0.5) < 1e-5).sum())
+    out["near_half_1e-4"] = np.int64((np.abs(pn - 0.5) < 1e-4).sum())
+    flat = pn.ravel()
+    stride = max(1, flat.size // 4096)
+    out["sample_stride"] = np.int64(stride)
+    out["samples"] = flat[::stride][:4096].copy()
+    if full_output:
+        out["probs"] = pn
+    else:
+        out["mask_packed"] = np.packbits(mask.ravel())
+    for k, v in stats.items():
+        out["gnstat_" + k] = v
+    save(tag + ".npz", **out)
+
+
+# ------------------------------------------------------------------ (7) Adam(amsgrad) + StepLR
+def gen_adam():
+    r = rng(17)
+    w0 = r.standard_normal(257).astype(np.float32)
+    grads = (r.standard_normal((5, 257)) * np.array([1, 10, 0.1, 1, 3])[:, None]).astype(np.float32)
+    w = torch.nn.Parameter(t(w0).clone())
+    opt = torch.optim.Adam([w], lr=2e-5, weight_decay=1e-6, amsgrad=True)     # main.py:133-137
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)      # main.py:139-142 (16000 there)
+    traj, lrs = [], []
+    for i in range(5):
+        opt.zero_grad()
+        w.grad = t(grads[i]).clone()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()                                                          # train.py:220-223 (per iteration)
+        traj.append(w.detach().numpy().copy())
+    save("adam.npz", w0=w0, grads=grads, traj=np.stack(traj), lrs=np.asarray(lrs, np.float64))
+
+
+# ------------------------------------------------------------------ (9) tiling
+def gen_tiling():
+    out = {}
+    shape = (240, 240, 155)
+    center, border, tile = (64, 64, 64), (32, 32, 32), (128, 128, 128)
+    grid = [int(np.ceil(j / i)) for i, j in zip(center, shape)]                # train.py:158
+    mins, maxs = [], []
+    for i in range(grid[0]):
+        for j in range(grid[1]):
+            for k in range(grid[2]):
+                a, b = ref_lh.get_indices(position=(i, j, k), center_shape=center, border=border)
+                mins.append(a)
+                maxs.append(b)
+    out["shape"], out["center"], out["border"], out["tile"], out["grid"] = map(np.asarray, (shape, center, border, tile, grid))
+    out["index_min"], out["index_max"] = np.asarray(mins), np.asarray(maxs)
+    # small end-to-end copy / copy_back identity on a ragged volume
+    r = rng(19)
+    data = r.standard_normal((1, 2, 21, 17, 11)).astype(np.float32)
+    c, b, tl = (8, 8, 8), (4, 4, 4), (16, 16, 16)
+    g2 = [int(np.ceil(j / i)) for i, j in zip(c, data.shape[2:])]
+    res = torch.zeros(data.shape)
+    tiles = []
+    for i in range(g2[0]):
+        for j in range(g2[1]):
+            for k in range(g2[2]):
+                a, bb = ref_lh.get_indices((i, j, k), c, b)
+                tl_t = ref_lh.copy(data=t(data), tile_shape=tl, index_min=a, index_max=bb)
+                tiles.append(tl_t.numpy().copy())
+                ref_lh.copy_back(data=res, tile=tl_t, center_shape=c, index_min=a, index_max=bb, border=b)
+    out["small_data"], out["small_tiles"], out["small_result"] = data, np.stack(tiles), res.numpy()
+    save("tiling.npz", **out)
+
+
+# ------------------------------------------------------------------ (8) checkpoint in Trainer._save layout
+def gen_checkpoint():
+    import tempfile
+    with contextlib.redirect_stdout(io.StringIO()):
+        import train as ref_train
+    cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
+    net, params = load_ref_unet(cfg, 23)
+    wrapped = torch.nn.DataParallel(module=net, device_ids=[0]) if False else net   # CPU-only image: no DataParallel devices
+    tmp = tempfile.mkdtemp()
+    tr = ref_train.Trainer(name="tiny", models_root=tmp, model=wrapped, rewrite=True, connect_tb=False)
+    tr.state.cuda = False
+    tr.state.epoch = 3
+    tr.state.global_step = 77
+    tr.state.best_val = 1.25
+    tr._save("best_model")                                                     # train.py:320-324
+    src = os.path.join(tmp, "tiny", "tinybest_model.pth")
+    dst_dir = os.path.join(HERE, "ckpt", "tiny")
+    os.makedirs(dst_dir, exist_ok=True)
+    with open(src, "rb") as f, open(os.path.join(dst_dir, "tinybest_model.pth"), "wb") as o:
+        o.write(f.read())
+    x = O.make_input(1, 8, 8, 8, seed=23)
+    net.eval()
+    with torch.no_grad():
+        y = net([t(x)])[0].numpy()
+    save("ckpt_expect.npz", probs=y, seed=np.int64(23))
+    print("wrote ckpt/tiny/tinybest_model.pth %.1f KB" % (os.path.getsize(src) / 1024))
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:])
+    full = O.DEFAULT_CFG
+    small = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[8, 16, 32], number_of_outputs=3)
+
+    def want(x):
+        return not which or x in which
+    if want("ops"):
+        gen_ops()
+    if want("residual"):
+        gen_residual()
+    if want("loss"):
+        gen_loss()
+    if want("unet32"):
+        gen_unet("unet32", full, 1, (32, 32, 32), 1337, full_output=True, with_backward=True)
+    if want("unet_small"):
+        gen_unet("unet_small", small, 2, (16, 24, 16), 7, full_output=True, with_backward=True)
+    if want("unet128"):
+        gen_unet("unet128", full, 1, (128, 128, 128), 1337, full_output=False, with_backward=False)
+    if want("adam"):
+        gen_adam()
+    if want("tiling"):
+        gen_tiling()
+    if want("ckpt"):
+        gen_checkpoint()
