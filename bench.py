@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the ResUNet hot path (BASELINE.json: 128^3 x 4ch volumes/sec fwd+bwd at 1/2/4/8 MI355X).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+A "step" is one data-parallel training step on synthetic 128^3 4-modality crops, per-GPU batch 4 (BASELINE
+configs[2]/[3]; weak scaling): UNet forward + Dice/BCE criterion + backward + RCCL all-reduce of the criterion
+sums and of the flat gradient buffer + Adam(amsgrad) -- every kernel hand-written HIP behind the C-ABI.  Inputs
+are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=1 it also carries
+  roofline     : the dominant kernel (conv3_f32_kernel<4,8,8,1>, the 16->16 3x3x3 conv at 128^3) timed live with HIP
+                 events on the launch stream: algorithmic FLOPs / average launch time vs the f32 MFMA peak,
+  cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample,
+  fwd          : forward-only volumes/s at batch 1 (BASELINE configs[1]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table: v_mfma_f32_16x16x4_f32, dense
+FWD_GFLOP_PER_VOL = 299.37        # algorithmic conv FLOPs per 128^3 volume, forward
+FWDBWD_GFLOP_PER_VOL = 890.87     # forward + backward
+
+
+def synth(n, size, seed, device):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((n, 4, size, size, size), dtype=np.float32)).to(device)
+    u = torch.from_numpy(rng.random((n, 1, size, size, size), dtype=np.float32)).to(device)
+    g = torch.cat([u > 0.70, u > 0.80, u > 0.90], dim=1).float().contiguous()       # nested WT >= TC >= ET
+    return x, g
+
+
+def init_params(backend, seed=1337):
+    """Random-init weights of the reference architecture: the weight_init.py distributions."""
+    flat = backend.new_flat()
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    for name, (shape, off, _dead) in backend.engine.layout.entries.items():
+        n = int(np.prod(shape))
+        if len(shape) == 5:
+            fan_in = shape[1] * shape[2] * shape[3] * shape[4]
+            v = torch.randn(n, generator=gen) * float(np.sqrt(2.0 / ((1 + 0.01 ** 2) * fan_in)))
+        elif name.endswith("conv_output.bias"):
+            v = torch.randn(n, generator=gen)
+        elif name.endswith(".weight"):
+            v = torch.rand(n, generator=gen) + 0.5
+        else:
+            v = torch.rand(n, generator=gen) - 0.5
+        flat[off:off + n] = v.to(flat.device)
+    return flat
+
+
+def time_region(fn, iters, distributed):
+    import torch.distributed as dist
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_probe(batch, size, launches=20):
+    """Dominant kernel: 3x3x3 conv 16->16 at size^3 (4 forward + 4 data-gradient launches of it per L0 block pair per step).
+    Timed with HIP events on the stream the kernel is launched on (torch's current stream)."""
+    from brats2019_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda")
+    x = torch.randn(batch, 16, size, size, size, device=dev)
+    w = torch.randn(16, 16, 3, 3, 3, device=dev) * 0.05
+    y = torch.empty_like(x)
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(batch, 16, 16, size, size, size, 3), dev)
+
+    def launch():
+        L.check(lib.ru_conv3d_fwd(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "conv")
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches          # includes the ~2 us weight-pack kernel that precedes each conv launch
+    flops = 2.0 * 27 * 16 * 16 * batch * size ** 3
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_conv3_l0.json")
+    if os.path.exists(prof):
+        try:
+            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": "conv3_f32_kernel<4,8,8,1> (3x3x3 conv 16->16, %d x %d^3)" % (batch, size),
+            "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+            "algorithmic_bytes_per_launch": int(2 * 16 * batch * size ** 3 * 4)}
+
+
+def cpu_baseline(size):
+    """The CPU oracle = the reference's op sequence on torch CPU, fwd+loss+bwd, batch 1."""
+    from oracle import resunet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = O.make_params(1337, **O.DEFAULT_CFG)
+    x, g = O.make_input(1, size, size, size), O.make_target(1, size, size, size)
+    O.forward_backward(params, x, g, **O.DEFAULT_CFG)                   # warm-up (cold call is several x slower)
+    t0 = time.perf_counter()
+    O.forward_backward(params, x, g, **O.DEFAULT_CFG)
+    dt = time.perf_counter() - t0
+    p = O.to_torch(params)
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        O.unet_forward(p, xt, **O.DEFAULT_CFG)
+        t1 = time.perf_counter()
+        O.unet_forward(p, xt, **O.DEFAULT_CFG)
+        dtf = time.perf_counter() - t1
+    return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": "1 timed fwd+loss+bwd step of one %d^3 x4ch volume (batch 1, fp32, torch CPU %s) after 1 warm-up step" % (size, torch.__version__),
+            "fwd_only_value": round(1.0 / dtf, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[2]: 4)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
+    args = ap.parse_args()
+
+    from brats2019_amd import parallel as P
+    rank, local, world = P.init_process_group_from_env("nccl")
+    distributed = world > 1
+    if world != max(args.gpus, 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    backend = P.HipBackend(device=dev)
+    flat = init_params(backend)                      # same seed on every rank: identical replicas
+    stepper = P.DataParallelStep(backend, flat)
+    x, g = synth(args.batch, args.size, 1000 + rank, dev)
+
+    last = {}
+
+    def one_step():
+        last["loss"] = stepper.step(x, g)[0]
+
+    for _ in range(args.warmup):
+        one_step()
+    dt = time_region(one_step, args.steps, distributed)
+    vols = args.batch * world * args.steps
+    value = vols / dt
+    loss = float(last["loss"])
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss %r" % loss)
+
+    out = {
+        "metric": "volumes_per_sec_fwd_bwd_128cubed_x4ch", "value": round(value, 3), "unit": "volumes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ResUNet([1,2,2,4],[1,1,1,1],[16,32,64,128],3) training step: fwd + Dice/BCE + bwd + grad all-reduce + Adam(amsgrad); "
+                               "%d^3 x 4ch synthetic crops, per-GPU batch %d (BASELINE configs[2], weak-scaled as configs[3])" % (args.size, args.batch),
+                   "global_batch": args.batch * world, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "in_channels": 4,
+                   "parallelism": "dp%d" % world, "precision": "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
+        "final_loss": round(loss, 6),
+        "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        # forward-only (BASELINE configs[1]: fp32 forward, batch 1)
+        x1 = x[:1].contiguous()
+        fwd = lambda: backend.forward(flat, x1, training=False)
+        for _ in range(2):
+            fwd()
+        it = max(5, args.steps)
+        dtf = time_region(fwd, it, False)
+        out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3),
+                      "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2)}
+        out["roofline"] = roofline_probe(args.batch, args.size)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Build libresunet_hip.so (gfx950) in-tree with hipcc.  `python -m brats2019_amd.build [--force]`.
+
+One `hipcc -c` per translation unit (run in parallel), then one link.  The shared library lands in
+brats2019_amd/lib/ (git-ignored, but it travels to the GPU box with the gpurun snapshot).  Objects are
+rebuilt only when a source or header is newer.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+OBJDIR = os.path.join(PKG, "build")
+LIB = os.path.join(LIBDIR, "libresunet_hip.so")
+SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "pointwise.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if not force and not _stale(obj, [path] + HEADERS):
+        return obj, ""
+    cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, r.stderr
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    for _, warn in results:
+        if warn.strip() and verbose:
+            sys.stderr.write(warn)
+    if force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024))
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,870 @@
+// engine.hip -- C-ABI entry points of libresunet_hip.so and the whole-network executor (ru_unet_*).
+//
+// The executor walks the topology of model.UNet (model.py:309-433) once per call and enqueues every kernel on
+// the caller's stream; all scratch (activations kept for backward, packed weights, reduction partials) is
+// carved out of the caller's workspace by a bump allocator whose layout is a pure function of the shapes, so
+// the same walk in "dry" mode is the workspace-size query.  No hipMalloc, no synchronisation.
+//
+// Forward dataflow of one Residual block (model.py:99-117), C channels:
+//   x --conv3--> y1 (+tile stats) --finalize--> (scale1, shift1)
+//   y1 --conv3 with fused lrelu(y1*scale1+shift1) on load--> y2 (+tile stats) --finalize--> (scale2, shift2)
+//   out = x + lrelu(y2*scale2+shift2)                               (one streaming pass)
+// i.e. the GroupNorm-apply + LeakyReLU between the two convolutions never touches HBM.
+#include "ru_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace ru {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return RU_EHIP;
+}
+
+constexpr float kSlope = 1e-2f;   // LeakyReLU(1e-2), model.py:93-94,352
+constexpr int kGroups = 8;        // GroupNorm(8, C), model.py:95-96,338
+constexpr float kEps = 1e-5f;
+constexpr int kInCh = 4;          // model.py:336
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool dry = true, failed = false;
+    float* alloc(size_t nfloats) {
+        const size_t bytes = align_up(nfloats * sizeof(float), 256);
+        const size_t o = off;
+        off += bytes;
+        if (dry) return nullptr;
+        if (off > cap) { failed = true; return nullptr; }
+        return reinterpret_cast<float*>(base + o);
+    }
+};
+
+#define RU_RUN(call)                      \
+    do {                                  \
+        if (!A.dry) {                     \
+            if (A.failed) { set_error("workspace too small"); return RU_ENOMEM; } \
+            const int rc__ = (call);      \
+            if (rc__ != RU_OK) return rc__; \
+        }                                 \
+    } while (0)
+
+__global__ void gn_scale_shift_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                      const float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift, int N, int C, int G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C, g = c / (C / G);
+    const float a = gamma[c] * rstd[n * G + g];
+    scale[i] = a;
+    shift[i] = beta[c] - mean[n * G + g] * a;
+}
+
+}  // namespace ru
+
+using namespace ru;
+
+// ====================================================================== engine
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int dims[5];
+    size_t offset, numel;
+    bool dead;
+};
+
+struct BlockP {           // parameter indices of one Residual (model.py:81-97)
+    int down = -1, conv1 = -1, conv2 = -1, n1w = -1, n1b = -1, n2w = -1, n2b = -1;
+    int cin_down = 0, c = 0;
+    // packed-weight slots (offsets in floats into the pack region)
+    size_t pk_f1 = 0, pk_f2 = 0, pk_d1 = 0, pk_d2 = 0, pk_downT = 0;
+};
+
+struct GNSave {
+    float *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+struct BlockSave {
+    const BlockP* bp = nullptr;
+    const float* xprev = nullptr;   // input before the optional down-sampling conv
+    float* xs2d = nullptr;          // space-to-depth of xprev (down blocks)
+    const float* x = nullptr;       // block input (after down-sampling)
+    float *y1 = nullptr, *y2 = nullptr, *out = nullptr;
+    GNSave g1, g2;
+    int N = 0, C = 0, D = 0, H = 0, W = 0;   // extents of x / y / out
+};
+
+struct DecSave {
+    const float* z = nullptr;      // coarse input
+    float *u = nullptr, *v = nullptr, *c = nullptr;
+    const float* skip = nullptr;
+    int level = 0;
+};
+
+struct ru_unet {
+    int depth = 0, nout = 0;
+    std::vector<int> enc, dec, ch;
+    std::vector<ParamInfo> params;
+    size_t total = 0;
+    std::vector<std::vector<BlockP>> enc_blocks, dec_blocks;
+    std::vector<BlockP> first_blocks;
+    std::vector<int> up_w, dec1_w;
+    std::vector<size_t> pk_upT, pk_decT;
+    int conv_in = -1, nin_w = -1, nin_b = -1, conv_out_w = -1, conv_out_b = -1;
+    size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
+
+    // state of the last forward
+    bool have_fwd = false, training = false;
+    int N = 0, D = 0, H = 0, W = 0;
+    char* ws = nullptr;
+    size_t ws_bytes = 0, fwd_end = 0;
+    float* pack = nullptr;
+    const float* x_in = nullptr;
+    float *y0 = nullptr, *t0 = nullptr, *probs = nullptr;
+    GNSave g0;
+    const float* head_in = nullptr;
+    std::vector<BlockSave> first_s;
+    std::vector<std::vector<BlockSave>> enc_s, dec_s;
+    std::vector<DecSave> dstage;
+    std::vector<const float*> skips;
+    std::vector<GNSave> gn_order;
+};
+
+static int add_param(ru_unet* h, const std::string& name, std::initializer_list<int> dims, bool dead = false) {
+    ParamInfo p;
+    p.name = name;
+    p.ndim = (int)dims.size();
+    size_t n = 1;
+    int i = 0;
+    for (int d : dims) { p.dims[i++] = d; n *= (size_t)d; }
+    for (; i < 5; ++i) p.dims[i] = 1;
+    p.offset = h->total;
+    p.numel = n;
+    p.dead = dead;
+    h->total += n;
+    h->params.push_back(p);
+    return (int)h->params.size() - 1;
+}
+
+static BlockP add_block(ru_unet* h, const std::string& prefix, int cin_down, int c, bool dead = false) {
+    BlockP b;
+    b.c = c;
+    b.cin_down = cin_down;
+    if (cin_down > 0) b.down = add_param(h, prefix + "downsample.0.weight", {c, cin_down, 2, 2, 2}, dead);
+    b.conv1 = add_param(h, prefix + "conv1.conv1.weight", {c, c, 3, 3, 3}, dead);
+    b.conv2 = add_param(h, prefix + "conv2.conv1.weight", {c, c, 3, 3, 3}, dead);
+    b.n1w = add_param(h, prefix + "norm1.weight", {c}, dead);
+    b.n1b = add_param(h, prefix + "norm1.bias", {c}, dead);
+    b.n2w = add_param(h, prefix + "norm2.weight", {c}, dead);
+    b.n2b = add_param(h, prefix + "norm2.bias", {c}, dead);
+    return b;
+}
+
+static std::string fmt(const char* f, int a, int b = 0) {
+    char buf[128];
+    snprintf(buf, sizeof(buf), f, a, b);
+    return buf;
+}
+
+static void assign_block_packs(ru_unet* h, BlockP& b) {
+    const size_t n = conv3_packed_floats(b.c, b.c);
+    b.pk_f1 = h->pk_total; h->pk_total += n;
+    b.pk_f2 = h->pk_total; h->pk_total += n;
+    b.pk_d1 = h->pk_total; h->pk_total += n;
+    b.pk_d2 = h->pk_total; h->pk_total += n;
+    if (b.down >= 0) { b.pk_downT = h->pk_total; h->pk_total += (size_t)8 * b.cin_down * b.c; }
+}
+
+extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const int* decoder_layers,
+                                    const int* number_of_channels, int number_of_outputs) {
+    if (depth < 2 || depth > 8 || !encoder_layers || !decoder_layers || !number_of_channels || number_of_outputs < 1) {
+        set_error("ru_unet_create: bad configuration");
+        return nullptr;
+    }
+    for (int i = 0; i < depth; ++i) {
+        if (number_of_channels[i] % kGroups != 0 || number_of_channels[i] <= 0 || encoder_layers[i] < 1 || decoder_layers[i] < 1) {
+            set_error("ru_unet_create: channels must be positive multiples of 8 (GroupNorm(8, C)) and layer counts >= 1");
+            return nullptr;
+        }
+    }
+    ru_unet* h = new ru_unet();
+    h->depth = depth;
+    h->nout = number_of_outputs;
+    h->enc.assign(encoder_layers, encoder_layers + depth);
+    h->dec.assign(decoder_layers, decoder_layers + depth);
+    h->ch.assign(number_of_channels, number_of_channels + depth);
+    const std::vector<int>& ch = h->ch;
+    // reference state_dict() order (model.py:320-357): encoder_convs, upsampling, decoder_convs, decoder_convs1x1,
+    // conv_input, norm_input, conv_first, conv_output
+    h->enc_blocks.resize(depth - 1);
+    for (int i = 0; i < depth - 1; ++i)
+        for (int j = 0; j < h->enc[i + 1]; ++j)
+            h->enc_blocks[i].push_back(add_block(h, fmt("encoder_convs.%d.%d.", i, j), j == 0 ? ch[i] : 0, ch[i + 1]));
+    for (int i = 0; i < depth - 1; ++i) h->up_w.push_back(add_param(h, fmt("upsampling.%d.1.weight", i), {ch[i], ch[i + 1], 1, 1, 1}));
+    h->dec_blocks.resize(depth);
+    for (int i = 0; i < depth; ++i)
+        for (int j = 0; j < h->dec[i]; ++j)
+            h->dec_blocks[i].push_back(add_block(h, fmt("decoder_convs.%d.%d.", i, j), 0, ch[i], i == depth - 1));
+    for (int i = 0; i < depth; ++i)
+        h->dec1_w.push_back(add_param(h, fmt("decoder_convs1x1.%d.weight", i), {ch[i], 2 * ch[i], 1, 1, 1}, i == depth - 1));
+    h->conv_in = add_param(h, "conv_input.weight", {ch[0], kInCh, 3, 3, 3});
+    h->nin_w = add_param(h, "norm_input.weight", {ch[0]});
+    h->nin_b = add_param(h, "norm_input.bias", {ch[0]});
+    for (int j = 0; j < h->enc[0]; ++j) h->first_blocks.push_back(add_block(h, fmt("conv_first.%d.", j), 0, ch[0]));
+    h->conv_out_w = add_param(h, "conv_output.weight", {number_of_outputs, ch[0], 3, 3, 3});
+    h->conv_out_b = add_param(h, "conv_output.bias", {number_of_outputs});
+    // packed-weight region layout
+    h->pk_total = 0;
+    h->pk_in = h->pk_total; h->pk_total += conv3_packed_floats(kInCh, ch[0]);
+    h->pk_out = h->pk_total; h->pk_total += conv3_packed_floats(ch[0], number_of_outputs);
+    h->pk_out_d = h->pk_total; h->pk_total += conv3_packed_floats(number_of_outputs, ch[0]);
+    for (auto& b : h->first_blocks) assign_block_packs(h, b);
+    for (auto& lv : h->enc_blocks) for (auto& b : lv) assign_block_packs(h, b);
+    for (int i = 0; i < depth - 1; ++i) for (auto& b : h->dec_blocks[i]) assign_block_packs(h, b);
+    for (int i = 0; i < depth - 1; ++i) {
+        h->pk_upT.push_back(h->pk_total); h->pk_total += (size_t)ch[i + 1] * ch[i];
+        h->pk_decT.push_back(h->pk_total); h->pk_total += (size_t)2 * ch[i] * ch[i];
+    }
+    return h;
+}
+
+extern "C" void ru_unet_destroy(ru_unet_t h) { delete h; }
+extern "C" int ru_unet_param_count(ru_unet_t h) { return h ? (int)h->params.size() : 0; }
+extern "C" const char* ru_unet_param_name(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr; }
+extern "C" int ru_unet_param_ndim(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].ndim : 0; }
+extern "C" int ru_unet_param_dim(ru_unet_t h, int i, int d) { return (h && i >= 0 && i < (int)h->params.size() && d >= 0 && d < 5) ? h->params[i].dims[d] : 0; }
+extern "C" size_t ru_unet_param_offset(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].offset : 0; }
+extern "C" size_t ru_unet_param_total(ru_unet_t h) { return h ? h->total : 0; }
+extern "C" int ru_unet_param_is_dead(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? (int)h->params[i].dead : 0; }
+
+// ---------------------------------------------------------------------- forward pieces
+static inline const float* P(const ru_unet* h, const float* params, int idx) { return params ? params + h->params[idx].offset : nullptr; }
+static inline float* G(const ru_unet* h, float* grads, int idx) { return grads ? grads + h->params[idx].offset : nullptr; }
+
+static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
+    float* pk = h->pack;
+    auto blk = [&](const BlockP& b) -> int {
+        RU_RUN(conv3_pack_weights(P(h, params, b.conv1), pk + b.pk_f1, b.c, b.c, 0, s));
+        RU_RUN(conv3_pack_weights(P(h, params, b.conv2), pk + b.pk_f2, b.c, b.c, 0, s));
+        if (h->training) {
+            RU_RUN(conv3_pack_weights(P(h, params, b.conv1), pk + b.pk_d1, b.c, b.c, 1, s));
+            RU_RUN(conv3_pack_weights(P(h, params, b.conv2), pk + b.pk_d2, b.c, b.c, 1, s));
+        }
+        if (b.down >= 0) RU_RUN(transpose_launch(P(h, params, b.down), pk + b.pk_downT, b.c, 8 * b.cin_down, s));
+        return RU_OK;
+    };
+    RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), pk + h->pk_in, kInCh, h->ch[0], 0, s));
+    RU_RUN(conv3_pack_weights(P(h, params, h->conv_out_w), pk + h->pk_out, h->ch[0], h->nout, 0, s));
+    if (h->training) RU_RUN(conv3_pack_weights(P(h, params, h->conv_out_w), pk + h->pk_out_d, h->ch[0], h->nout, 1, s));
+    for (auto& b : h->first_blocks) { int rc = blk(b); if (rc) return rc; }
+    for (auto& lv : h->enc_blocks) for (auto& b : lv) { int rc = blk(b); if (rc) return rc; }
+    for (int i = 0; i < h->depth - 1; ++i) for (auto& b : h->dec_blocks[i]) { int rc = blk(b); if (rc) return rc; }
+    for (int i = 0; i < h->depth - 1; ++i) {
+        RU_RUN(transpose_launch(P(h, params, h->up_w[i]), pk + h->pk_upT[i], h->ch[i], h->ch[i + 1], s));
+        RU_RUN(transpose_launch(P(h, params, h->dec1_w[i]), pk + h->pk_decT[i], h->ch[i], 2 * h->ch[i], s));
+    }
+    return RU_OK;
+}
+
+// y = conv3(x) with optional fused input transform, tile statistics -> GNSave (mean/rstd/scale/shift)
+static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, float* y, const GNSave* in_gn,
+                    const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W) {
+    const int nblk = conv3_tiles_per_sample(N, Cin, Cout, D, H, W);
+    float* partials = A.alloc((size_t)N * Cout * nblk * 2);
+    out_gn.mean = A.alloc((size_t)N * kGroups);
+    out_gn.rstd = A.alloc((size_t)N * kGroups);
+    out_gn.scale = A.alloc((size_t)N * Cout);
+    out_gn.shift = A.alloc((size_t)N * Cout);
+    Conv3Args a{};
+    a.x = x; a.wp = wp; a.y = y;
+    a.in_scale = in_gn ? in_gn->scale : nullptr;
+    a.in_shift = in_gn ? in_gn->shift : nullptr;
+    a.in_slope = kSlope;
+    a.stat_partials = partials;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    RU_RUN(conv3_launch(a, s));
+    RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
+                              (size_t)D * H * W, kGroups, kEps, s));
+    h->gn_order.push_back(out_gn);
+    return RU_OK;
+}
+
+static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, const BlockP& bp, const float* xprev,
+                     int N, int D, int H, int W /* extents of xprev */, BlockSave& sv, const float** out) {
+    sv = BlockSave();
+    sv.bp = &bp;
+    sv.xprev = xprev;
+    const int C = bp.c;
+    const float* x = xprev;
+    if (bp.down >= 0) {
+        const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+        const size_t Vo = (size_t)Do * Ho * Wo;
+        sv.xs2d = A.alloc((size_t)N * 8 * bp.cin_down * Vo);
+        float* xd = A.alloc((size_t)N * C * Vo);
+        RU_RUN(s2d_launch(xprev, sv.xs2d, N, bp.cin_down, D, H, W, s));
+        Conv1Args c1{};
+        c1.x0 = sv.xs2d; c1.C0 = 8 * bp.cin_down; c1.wT = h->pack + bp.pk_downT; c1.ldw = C; c1.y = xd; c1.out_slope = 1.f;
+        c1.N = N; c1.Cout = C; c1.V = Vo;
+        RU_RUN(conv1_launch(c1, s));
+        x = xd; D = Do; H = Ho; W = Wo;
+    }
+    const size_t V = (size_t)D * H * W;
+    sv.x = x; sv.N = N; sv.C = C; sv.D = D; sv.H = H; sv.W = W;
+    sv.y1 = A.alloc((size_t)N * C * V);
+    int rc = conv3_gn(h, A, s, x, h->pack + bp.pk_f1, sv.y1, nullptr, P(h, params, bp.n1w), P(h, params, bp.n1b), sv.g1, N, C, C, D, H, W);
+    if (rc) return rc;
+    sv.y2 = A.alloc((size_t)N * C * V);
+    rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
+    if (rc) return rc;
+    sv.out = A.alloc((size_t)N * C * V);
+    RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
+    *out = sv.out;
+    return RU_OK;
+}
+
+static int unet_forward_impl(ru_unet* h, const float* params, const float* x, float* probs_out, Arena& A, hipStream_t s) {
+    const int N = h->N, depth = h->depth;
+    std::vector<int> Dl(depth), Hl(depth), Wl(depth);
+    for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
+    auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
+    h->gn_order.clear();
+    h->pack = A.alloc(h->pk_total);
+    int rc = pack_all(h, params, A, s);
+    if (rc) return rc;
+
+    // stem: conv_input -> norm_input (no activation, model.py:412-413)
+    const int C0 = h->ch[0];
+    h->x_in = x;
+    h->y0 = A.alloc((size_t)N * C0 * Vl(0));
+    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    if (rc) return rc;
+    h->t0 = A.alloc((size_t)N * C0 * Vl(0));
+    RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
+    const float* cur = h->t0;
+    h->first_s.assign(h->first_blocks.size(), BlockSave());
+    for (size_t j = 0; j < h->first_blocks.size(); ++j) {
+        rc = block_fwd(h, params, A, s, h->first_blocks[j], cur, N, Dl[0], Hl[0], Wl[0], h->first_s[j], &cur);
+        if (rc) return rc;
+    }
+    // encoder (model.py:416-418)
+    h->skips.assign(depth - 1, nullptr);
+    h->enc_s.assign(depth - 1, {});
+    for (int i = 0; i < depth - 1; ++i) {
+        h->skips[i] = cur;
+        h->enc_s[i].assign(h->enc_blocks[i].size(), BlockSave());
+        for (size_t j = 0; j < h->enc_blocks[i].size(); ++j) {
+            const int lv = j == 0 ? i : i + 1;
+            rc = block_fwd(h, params, A, s, h->enc_blocks[i][j], cur, N, Dl[lv], Hl[lv], Wl[lv], h->enc_s[i][j], &cur);
+            if (rc) return rc;
+        }
+    }
+    // decoder (model.py:420-426)
+    h->dstage.assign(depth - 1, DecSave());
+    h->dec_s.assign(depth - 1, {});
+    for (int i = depth - 2; i >= 0; --i) {
+        DecSave& ds = h->dstage[i];
+        ds.level = i;
+        ds.z = cur;
+        ds.skip = h->skips[i];
+        const int Ci = h->ch[i], Cc = h->ch[i + 1];
+        ds.u = A.alloc((size_t)N * Cc * Vl(i));
+        RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        ds.v = A.alloc((size_t)N * Ci * Vl(i));
+        Conv1Args c1{};
+        c1.x0 = ds.u; c1.C0 = Cc; c1.wT = h->pack + h->pk_upT[i]; c1.ldw = Ci; c1.y = ds.v; c1.out_slope = kSlope;   // + LeakyReLU (model.py:422)
+        c1.N = N; c1.Cout = Ci; c1.V = Vl(i);
+        RU_RUN(conv1_launch(c1, s));
+        ds.c = A.alloc((size_t)N * Ci * Vl(i));
+        Conv1Args c2{};
+        c2.x0 = ds.skip; c2.C0 = Ci; c2.x1 = ds.v; c2.C1 = Ci;                                                        // cat([skip, up]) (model.py:424)
+        c2.wT = h->pack + h->pk_decT[i]; c2.ldw = Ci; c2.y = ds.c; c2.out_slope = 1.f; c2.N = N; c2.Cout = Ci; c2.V = Vl(i);
+        RU_RUN(conv1_launch(c2, s));
+        cur = ds.c;
+        h->dec_s[i].assign(h->dec_blocks[i].size(), BlockSave());
+        for (size_t j = 0; j < h->dec_blocks[i].size(); ++j) {
+            rc = block_fwd(h, params, A, s, h->dec_blocks[i][j], cur, N, Dl[i], Hl[i], Wl[i], h->dec_s[i][j], &cur);
+            if (rc) return rc;
+        }
+    }
+    // head: conv_output + bias + sigmoid (model.py:429-431)
+    h->head_in = cur;
+    float* pdst = probs_out;
+    if (h->training) { h->probs = A.alloc((size_t)N * h->nout * Vl(0)); pdst = h->probs; }
+    Conv3Args a{};
+    a.x = cur; a.wp = h->pack + h->pk_out; a.bias = P(h, params, h->conv_out_b); a.y = pdst; a.sigmoid = 1;
+    a.N = N; a.Cin = C0; a.Cout = h->nout; a.D = Dl[0]; a.H = Hl[0]; a.W = Wl[0];
+    RU_RUN(conv3_launch(a, s));
+    if (h->training && !A.dry) {
+        hipError_t e = hipMemcpyAsync(probs_out, h->probs, (size_t)N * h->nout * Vl(0) * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(probs)");
+    }
+    return RU_OK;
+}
+
+// ---------------------------------------------------------------------- backward pieces
+// GroupNorm(+LeakyReLU) backward: d_act -> dy (gradient w.r.t. the raw conv output), dgamma/dbeta written
+static int gn_bwd(Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
+                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V) {
+    const int nblk = gn_bwd_tiles(V);
+    float* part = A.alloc((size_t)N * C * nblk * 2);
+    float* coef = A.alloc((size_t)N * C * 3);
+    RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+    RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s));
+    RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
+    return RU_OK;
+}
+
+static int wgrad3_run(Arena& A, hipStream_t s, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W) {
+    Wgrad3Args w{};
+    w.x = x; w.dy = dy; w.dw = dw;
+    w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
+    w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
+    w.ws = A.alloc(w.ws_bytes / sizeof(float));
+    w.N = N; w.Cin = Cin; w.Cout = Cout; w.D = D; w.H = H; w.W = W;
+    RU_RUN(wgrad3_launch(w, s));
+    return RU_OK;
+}
+
+static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, float* dw, int ldw, int N, int Cin, int Cout, size_t V) {
+    Wgrad1Args w{};
+    w.x = x; w.dy = dy; w.dw = dw; w.ldw = ldw;
+    w.ws_bytes = wgrad1_workspace_bytes(N, Cin, Cout, V);
+    w.ws = A.alloc(w.ws_bytes / sizeof(float));
+    w.N = N; w.Cin = Cin; w.Cout = Cout; w.V = V;
+    RU_RUN(wgrad1_launch(w, s));
+    return RU_OK;
+}
+
+// Residual backward: dout -> d(xprev); parameter gradients into `grads`
+static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hipStream_t s, const BlockSave& sv, const float* dout,
+                     const float** dxprev_out) {
+    const BlockP& bp = *sv.bp;
+    const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
+    const size_t V = (size_t)D * H * W;
+    float* dy2 = A.alloc((size_t)N * C * V);
+    int rc = gn_bwd(A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
+    if (rc) return rc;
+    rc = wgrad3_run(A, s, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W);
+    if (rc) return rc;
+    float* da1 = A.alloc((size_t)N * C * V);
+    Conv3Args d2{};
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    RU_RUN(conv3_launch(d2, s));
+    float* dy1 = A.alloc((size_t)N * C * V);
+    rc = gn_bwd(A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
+    if (rc) return rc;
+    rc = wgrad3_run(A, s, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W);
+    if (rc) return rc;
+    float* dx = A.alloc((size_t)N * C * V);
+    Conv3Args d1{};
+    d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout;       // skip path: dx = dout + dgrad(conv1)
+    d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
+    RU_RUN(conv3_launch(d1, s));
+    if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
+    // down-sampling conv backward (Appendix A2): 1x1 over the space-to-depth view
+    const int Cp = bp.cin_down;
+    rc = wgrad1_run(A, s, sv.xs2d, dx, G(h, grads, bp.down), 8 * Cp, N, 8 * Cp, C, V);
+    if (rc) return rc;
+    float* t = A.alloc((size_t)N * 8 * Cp * V);
+    Conv1Args c1{};
+    c1.x0 = dx; c1.C0 = C; c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp; c1.y = t; c1.out_slope = 1.f; c1.N = N; c1.Cout = 8 * Cp; c1.V = V;
+    RU_RUN(conv1_launch(c1, s));
+    float* dxp = A.alloc((size_t)N * Cp * V * 8);
+    RU_RUN(d2s_launch(t, dxp, N, Cp, 2 * D, 2 * H, 2 * W, s));
+    *dxprev_out = dxp;
+    return RU_OK;
+}
+
+static int unet_backward_impl(ru_unet* h, const float* params, const float* dprobs, float* grads, float* dx_in, Arena& A, hipStream_t s) {
+    const int N = h->N, depth = h->depth;
+    std::vector<int> Dl(depth), Hl(depth), Wl(depth);
+    for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
+    auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
+    const int C0 = h->ch[0];
+    RU_RUN(fill_launch(grads, 0.f, h->total, s));     // dead parameters keep zero gradient
+    // head
+    float* dlog = A.alloc((size_t)N * h->nout * Vl(0));
+    RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
+    int rc = wgrad3_run(A, s, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0]);
+    if (rc) return rc;
+    {
+        const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
+        float* wsp = A.alloc(wsb / sizeof(float) + 1);
+        RU_RUN(bias_grad_launch(dlog, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
+    }
+    float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
+    Conv3Args dh{};
+    dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
+    RU_RUN(conv3_launch(dh, s));
+    const float* dcur = dcur_buf;
+    std::vector<const float*> dskip(depth - 1, nullptr);
+    // decoder stages, reverse of execution order (forward ran i = depth-2 .. 0)
+    for (int i = 0; i <= depth - 2; ++i) {
+        for (int j = (int)h->dec_s[i].size() - 1; j >= 0; --j) {
+            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur);
+            if (rc) return rc;
+        }
+        const DecSave& ds = h->dstage[i];
+        const int Ci = h->ch[i], Cc = h->ch[i + 1];
+        const size_t V = Vl(i);
+        // decoder_convs1x1[i] over cat([skip, v]) (model.py:424-425)
+        const float* wdec = P(h, params, h->dec1_w[i]);          // [Ci][2Ci]
+        float* gdec = G(h, grads, h->dec1_w[i]);
+        rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V);
+        if (rc) return rc;
+        rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V);
+        if (rc) return rc;
+        float* dsk = A.alloc((size_t)N * Ci * V);
+        float* dv = A.alloc((size_t)N * Ci * V);
+        Conv1Args a1{};
+        a1.x0 = dcur; a1.C0 = Ci; a1.wT = wdec; a1.ldw = 2 * Ci; a1.y = dsk; a1.out_slope = 1.f; a1.N = N; a1.Cout = Ci; a1.V = V;
+        RU_RUN(conv1_launch(a1, s));
+        Conv1Args a2 = a1;
+        a2.wT = A.dry ? nullptr : wdec + Ci; a2.y = dv;
+        RU_RUN(conv1_launch(a2, s));
+        dskip[i] = dsk;
+        // LeakyReLU backward from the output v (model.py:422; Appendix A4), then upsampling[i][1] (1x1) and Trilinear
+        float* dpre = A.alloc((size_t)N * Ci * V);
+        RU_RUN(lrelu_bwd_launch(ds.v, dv, dpre, (size_t)N * Ci * V, kSlope, s));
+        rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V);
+        if (rc) return rc;
+        float* du = A.alloc((size_t)N * Cc * V);
+        Conv1Args a3{};
+        a3.x0 = dpre; a3.C0 = Ci; a3.wT = P(h, params, h->up_w[i]); a3.ldw = Cc; a3.y = du; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
+        RU_RUN(conv1_launch(a3, s));
+        float* dz = A.alloc((size_t)N * Cc * Vl(i + 1));
+        RU_RUN(up2_bwd_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        dcur = dz;
+    }
+    // encoder levels, deepest first; the skip gradient joins at each level's input
+    for (int i = depth - 2; i >= 0; --i) {
+        for (int j = (int)h->enc_s[i].size() - 1; j >= 0; --j) {
+            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur);
+            if (rc) return rc;
+        }
+        float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
+        RU_RUN(add_launch(dcur, dskip[i], sum, (size_t)N * h->ch[i] * Vl(i), s));
+        dcur = sum;
+    }
+    for (int j = (int)h->first_s.size() - 1; j >= 0; --j) {
+        rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur);
+        if (rc) return rc;
+    }
+    // norm_input (no activation: slope 1) and conv_input
+    float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
+    rc = gn_bwd(A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
+    if (rc) return rc;
+    rc = wgrad3_run(A, s, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    if (rc) return rc;
+    if (dx_in) {
+        // d/d(input): not needed by training (train.py:201-210), offered for gradient checks
+        float* wpd = A.alloc(conv3_packed_floats(C0, kInCh));
+        RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), wpd, kInCh, C0, 1, s));
+        Conv3Args di{};
+        di.x = dy0; di.wp = wpd; di.y = dx_in; di.N = N; di.Cin = C0; di.Cout = kInCh; di.D = Dl[0]; di.H = Hl[0]; di.W = Wl[0];
+        RU_RUN(conv3_launch(di, s));
+    }
+    return RU_OK;
+}
+
+static int check_dims(ru_unet* h, int N, int D, int H, int W) {
+    const int m = 1 << (h->depth - 1);
+    RU_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "ru_unet: bad extents");
+    RU_REQUIRE(D % m == 0 && H % m == 0 && W % m == 0, "ru_unet: D,H,W must be divisible by %d (model.py:361 stride-2 convs)", m);
+    return RU_OK;
+}
+
+extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int W, int training) {
+    if (!h || check_dims(h, N, D, H, W) != RU_OK) return 0;
+    ru_unet tmp = *h;            // dry walk on a copy: does not disturb a live forward state
+    tmp.N = N; tmp.D = D; tmp.H = H; tmp.W = W; tmp.training = training != 0;
+    Arena A;
+    A.dry = true;
+    if (unet_forward_impl(&tmp, nullptr, nullptr, nullptr, A, nullptr) != RU_OK) return 0;
+    if (training) {
+        if (unet_backward_impl(&tmp, nullptr, nullptr, nullptr, (float*)1, A, nullptr) != RU_OK) return 0;
+    }
+    return A.off + 4096;
+}
+
+extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x, float* probs, int N, int D, int H, int W, int training,
+                               void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(h && params && x && probs && ws, "ru_unet_forward: null argument");
+    int rc = check_dims(h, N, D, H, W);
+    if (rc) return rc;
+    h->have_fwd = false;
+    h->N = N; h->D = D; h->H = H; h->W = W; h->training = training != 0;
+    h->ws = (char*)ws; h->ws_bytes = ws_bytes;
+    Arena A;
+    A.dry = false; A.base = (char*)ws; A.cap = ws_bytes;
+    rc = unet_forward_impl(h, params, x, probs, A, (hipStream_t)stream);
+    if (rc) return rc;
+    if (A.failed) { set_error("ru_unet_forward: workspace too small (%zu bytes given)", ws_bytes); return RU_ENOMEM; }
+    h->fwd_end = A.off;
+    h->have_fwd = true;
+    return RU_OK;
+}
+
+extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx, ru_stream_t stream) {
+    RU_REQUIRE(h && params && dprobs && grads, "ru_unet_backward: null argument");
+    if (!h->have_fwd || !h->training) { set_error("ru_unet_backward: needs a preceding training-mode ru_unet_forward"); return RU_ESTATE; }
+    Arena A;
+    A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end;
+    int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream);
+    if (rc) return rc;
+    if (A.failed) { set_error("ru_unet_backward: workspace too small"); return RU_ENOMEM; }
+    return RU_OK;
+}
+
+extern "C" int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream) {
+    RU_REQUIRE(h && h->have_fwd, "ru_unet_gn_stats: no forward state");
+    if (idx < 0) return (int)h->gn_order.size();
+    RU_REQUIRE(idx < (int)h->gn_order.size() && mean && rstd, "ru_unet_gn_stats: bad index");
+    const size_t bytes = (size_t)h->N * kGroups * sizeof(float);
+    hipError_t e = hipMemcpyAsync(mean, h->gn_order[idx].mean, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rstd, h->gn_order[idx].rstd, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "ru_unet_gn_stats");
+    return RU_OK;
+}
+
+// ====================================================================== op-level C-ABI
+extern "C" const char* ru_last_error(void) { return g_err; }
+extern "C" int ru_version(void) { return 100; }
+extern "C" int ru_device_ok(void) {
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0;
+}
+
+struct WsCarver {
+    char* base; size_t cap, off = 0; bool failed = false;
+    WsCarver(void* b, size_t c) : base((char*)b), cap(c) {}
+    float* take(size_t nfloats) {
+        const size_t bytes = align_up(nfloats * sizeof(float), 256);
+        if (!base || off + bytes > cap) { failed = true; return nullptr; }
+        float* p = (float*)(base + off);
+        off += bytes;
+        return p;
+    }
+};
+#define RU_WS_OK(w) do { if ((w).failed) { set_error("workspace too small"); return RU_ENOMEM; } } while (0)
+
+extern "C" size_t ru_conv3d_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int k) {
+    size_t b = 4096;
+    if (k == 3) {
+        b += align_up(conv3_packed_floats(Cin, Cout) * 4, 256) + align_up(conv3_packed_floats(Cout, Cin) * 4, 256);
+        b += align_up(wgrad3_workspace_bytes(N, Cin, Cout, D, H, W), 256) + align_up(bias_grad_workspace_bytes(N, Cout, (size_t)D * H * W), 256);
+    } else if (k == 1) {
+        b += align_up((size_t)Cin * Cout * 4, 256) + align_up(wgrad1_workspace_bytes(N, Cin, Cout, (size_t)D * H * W), 256);
+    } else if (k == 2) {
+        const size_t Vo = (size_t)(D / 2) * (H / 2) * (W / 2);
+        b += align_up((size_t)N * 8 * Cin * Vo * 4, 256) + align_up((size_t)8 * Cin * Cout * 4, 256) + align_up(wgrad1_workspace_bytes(N, 8 * Cin, Cout, Vo), 256);
+    }
+    return b;
+}
+
+extern "C" int ru_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int D, int H, int W, int k,
+                             void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && w && y, "ru_conv3d_fwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver C(ws, ws_bytes);
+    if (k == 3) {
+        float* wp = C.take(conv3_packed_floats(Cin, Cout));
+        RU_WS_OK(C);
+        int rc = conv3_pack_weights(w, wp, Cin, Cout, 0, s);
+        if (rc) return rc;
+        Conv3Args a{};
+        a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+        return conv3_launch(a, s);
+    }
+    RU_REQUIRE(!bias, "ru_conv3d_fwd: bias only supported for k=3 (model.py:348)");
+    if (k == 1) {
+        float* wT = C.take((size_t)Cin * Cout);
+        RU_WS_OK(C);
+        int rc = transpose_launch(w, wT, Cout, Cin, s);
+        if (rc) return rc;
+        Conv1Args a{};
+        a.x0 = x; a.C0 = Cin; a.wT = wT; a.ldw = Cout; a.y = y; a.out_slope = 1.f; a.N = N; a.Cout = Cout; a.V = (size_t)D * H * W;
+        return conv1_launch(a, s);
+    }
+    if (k == 2) {
+        RU_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "ru_conv3d_fwd: k=2 needs even extents");
+        const size_t Vo = (size_t)(D / 2) * (H / 2) * (W / 2);
+        float* xs = C.take((size_t)N * 8 * Cin * Vo);
+        float* wT = C.take((size_t)8 * Cin * Cout);
+        RU_WS_OK(C);
+        int rc = s2d_launch(x, xs, N, Cin, D, H, W, s);
+        if (rc) return rc;
+        rc = transpose_launch(w, wT, Cout, 8 * Cin, s);
+        if (rc) return rc;
+        Conv1Args a{};
+        a.x0 = xs; a.C0 = 8 * Cin; a.wT = wT; a.ldw = Cout; a.y = y; a.out_slope = 1.f; a.N = N; a.Cout = Cout; a.V = Vo;
+        return conv1_launch(a, s);
+    }
+    set_error("ru_conv3d_fwd: unsupported kernel size %d", k);
+    return RU_EINVAL;
+}
+
+extern "C" int ru_conv3d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int D, int H, int W, int k,
+                                  void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(dy && w && dx, "ru_conv3d_bwd_data: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver C(ws, ws_bytes);
+    if (k == 3) {
+        float* wp = C.take(conv3_packed_floats(Cout, Cin));
+        RU_WS_OK(C);
+        int rc = conv3_pack_weights(w, wp, Cin, Cout, 1, s);
+        if (rc) return rc;
+        Conv3Args a{};
+        a.x = dy; a.wp = wp; a.y = dx; a.N = N; a.Cin = Cout; a.Cout = Cin; a.D = D; a.H = H; a.W = W;
+        return conv3_launch(a, s);
+    }
+    if (k == 1) {
+        Conv1Args a{};
+        a.x0 = dy; a.C0 = Cout; a.wT = w; a.ldw = Cin; a.y = dx; a.out_slope = 1.f; a.N = N; a.Cout = Cin; a.V = (size_t)D * H * W;
+        return conv1_launch(a, s);
+    }
+    if (k == 2) {
+        RU_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "ru_conv3d_bwd_data: k=2 needs even extents");
+        const size_t Vo = (size_t)(D / 2) * (H / 2) * (W / 2);
+        float* t = C.take((size_t)N * 8 * Cin * Vo);
+        RU_WS_OK(C);
+        Conv1Args a{};
+        a.x0 = dy; a.C0 = Cout; a.wT = w; a.ldw = 8 * Cin; a.y = t; a.out_slope = 1.f; a.N = N; a.Cout = 8 * Cin; a.V = Vo;
+        int rc = conv1_launch(a, s);
+        if (rc) return rc;
+        return d2s_launch(t, dx, N, Cin, D, H, W, s);
+    }
+    set_error("ru_conv3d_bwd_data: unsupported kernel size %d", k);
+    return RU_EINVAL;
+}
+
+extern "C" int ru_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int Cout, int D, int H, int W, int k,
+                                    void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && dy && dw, "ru_conv3d_bwd_weight: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver C(ws, ws_bytes);
+    if (k == 3) {
+        Wgrad3Args a{};
+        a.x = x; a.dy = dy; a.dw = dw; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+        a.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
+        a.ws = C.take(a.ws_bytes / 4);
+        RU_WS_OK(C);
+        int rc = wgrad3_launch(a, s);
+        if (rc) return rc;
+        if (db) {
+            const size_t b = bias_grad_workspace_bytes(N, Cout, (size_t)D * H * W);
+            float* p = C.take(b / 4 + 1);
+            RU_WS_OK(C);
+            return bias_grad_launch(dy, db, N, Cout, (size_t)D * H * W, p, b, s);
+        }
+        return RU_OK;
+    }
+    RU_REQUIRE(!db, "ru_conv3d_bwd_weight: bias only supported for k=3");
+    if (k == 1) {
+        Wgrad1Args a{};
+        a.x = x; a.dy = dy; a.dw = dw; a.ldw = Cin; a.N = N; a.Cin = Cin; a.Cout = Cout; a.V = (size_t)D * H * W;
+        a.ws_bytes = wgrad1_workspace_bytes(N, Cin, Cout, a.V);
+        a.ws = C.take(a.ws_bytes / 4);
+        RU_WS_OK(C);
+        return wgrad1_launch(a, s);
+    }
+    if (k == 2) {
+        RU_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "ru_conv3d_bwd_weight: k=2 needs even extents");
+        const size_t Vo = (size_t)(D / 2) * (H / 2) * (W / 2);
+        float* xs = C.take((size_t)N * 8 * Cin * Vo);
+        RU_WS_OK(C);
+        int rc = s2d_launch(x, xs, N, Cin, D, H, W, s);
+        if (rc) return rc;
+        Wgrad1Args a{};
+        a.x = xs; a.dy = dy; a.dw = dw; a.ldw = 8 * Cin; a.N = N; a.Cin = 8 * Cin; a.Cout = Cout; a.V = Vo;
+        a.ws_bytes = wgrad1_workspace_bytes(N, 8 * Cin, Cout, Vo);
+        a.ws = C.take(a.ws_bytes / 4);
+        RU_WS_OK(C);
+        return wgrad1_launch(a, s);
+    }
+    set_error("ru_conv3d_bwd_weight: unsupported kernel size %d", k);
+    return RU_EINVAL;
+}
+
+extern "C" size_t ru_groupnorm_workspace_bytes(int N, int C, size_t V) {
+    return 4096 + align_up((size_t)N * C * gn_stats_tiles(V) * 2 * 4, 256) + 5 * align_up((size_t)N * C * 4, 256) + align_up((size_t)N * C * 3 * 4, 256);
+}
+
+extern "C" int ru_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean, float* rstd,
+                                int N, int C, size_t V, int G, float eps, float slope, void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && gamma && beta && y && mean && rstd, "ru_groupnorm_fwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver Cw(ws, ws_bytes);
+    const int nblk = gn_stats_tiles(V);
+    float* part = Cw.take((size_t)N * C * nblk * 2);
+    float* scale = Cw.take((size_t)N * C);
+    float* shift = Cw.take((size_t)N * C);
+    RU_WS_OK(Cw);
+    int rc = gn_stats_launch(x, part, N, C, V, s);
+    if (rc) return rc;
+    rc = gn_finalize_launch(part, nblk, gamma, beta, mean, rstd, scale, shift, N, C, V, G, eps, s);
+    if (rc) return rc;
+    return gn_apply_launch(x, scale, shift, residual, y, N, C, V, slope, s);
+}
+
+extern "C" int ru_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd, const float* dy,
+                                float* dx, float* dgamma, float* dbeta, int N, int C, size_t V, int G, float slope,
+                                void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && gamma && beta && mean && rstd && dy && dx, "ru_groupnorm_bwd: null argument");
+    RU_REQUIRE(C % G == 0, "ru_groupnorm_bwd: C %% G != 0");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver Cw(ws, ws_bytes);
+    const int nblk = gn_bwd_tiles(V);
+    float* part = Cw.take((size_t)N * C * nblk * 2);
+    float* scale = Cw.take((size_t)N * C);
+    float* shift = Cw.take((size_t)N * C);
+    float* coef = Cw.take((size_t)N * C * 3);
+    RU_WS_OK(Cw);
+    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, gamma, beta, mean, rstd, scale, shift, N, C, G);
+    RU_CHECK_LAUNCH("gn_scale_shift_kernel");
+    int rc = gn_bwd_reduce_launch(x, dy, scale, shift, mean, rstd, slope, part, N, C, V, G, s);
+    if (rc) return rc;
+    rc = gn_bwd_finalize_launch(part, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s);
+    if (rc) return rc;
+    return gn_bwd_apply_launch(x, dy, scale, shift, coef, slope, dx, N, C, V, s);
+}
+
+extern "C" int ru_leaky_relu_fwd(const float* x, float* y, size_t n, float slope, ru_stream_t stream) { return lrelu_fwd_launch(x, y, n, slope, (hipStream_t)stream); }
+extern "C" int ru_leaky_relu_bwd(const float* y, const float* dy, float* dx, size_t n, float slope, ru_stream_t stream) { return lrelu_bwd_launch(y, dy, dx, n, slope, (hipStream_t)stream); }
+extern "C" int ru_upsample2x_trilinear_fwd(const float* x, float* y, int N, int C, int D, int H, int W, ru_stream_t stream) { return up2_fwd_launch(x, y, N, C, D, H, W, (hipStream_t)stream); }
+extern "C" int ru_upsample2x_trilinear_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, ru_stream_t stream) { return up2_bwd_launch(dy, dx, N, C, D, H, W, (hipStream_t)stream); }
+extern "C" int ru_sigmoid_fwd(const float* x, float* y, size_t n, ru_stream_t stream) { return sigmoid_launch(x, y, n, (hipStream_t)stream); }
+
+extern "C" size_t ru_criterion_workspace_bytes(int N, int C, size_t V) { return 4096 + (size_t)N * C * crit_tiles(V) * 3 * sizeof(float); }
+extern "C" int ru_criterion_sums(const float* p, const float* g, double* sums, int N, int C, size_t V, float bg_weight, void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(p && g && sums, "ru_criterion_sums: null argument");
+    return crit_sums_launch(p, g, sums, N, C, V, bg_weight, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int ru_criterion_grad(const float* p, const float* g, const double* sums, double count, float w_dice, float w_bce, float bg_weight,
+                                 float priority, float* dp, int N, int C, size_t V, ru_stream_t stream) {
+    RU_REQUIRE(p && g && sums && dp && count > 0, "ru_criterion_grad: bad argument");
+    return crit_grad_launch(p, g, sums, count, w_dice, w_bce, bg_weight, priority, dp, N, C, V, (hipStream_t)stream);
+}
+extern "C" int ru_criterion_value(const double* sums_host, int C, double count, double priority, double* dice, double* bce) {
+    RU_REQUIRE(sums_host && C > 0 && count > 0, "ru_criterion_value: bad argument");
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) acc += 2.0 * (sums_host[c] + 1e-6) / (sums_host[C + c] + 2e-6);   // loss.py:114-117
+    if (dice) *dice = priority * (1.0 - acc / C);                                                  // loss.py:122
+    if (bce) *bce = -sums_host[2 * C] / count;                                                     // loss.py:79
+    return RU_OK;
+}
+extern "C" int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, int step, ru_stream_t stream) {
+    RU_REQUIRE(w && g && m && v && vmax, "ru_adam_amsgrad_step: null argument");
+    return adam_launch(w, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}

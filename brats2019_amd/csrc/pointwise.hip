@@ -1,0 +1,714 @@
+// pointwise.hip -- the HBM-bound kernels of the ResUNet path (gfx950): 1x1x1 convolution, space-to-depth for the
+// 2x2x2 stride-2 convolution, GroupNorm statistics / apply / backward, LeakyReLU, sigmoid, trilinear x2 up-sampling
+// and its transpose, the Dice+BCE criterion, and Adam(amsgrad).  All are streaming kernels: 16-byte coalesced
+// accesses along W (NCDHW), one pass per tensor, two-stage deterministic reductions (no float atomics).
+#include "ru_common.h"
+
+namespace ru {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over a 256-thread block; result valid in thread 0 (and broadcast through `buf[0]`)
+__device__ __forceinline__ float block_sum(float v, float* buf) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return buf[0] + buf[1] + buf[2] + buf[3];
+}
+__device__ __forceinline__ double block_sum_d(double v, double* buf) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return buf[0] + buf[1] + buf[2] + buf[3];
+}
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+static inline unsigned grid1d(size_t n, int per_block, unsigned cap = 1u << 20) {
+    size_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+// ------------------------------------------------------------------ 1x1x1 convolution (model.py:393,401), VALU with scalar weights
+// Each thread owns VEC consecutive voxels and 16 output channels; the weight of (c, o) is wave-uniform, so it is
+// fetched by scalar loads and used as the SGPR operand of v_fmac_f32.  The channel concat of model.py:424 is the
+// two-pointer input (x0 then x1) -- the cat is never materialised.
+template <int VEC>
+__global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
+    const int n = blockIdx.z;
+    const int co0 = blockIdx.y * 16;
+    const size_t V = a.V;
+    const size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (v >= V) return;
+    float acc[16][VEC];
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[o][k] = 0.f;
+    int widx[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) widx[o] = (co0 + o < a.Cout) ? co0 + o : a.Cout - 1;
+
+    const float* xp = a.x0 + (size_t)n * a.C0 * V + v;
+    const float* wr = a.wT;
+#pragma unroll 4
+    for (int c = 0; c < a.C0; ++c) {
+        float xv[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + (size_t)c * V);
+            xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+        } else {
+            xv[0] = xp[(size_t)c * V];
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const float w = wr[(size_t)c * a.ldw + widx[o]];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[o][k] += w * xv[k];
+        }
+    }
+    if (a.x1) {
+        const float* xq = a.x1 + (size_t)n * a.C1 * V + v;
+        const float* wq = a.wT + (size_t)a.C0 * a.ldw;
+#pragma unroll 4
+        for (int c = 0; c < a.C1; ++c) {
+            float xv[VEC];
+            if (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xq + (size_t)c * V);
+                xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+            } else {
+                xv[0] = xq[(size_t)c * V];
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const float w = wq[(size_t)c * a.ldw + widx[o]];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[o][k] += w * xv[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        if (co0 + o >= a.Cout) continue;
+        const size_t idx = ((size_t)n * a.Cout + co0 + o) * V + v;
+        float r[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = lrelu(acc[o][k], a.out_slope);
+        if (a.add) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) r[k] += a.add[idx + k];
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(a.y + idx) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+        else a.y[idx] = r[0];
+    }
+}
+
+int conv1_launch(const Conv1Args& a, hipStream_t s) {
+    RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cout, "conv1: bad shape");
+    const bool vec = (a.V % 4) == 0;
+    const size_t nthreads = vec ? a.V / 4 : a.V;
+    dim3 grid((unsigned)((nthreads + 255) / 256), (unsigned)cdiv(a.Cout, 16), (unsigned)a.N);
+    if (vec) hipLaunchKernelGGL(conv1_kernel<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), 0, s, a);
+    RU_CHECK_LAUNCH("conv1_kernel");
+    return RU_OK;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int c = i / rows, r = i % rows;      // dst index i = c*rows + r
+    dst[i] = src[(size_t)r * cols + c];
+}
+int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, s, src, dst, rows, cols);
+    RU_CHECK_LAUNCH("transpose_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ space-to-depth / depth-to-space (2x2x2 stride-2 conv, model.py:361-363)
+// The non-overlapping 2^3 patches make the down-sampling conv a 1x1x1 conv over 8*Cin channels;
+// channel order c*8 + i*4 + j*2 + k matches the flattening of the reference weight [Cout][Cin][2][2][2].
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int D, int H, int W) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)NC * Do * Ho * Wo;
+    const size_t Vo = (size_t)Do * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        size_t r = i / Wo;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int zo = (int)(r % Do);
+        const size_t nc = r / Do;
+        const float* xp = x + ((nc * D + 2 * zo) * H + 2 * yo) * (size_t)W + 2 * xo;
+        float* yp = y + nc * 8 * Vo + ((size_t)zo * Ho + yo) * Wo + xo;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const float2 t = *reinterpret_cast<const float2*>(xp + ((size_t)(ij >> 1) * H + (ij & 1)) * W);
+            yp[(size_t)(ij * 2) * Vo] = t.x;
+            yp[(size_t)(ij * 2 + 1) * Vo] = t.y;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void d2s_kernel(const float* __restrict__ y, float* __restrict__ x, int NC, int D, int H, int W) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)NC * Do * Ho * Wo;
+    const size_t Vo = (size_t)Do * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        size_t r = i / Wo;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int zo = (int)(r % Do);
+        const size_t nc = r / Do;
+        float* xp = x + ((nc * D + 2 * zo) * H + 2 * yo) * (size_t)W + 2 * xo;
+        const float* yp = y + nc * 8 * Vo + ((size_t)zo * Ho + yo) * Wo + xo;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            float2 t;
+            t.x = yp[(size_t)(ij * 2) * Vo];
+            t.y = yp[(size_t)(ij * 2 + 1) * Vo];
+            *reinterpret_cast<float2*>(xp + ((size_t)(ij >> 1) * H + (ij & 1)) * W) = t;
+        }
+    }
+}
+int s2d_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {
+    RU_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "s2d: extents must be even");
+    const size_t total = (size_t)N * C * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, x, y, N * C, D, H, W);
+    RU_CHECK_LAUNCH("s2d_kernel");
+    return RU_OK;
+}
+int d2s_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s) {
+    RU_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "d2s: extents must be even");
+    const size_t total = (size_t)N * C * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(d2s_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, y, x, N * C, D, H, W);
+    RU_CHECK_LAUNCH("d2s_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm (model.py:95-96,338)
+constexpr int GN_CHUNK = 8192;   // elements of one (n,c) row reduced by one workgroup
+int gn_stats_tiles(size_t V) { return (int)((V + GN_CHUNK - 1) / GN_CHUNK); }
+int gn_bwd_tiles(size_t V) { return gn_stats_tiles(V); }
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partials, size_t V, int nblk) {
+    __shared__ float buf[4];
+    const size_t row = blockIdx.y;              // n*C + c
+    const size_t v0 = (size_t)blockIdx.x * GN_CHUNK;
+    const size_t v1 = v0 + GN_CHUNK < V ? v0 + GN_CHUNK : V;
+    const float* xp = x + row * V;
+    float s1 = 0.f, s2 = 0.f;
+    if ((V & 3) == 0) {
+        for (size_t v = v0 + threadIdx.x * 4; v < v1; v += 1024) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + v);
+            s1 += (t.x + t.y) + (t.z + t.w);
+            s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+    } else {
+        for (size_t v = v0 + threadIdx.x; v < v1; v += 256) { const float t = xp[v]; s1 += t; s2 += t * t; }
+    }
+    s1 = block_sum(s1, buf);
+    s2 = block_sum(s2, buf);
+    if (threadIdx.x == 0) {
+        float* p = partials + (row * nblk + blockIdx.x) * 2;
+        p[0] = s1; p[1] = s2;
+    }
+}
+int gn_stats_launch(const float* x, float* partials, int N, int C, size_t V, hipStream_t s) {
+    const int nblk = gn_stats_tiles(V);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, N * C), dim3(256), 0, s, x, partials, V, nblk);
+    RU_CHECK_LAUNCH("gn_stats_kernel");
+    return RU_OK;
+}
+
+// one workgroup per (n, g): float64 combine of the per-tile float32 (sum, sumsq) partials
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift, int C, size_t V, int G, float eps) {
+    __shared__ double buf[4];
+    __shared__ float sh[2];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G;
+    const float* p = partials + ((size_t)n * C + (size_t)g * cpg) * nblk * 2;   // cpg*nblk contiguous (sum,sumsq) pairs
+    const int cnt = cpg * nblk;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 256) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
+    s1 = block_sum_d(s1, buf);
+    s2 = block_sum_d(s2, buf);
+    if (threadIdx.x == 0) {
+        const double m = (double)cpg * (double)V;
+        const double mu = s1 / m;
+        double var = s2 / m - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const double rs = 1.0 / sqrt(var + (double)eps);
+        sh[0] = (float)mu; sh[1] = (float)rs;
+        mean[blockIdx.x] = (float)mu;
+        rstd[blockIdx.x] = (float)rs;
+    }
+    __syncthreads();
+    if (threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        const float a = gamma[c] * sh[1];
+        scale[n * C + c] = a;
+        shift[n * C + c] = beta[c] - sh[0] * a;
+    }
+}
+int gn_finalize_launch(const float* partials, int nblk, const float* gamma, const float* beta, float* mean, float* rstd,
+                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s) {
+    RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, s, partials, nblk, gamma, beta, mean, rstd, scale, shift, C, V, G, eps);
+    RU_CHECK_LAUNCH("gn_finalize_kernel");
+    return RU_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, float* __restrict__ y, size_t V, float slope) {
+    const size_t row = blockIdx.y;
+    const float a = scale[row], b = shift[row];
+    const size_t base = row * V;
+    for (size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; v < V; v += (size_t)gridDim.x * 256 * VEC) {
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + base + v);
+            float4 o;
+            o.x = lrelu(t.x * a + b, slope); o.y = lrelu(t.y * a + b, slope);
+            o.z = lrelu(t.z * a + b, slope); o.w = lrelu(t.w * a + b, slope);
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(res + base + v);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(y + base + v) = o;
+        } else {
+            float o = lrelu(x[base + v] * a + b, slope);
+            if (res) o += res[base + v];
+            y[base + v] = o;
+        }
+    }
+}
+static inline dim3 rows_grid(size_t V, int vec, int rows) {
+    size_t bx = (V / vec + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)rows);
+}
+int gn_apply_launch(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                    int N, int C, size_t V, float slope, hipStream_t s) {
+    if (V % 4 == 0) hipLaunchKernelGGL(gn_apply_kernel<4>, rows_grid(V, 4, N * C), dim3(256), 0, s, x, scale, shift, res, y, V, slope);
+    else hipLaunchKernelGGL(gn_apply_kernel<1>, rows_grid(V, 1, N * C), dim3(256), 0, s, x, scale, shift, res, y, V, slope);
+    RU_CHECK_LAUNCH("gn_apply_kernel");
+    return RU_OK;
+}
+
+// backward: S1 = sum dyh, S2 = sum dyh * xhat per (n,c) tile, dyh = dy * lrelu'(pre), pre = x*scale+shift
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk) {
+    __shared__ float buf[4];
+    const size_t row = blockIdx.y;
+    const int n = (int)(row / C), c = (int)(row % C);
+    const int g = c / (C / G);
+    const float a = scale[row], b = shift[row];
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    const size_t v0 = (size_t)blockIdx.x * GN_CHUNK;
+    const size_t v1 = v0 + GN_CHUNK < V ? v0 + GN_CHUNK : V;
+    const float* xp = x + row * V;
+    const float* dp = dy + row * V;
+    float s1 = 0.f, s2 = 0.f;
+    if ((V & 3) == 0) {
+        for (size_t v = v0 + threadIdx.x * 4; v < v1; v += 1024) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + v);
+            const float4 d = *reinterpret_cast<const float4*>(dp + v);
+            const float tx[4] = {t.x, t.y, t.z, t.w};
+            const float dx[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dh = (tx[k] * a + b) > 0.f ? dx[k] : dx[k] * slope;
+                s1 += dh;
+                s2 += dh * ((tx[k] - mu) * rs);
+            }
+        }
+    } else {
+        for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
+            const float t = xp[v], d = dp[v];
+            const float dh = (t * a + b) > 0.f ? d : d * slope;
+            s1 += dh;
+            s2 += dh * ((t - mu) * rs);
+        }
+    }
+    s1 = block_sum(s1, buf);
+    s2 = block_sum(s2, buf);
+    if (threadIdx.x == 0) {
+        float* p = partials + (row * nblk + blockIdx.x) * 2;
+        p[0] = s1; p[1] = s2;
+    }
+}
+int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s) {
+    const int nblk = gn_bwd_tiles(V);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, N * C), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk);
+    RU_CHECK_LAUNCH("gn_bwd_reduce_kernel");
+    return RU_OK;
+}
+
+// one workgroup per group g, walking the batch in order (deterministic dgamma/dbeta)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G) {
+    __shared__ double buf[4];
+    __shared__ double S[2][256];
+    const int g = blockIdx.x;
+    const int cpg = C / G;
+    double dg_acc = 0.0, db_acc = 0.0;   // threads < cpg accumulate their channel over n
+    for (int n = 0; n < N; ++n) {
+        for (int j = 0; j < cpg; ++j) {
+            const float* p = partials + ((size_t)n * C + g * cpg + j) * nblk * 2;
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = threadIdx.x; i < nblk; i += 256) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
+            s1 = block_sum_d(s1, buf);
+            s2 = block_sum_d(s2, buf);
+            if (threadIdx.x == 0) { S[0][j] = s1; S[1][j] = s2; }
+        }
+        __syncthreads();
+        double m1 = 0.0, m2 = 0.0;
+        for (int j = 0; j < cpg; ++j) {
+            const double gm = (double)gamma[g * cpg + j];
+            m1 += gm * S[0][j];
+            m2 += gm * S[1][j];
+        }
+        const double m = (double)cpg * (double)V;
+        m1 /= m; m2 /= m;
+        const double mu = (double)mean[n * G + g], rs = (double)rstd[n * G + g];
+        if (threadIdx.x < cpg) {
+            const int c = g * cpg + threadIdx.x;
+            float* q = coef + ((size_t)n * C + c) * 3;
+            q[0] = (float)(rs * (double)gamma[c]);
+            q[1] = (float)(-rs * rs * m2);
+            q[2] = (float)(rs * rs * m2 * mu - rs * m1);
+            db_acc += S[0][threadIdx.x];
+            dg_acc += S[1][threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        if (dgamma) dgamma[c] = (float)dg_acc;
+        if (dbeta) dbeta[c] = (float)db_acc;
+    }
+}
+int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
+                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s) {
+    RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    RU_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+    return RU_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ coef, float slope,
+                                                           float* __restrict__ dx, size_t V) {
+    const size_t row = blockIdx.y;
+    const float a = scale[row], b = shift[row];
+    const float cA = coef[row * 3], cB = coef[row * 3 + 1], cC = coef[row * 3 + 2];
+    const size_t base = row * V;
+    for (size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; v < V; v += (size_t)gridDim.x * 256 * VEC) {
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + base + v);
+            const float4 d = *reinterpret_cast<const float4*>(dy + base + v);
+            float4 o;
+            o.x = cA * ((t.x * a + b) > 0.f ? d.x : d.x * slope) + (cB * t.x + cC);
+            o.y = cA * ((t.y * a + b) > 0.f ? d.y : d.y * slope) + (cB * t.y + cC);
+            o.z = cA * ((t.z * a + b) > 0.f ? d.z : d.z * slope) + (cB * t.z + cC);
+            o.w = cA * ((t.w * a + b) > 0.f ? d.w : d.w * slope) + (cB * t.w + cC);
+            *reinterpret_cast<float4*>(dx + base + v) = o;
+        } else {
+            const float t = x[base + v], d = dy[base + v];
+            dx[base + v] = cA * ((t * a + b) > 0.f ? d : d * slope) + (cB * t + cC);
+        }
+    }
+}
+int gn_bwd_apply_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef,
+                        float slope, float* dx, int N, int C, size_t V, hipStream_t s) {
+    if (V % 4 == 0) hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, rows_grid(V, 4, N * C), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, V);
+    else hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, rows_grid(V, 1, N * C), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, V);
+    RU_CHECK_LAUNCH("gn_bwd_apply_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ flat elementwise
+enum { EW_LRELU = 0, EW_LRELU_BWD = 1, EW_SIGMOID = 2, EW_SIGMOID_BWD = 3, EW_ADD = 4, EW_FILL = 5 };
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n, float p) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float r;
+        if (OP == EW_LRELU) r = lrelu(a[i], p);
+        else if (OP == EW_LRELU_BWD) r = a[i] > 0.f ? b[i] : b[i] * p;            // a = OUTPUT of the LeakyReLU, b = dy
+        else if (OP == EW_SIGMOID) r = 1.f / (1.f + expf(-a[i]));
+        else if (OP == EW_SIGMOID_BWD) { const float q = a[i]; r = b[i] * q * (1.f - q); }   // a = p, b = dp
+        else if (OP == EW_ADD) r = a[i] + b[i];
+        else r = p;
+        y[i] = r;
+    }
+}
+template <int OP>
+static int ew_launch(const float* a, const float* b, float* y, size_t n, float p, hipStream_t s, const char* name) {
+    if (n == 0) return RU_OK;
+    hipLaunchKernelGGL(ew_kernel<OP>, dim3(grid1d(n, 256 * 4, 8192)), dim3(256), 0, s, a, b, y, n, p);
+    RU_CHECK_LAUNCH(name);
+    return RU_OK;
+}
+int lrelu_fwd_launch(const float* x, float* y, size_t n, float slope, hipStream_t s) { return ew_launch<EW_LRELU>(x, nullptr, y, n, slope, s, "lrelu"); }
+int lrelu_bwd_launch(const float* yv, const float* dy, float* dx, size_t n, float slope, hipStream_t s) { return ew_launch<EW_LRELU_BWD>(yv, dy, dx, n, slope, s, "lrelu_bwd"); }
+int sigmoid_launch(const float* x, float* y, size_t n, hipStream_t s) { return ew_launch<EW_SIGMOID>(x, nullptr, y, n, 0.f, s, "sigmoid"); }
+int sigmoid_bwd_launch(const float* p, const float* dp, float* dz, size_t n, hipStream_t s) { return ew_launch<EW_SIGMOID_BWD>(p, dp, dz, n, 0.f, s, "sigmoid_bwd"); }
+int add_launch(const float* a, const float* b, float* y, size_t n, hipStream_t s) { return ew_launch<EW_ADD>(a, b, y, n, 0.f, s, "add"); }
+int fill_launch(float* p, float v, size_t n, hipStream_t s) { return ew_launch<EW_FILL>(nullptr, nullptr, p, n, v, s, "fill"); }
+
+// ------------------------------------------------------------------ trilinear x2, align_corners=False (model.py:12-14)
+// source index of output o: src = max(o/2 - 0.25, 0); i0 = floor(src); l1 = src - i0; i1 = i0 + (i0 < n-1)
+__device__ __forceinline__ void up2_src(int o, int n, int& i0, int& i1, float& l0, float& l1) {
+    float src = 0.5f * (float)o - 0.25f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H;
+    const size_t total = (size_t)NC * Do * Ho * W;     // one thread per output x-PAIR (2k, 2k+1)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % W);
+        size_t r = i / W;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int zo = (int)(r % Do);
+        const size_t nc = r / Do;
+        int z0, z1, y0, y1; float lz0, lz1, ly0, ly1;
+        up2_src(zo, D, z0, z1, lz0, lz1);
+        up2_src(yo, H, y0, y1, ly0, ly1);
+        const int km = k > 0 ? k - 1 : 0, kp = k < W - 1 ? k + 1 : k;
+        const float* p00 = x + ((nc * D + z0) * H + y0) * (size_t)W;
+        const float* p01 = x + ((nc * D + z0) * H + y1) * (size_t)W;
+        const float* p10 = x + ((nc * D + z1) * H + y0) * (size_t)W;
+        const float* p11 = x + ((nc * D + z1) * H + y1) * (size_t)W;
+        // even output 2k: src = k - 0.25 -> (k-1: 0.25, k: 0.75), except k == 0 -> (0: 1, 1: 0)
+        // odd output 2k+1: src = k + 0.25 -> (k: 0.75, k+1 clamped: 0.25)
+        const float e0 = k > 0 ? 0.25f : 1.f, e1 = k > 0 ? 0.75f : 0.f;
+        const int ei0 = k > 0 ? km : 0, ei1 = k > 0 ? k : (W > 1 ? 1 : 0);
+        const float ev = lz0 * (ly0 * (e0 * p00[ei0] + e1 * p00[ei1]) + ly1 * (e0 * p01[ei0] + e1 * p01[ei1])) +
+                         lz1 * (ly0 * (e0 * p10[ei0] + e1 * p10[ei1]) + ly1 * (e0 * p11[ei0] + e1 * p11[ei1]));
+        const float ov = lz0 * (ly0 * (0.75f * p00[k] + 0.25f * p00[kp]) + ly1 * (0.75f * p01[k] + 0.25f * p01[kp])) +
+                         lz1 * (ly0 * (0.75f * p10[k] + 0.25f * p10[kp]) + ly1 * (0.75f * p11[k] + 0.25f * p11[kp]));
+        float* yp = y + ((nc * Do + zo) * Ho + yo) * (size_t)(2 * W) + 2 * k;
+        *reinterpret_cast<float2*>(yp) = make_float2(ev, ov);
+    }
+}
+int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * C * 2 * D * 2 * H * W;
+    hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, x, y, N * C, D, H, W);
+    RU_CHECK_LAUNCH("up2_fwd_kernel");
+    return RU_OK;
+}
+
+// transpose of the above in gather form: dx[k] collects from outputs 2k-1 .. 2k+2 on each axis
+__device__ __forceinline__ float up2_coef(int o, int n, int k) {
+    int i0, i1; float l0, l1;
+    up2_src(o, n, i0, i1, l0, l1);
+    return (i0 == k ? l0 : 0.f) + (i1 == k ? l1 : 0.f);
+}
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)NC * D * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kx = (int)(i % W);
+        size_t r = i / W;
+        const int ky = (int)(r % H); r /= H;
+        const int kz = (int)(r % D);
+        const size_t nc = r / D;
+        float wz[4], wy[4], wx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oz = 2 * kz - 1 + t, oy = 2 * ky - 1 + t, ox = 2 * kx - 1 + t;
+            wz[t] = (oz >= 0 && oz < Do) ? up2_coef(oz, D, kz) : 0.f;
+            wy[t] = (oy >= 0 && oy < Ho) ? up2_coef(oy, H, ky) : 0.f;
+            wx[t] = (ox >= 0 && ox < Wo) ? up2_coef(ox, W, kx) : 0.f;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            if (wz[a] == 0.f) continue;
+            const int oz = 2 * kz - 1 + a;
+            float accy = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (wy[b] == 0.f) continue;
+                const int oy = 2 * ky - 1 + b;
+                const float* p = dy + ((nc * Do + oz) * Ho + oy) * (size_t)Wo;
+                float accx = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ox = 2 * kx - 1 + c;
+                    if (wx[c] != 0.f) accx += wx[c] * p[ox];
+                }
+                accy += wy[b] * accx;
+            }
+            acc += wz[a] * accy;
+        }
+        dx[i] = acc;
+    }
+}
+int up2_bwd_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * C * D * H * W;
+    hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, dy, dx, N * C, D, H, W);
+    RU_CHECK_LAUNCH("up2_bwd_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ bias gradient (conv_output.bias, model.py:348)
+constexpr int BG_CHUNK = 16384;
+size_t bias_grad_workspace_bytes(int N, int C, size_t V) { return (size_t)N * C * ((V + BG_CHUNK - 1) / BG_CHUNK) * sizeof(float); }
+__global__ __launch_bounds__(256) void bias_partial_kernel(const float* __restrict__ dy, float* __restrict__ part, size_t V, int nblk) {
+    __shared__ float buf[4];
+    const size_t row = blockIdx.y;
+    const size_t v0 = (size_t)blockIdx.x * BG_CHUNK;
+    const size_t v1 = v0 + BG_CHUNK < V ? v0 + BG_CHUNK : V;
+    float s1 = 0.f;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) s1 += dy[row * V + v];
+    s1 = block_sum(s1, buf);
+    if (threadIdx.x == 0) part[row * nblk + blockIdx.x] = s1;
+}
+__global__ __launch_bounds__(256) void bias_final_kernel(const float* __restrict__ part, float* __restrict__ db, int N, int C, int nblk) {
+    __shared__ double buf[4];
+    const int c = blockIdx.x;
+    double s1 = 0.0;
+    for (int i = threadIdx.x; i < N * nblk; i += 256) {
+        const int n = i / nblk, b = i % nblk;
+        s1 += (double)part[((size_t)n * C + c) * nblk + b];
+    }
+    s1 = block_sum_d(s1, buf);
+    if (threadIdx.x == 0) db[c] = (float)s1;
+}
+int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < bias_grad_workspace_bytes(N, C, V)) { set_error("bias_grad: workspace too small"); return RU_ENOMEM; }
+    const int nblk = (int)((V + BG_CHUNK - 1) / BG_CHUNK);
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(nblk, N * C), dim3(256), 0, s, dy, (float*)ws, V, nblk);
+    RU_CHECK_LAUNCH("bias_partial_kernel");
+    hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, db, N, C, nblk);
+    RU_CHECK_LAUNCH("bias_final_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ criterion: Dice_loss_joint + BCE_Loss (loss.py:64-79,98-122)
+constexpr int CR_CHUNK = 8192;
+int crit_tiles(size_t V) { return (int)((V + CR_CHUNK - 1) / CR_CHUNK); }
+__global__ __launch_bounds__(256) void crit_partial_kernel(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ part,
+                                                           size_t V, int nblk, float bgw) {
+    __shared__ float buf[4];
+    const size_t row = blockIdx.y;             // n*C + c
+    const size_t v0 = (size_t)blockIdx.x * CR_CHUNK;
+    const size_t v1 = v0 + CR_CHUNK < V ? v0 + CR_CHUNK : V;
+    const float one_eps = (float)(1.0 + 1e-6);   // the float32 value of loss.py:77's (1.+1e-6)
+    float si = 0.f, su = 0.f, sb = 0.f;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
+        const float pv = p[row * V + v], gv = g[row * V + v];
+        si += pv * gv;
+        su += pv * pv + gv;
+        sb += gv * logf(pv + 1e-6f) + bgw * (1.f - gv) * logf(one_eps - pv);
+    }
+    si = block_sum(si, buf);
+    su = block_sum(su, buf);
+    sb = block_sum(sb, buf);
+    if (threadIdx.x == 0) {
+        float* q = part + (row * nblk + blockIdx.x) * 3;
+        q[0] = si; q[1] = su; q[2] = sb;
+    }
+}
+__global__ __launch_bounds__(256) void crit_final_kernel(const float* __restrict__ part, double* __restrict__ sums, int N, int C, int nblk) {
+    __shared__ double buf[4];
+    double bce = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double si = 0.0, su = 0.0, sb = 0.0;
+        for (int i = threadIdx.x; i < N * nblk; i += 256) {
+            const int n = i / nblk, b = i % nblk;
+            const float* q = part + (((size_t)n * C + c) * nblk + b) * 3;
+            si += (double)q[0]; su += (double)q[1]; sb += (double)q[2];
+        }
+        si = block_sum_d(si, buf);
+        su = block_sum_d(su, buf);
+        sb = block_sum_d(sb, buf);
+        if (threadIdx.x == 0) { sums[c] = si; sums[C + c] = su; }
+        bce += sb;
+    }
+    if (threadIdx.x == 0) sums[2 * C] = bce;
+}
+int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C, size_t V, float bgw, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int nblk = crit_tiles(V);
+    if (!ws || ws_bytes < (size_t)N * C * nblk * 3 * sizeof(float)) { set_error("criterion: workspace too small"); return RU_ENOMEM; }
+    hipLaunchKernelGGL(crit_partial_kernel, dim3(nblk, N * C), dim3(256), 0, s, p, g, (float*)ws, V, nblk, bgw);
+    RU_CHECK_LAUNCH("crit_partial_kernel");
+    hipLaunchKernelGGL(crit_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, sums, N, C, nblk);
+    RU_CHECK_LAUNCH("crit_final_kernel");
+    return RU_OK;
+}
+__global__ __launch_bounds__(256) void crit_grad_kernel(const float* __restrict__ p, const float* __restrict__ g, const double* __restrict__ sums,
+                                                        double count, float w_dice, float w_bce, float bgw, float priority,
+                                                        float* __restrict__ dp, int C, size_t V) {
+    const size_t row = blockIdx.y;
+    const int c = (int)(row % C);
+    const double I = sums[c] + 1e-6, U = sums[C + c] + 2e-6;
+    const double k = (double)priority * (2.0 / (double)C) * (double)w_dice;
+    const float cg = (float)(-k / U), cp = (float)(2.0 * k * I / (U * U));
+    const float cb = (float)((double)w_bce / count);
+    const float one_eps = (float)(1.0 + 1e-6);
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+        const float pv = p[row * V + v], gv = g[row * V + v];
+        const float bce = -(gv / (pv + 1e-6f) - bgw * (1.f - gv) / (one_eps - pv));
+        dp[row * V + v] = (cg * gv + cp * pv) + cb * bce;
+    }
+}
+int crit_grad_launch(const float* p, const float* g, const double* sums, double count, float w_dice, float w_bce,
+                     float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s) {
+    hipLaunchKernelGGL(crit_grad_kernel, rows_grid(V, 1, N * C), dim3(256), 0, s, p, g, sums, count, w_dice, w_bce, bgw, priority, dp, C, V);
+    RU_CHECK_LAUNCH("crit_grad_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ Adam(amsgrad=True, weight_decay) (main.py:133-137)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   float* __restrict__ vmax, size_t n, float step_size, float b1, float b2, float eps, float wd,
+                                                   float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float wi = w[i];
+        const float gi = g[i] + wd * wi;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float vm = fmaxf(vmax[i], vi);
+        const float denom = sqrtf(vm) / bc2_sqrt + eps;
+        m[i] = mi; v[i] = vi; vmax[i] = vm;
+        w[i] = wi - step_size * (mi / denom);
+    }
+}
+int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float b1, float b2,
+                float eps, float wd, int step, hipStream_t s) {
+    if (n == 0) return RU_OK;
+    RU_REQUIRE(step >= 1, "adam: step is 1-based");
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256 * 4, 4096)), dim3(256), 0, s, w, g, m, v, vmax, n, (float)((double)lr / bc1), b1, b2, eps, wd,
+                       (float)sqrt(bc2));
+    RU_CHECK_LAUNCH("adam_kernel");
+    return RU_OK;
+}
+
+}  // namespace ru

@@ -1,0 +1,148 @@
+// Internal declarations shared by the HIP translation units of libresunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/resunet_hip.h"
+
+namespace ru {
+
+// thread-local error message (ru_last_error)
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define RU_CHECK_LAUNCH(what)                                  \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return ru::hip_fail(e__, what); \
+    } while (0)
+
+#define RU_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            ru::set_error(__VA_ARGS__);  \
+            return RU_EINVAL;            \
+        }                                \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ------------------------------------------------------------------ conv 3x3x3 (conv3_f32.hip)
+// Implicit GEMM on v_mfma_f32_16x16x4_f32.  Weights must be PACKED: wp[tap][CinP][CoutP] (K-major).
+struct Conv3Args {
+    const float* x;          // [N][Cin][D][H][W]
+    const float* wp;         // packed weights [27][CinP][CoutP]
+    const float* bias;       // [Cout] or null
+    float* y;                // [N][Cout][D][H][W]
+    const float* add;        // same shape as y, added in the epilogue, or null
+    const float* in_scale;   // [N][Cin] fused input transform v -> lrelu(v*scale+shift, in_slope), or null
+    const float* in_shift;
+    float in_slope;
+    float* stat_partials;    // [N][Cout][nblk][2] per-tile (sum, sumsq) of y, or null
+    int sigmoid;             // apply 1/(1+exp(-v)) in the epilogue
+    int N, Cin, Cout, D, H, W;
+    int CinP, CoutP;
+};
+int conv3_cin_pad(int Cin);                       // CinP for a given Cin
+static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
+// number of spatial tiles per sample the kernel will use (== nblk of stat_partials)
+int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_launch(const Conv3Args& a, hipStream_t s);
+// pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:
+// the packed conv maps Cout_f input channels to Cin_f output channels).
+int conv3_pack_weights(const float* w, float* wp, int Cin_f, int Cout_f, int mode, hipStream_t s);
+size_t conv3_packed_floats(int Cin_conv, int Cout_conv);   // for the conv as launched (after any swap)
+
+// ------------------------------------------------------------------ weight gradients (wgrad_f32.hip)
+struct Wgrad3Args {
+    const float* x;          // [N][Cin][D][H][W]  (conv input; fused transform like Conv3Args)
+    const float* dy;         // [N][Cout][D][H][W]
+    const float* in_scale;
+    const float* in_shift;
+    float in_slope;
+    float* dw;               // [Cout][Cin][27]  (overwritten)
+    float* db;               // [Cout] or null (sum of dy)
+    void* ws;                // partials
+    size_t ws_bytes;
+    int N, Cin, Cout, D, H, W;
+};
+size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
+
+// 1x1x1: dw[o][c] = sum_{n,v} dy[n][o][v] * x[n][c][v]; result written to dw[o*ldw + c] (ldw >= Cin)
+struct Wgrad1Args {
+    const float* x;          // [N][Cin][V]
+    const float* dy;         // [N][Cout][V]
+    float* dw;
+    int ldw;
+    void* ws;
+    size_t ws_bytes;
+    int N, Cin, Cout;
+    size_t V;
+};
+size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
+int wgrad1_launch(const Wgrad1Args& a, hipStream_t s);
+
+// ------------------------------------------------------------------ pointwise / small kernels (pointwise.hip)
+// y[n][o][v] = act( sum_c wT[c*ldw + o] * xcat[n][c][v] ) (+ add), xcat = concat(x0[C0], x1[C1]) on channels.
+struct Conv1Args {
+    const float* x0; int C0;
+    const float* x1; int C1;     // may be null / 0
+    const float* wT;             // [C0+C1][ldw] (input-channel major)
+    int ldw;
+    float* y;                    // [N][Cout][V]
+    const float* add;            // or null
+    float out_slope;             // LeakyReLU slope on the output (1 = none)
+    int N, Cout;
+    size_t V;
+};
+int conv1_launch(const Conv1Args& a, hipStream_t s);
+int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
+
+// space-to-depth for the 2x2x2 stride-2 conv: y[n][c*8 + (i*4+j*2+k)][z][y][x] = x[n][c][2z+i][2y+j][2x+k]
+int s2d_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);   // D,H,W = input (even)
+int d2s_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s);   // inverse (x overwritten)
+
+// GroupNorm pieces
+int gn_stats_tiles(size_t V);                                                    // nblk used by gn_stats_launch
+int gn_stats_launch(const float* x, float* partials, int N, int C, size_t V, hipStream_t s);   // [N][C][nblk][2]
+// partials -> mean,rstd [N][G]; scale,shift [N][C] (y = x*scale+shift)
+int gn_finalize_launch(const float* partials, int nblk, const float* gamma, const float* beta, float* mean, float* rstd,
+                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s);
+// y = (res ? res : 0) + lrelu(x*scale[n,c]+shift[n,c], slope)
+int gn_apply_launch(const float* x, const float* scale, const float* shift, const float* res, float* y,
+                    int N, int C, size_t V, float slope, hipStream_t s);
+// backward.  reduce: per (n,c) S1 = sum dyh, S2 = sum dyh*xhat (dyh = dy * lrelu'(x*scale+shift)).
+int gn_bwd_tiles(size_t V);
+int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
+// partials -> coefficient triples coef[N][C][3] (dx = cA*dyh + cB*x + cC) and dgamma/dbeta (overwritten or accumulated)
+int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
+                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s);
+int gn_bwd_apply_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef,
+                        float slope, float* dx, int N, int C, size_t V, hipStream_t s);
+
+int lrelu_fwd_launch(const float* x, float* y, size_t n, float slope, hipStream_t s);
+int lrelu_bwd_launch(const float* y, const float* dy, float* dx, size_t n, float slope, hipStream_t s);
+int sigmoid_launch(const float* x, float* y, size_t n, hipStream_t s);
+int sigmoid_bwd_launch(const float* p, const float* dp, float* dz, size_t n, hipStream_t s);   // dz = dp*p*(1-p)
+int add_launch(const float* a, const float* b, float* y, size_t n, hipStream_t s);
+int fill_launch(float* p, float v, size_t n, hipStream_t s);
+int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);
+int up2_bwd_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
+int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
+size_t bias_grad_workspace_bytes(int N, int C, size_t V);
+
+int crit_tiles(size_t total);
+int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C, size_t V, float bgw, void* ws, size_t ws_bytes, hipStream_t s);
+int crit_grad_launch(const float* p, const float* g, const double* sums, double count, float w_dice, float w_bce,
+                     float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s);
+int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float b1, float b2,
+                float eps, float wd, int step, hipStream_t s);
+
+}  // namespace ru

@@ -1,0 +1,121 @@
+"""Host handle on the whole-network executor of libresunet_hip.so (ru_unet_*): one C call enqueues the
+entire UNet.forward (model.py:407-433) or its backward on torch's current HIP stream.
+
+Parameters and gradients are single flat float32 device buffers in reference state_dict() order; the
+library reports the layout (names, shapes, offsets, which tensors are dead).  The flat gradient buffer is
+what the data-parallel step all-reduces over RCCL (parallel.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+
+DEFAULT_CFG = dict(depth=4, encoder_layers=[1, 2, 2, 4], decoder_layers=[1, 1, 1, 1],
+                   number_of_channels=[16, 32, 64, 128], number_of_outputs=3)     # main.py:56-59
+
+
+class ParamLayout:
+    """Names / shapes / offsets of the flat parameter buffer (pure metadata; needs the library, not a GPU)."""
+
+    def __init__(self, depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs):
+        lib = L.load()
+        self.cfg = dict(depth=int(depth), encoder_layers=[int(v) for v in encoder_layers],
+                        decoder_layers=[int(v) for v in decoder_layers],
+                        number_of_channels=[int(v) for v in number_of_channels], number_of_outputs=int(number_of_outputs))
+        arr = lambda v: (C.c_int * len(v))(*v)
+        self.handle = lib.ru_unet_create(self.cfg["depth"], arr(self.cfg["encoder_layers"]), arr(self.cfg["decoder_layers"]),
+                                         arr(self.cfg["number_of_channels"]), self.cfg["number_of_outputs"])
+        if not self.handle:
+            raise RuntimeError("ru_unet_create failed: " + L.last_error())
+        self.handle = C.c_void_p(self.handle)
+        self.entries = OrderedDict()
+        for i in range(lib.ru_unet_param_count(self.handle)):
+            name = lib.ru_unet_param_name(self.handle, i).decode()
+            shape = tuple(lib.ru_unet_param_dim(self.handle, i, d) for d in range(lib.ru_unet_param_ndim(self.handle, i)))
+            self.entries[name] = (shape, int(lib.ru_unet_param_offset(self.handle, i)), bool(lib.ru_unet_param_is_dead(self.handle, i)))
+        self.total = int(lib.ru_unet_param_total(self.handle))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.load().ru_unet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def views(self, flat):
+        """OrderedDict name -> view of `flat` with the parameter's shape."""
+        out = OrderedDict()
+        for name, (shape, off, _dead) in self.entries.items():
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = flat[off:off + n].view(shape)
+        return out
+
+
+class UNetEngine:
+    """forward()/backward() on device buffers.  One engine == one in-flight forward state."""
+
+    def __init__(self, depth=4, encoder_layers=(1, 2, 2, 4), decoder_layers=(1, 1, 1, 1),
+                 number_of_channels=(16, 32, 64, 128), number_of_outputs=3):
+        self.layout = ParamLayout(depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs)
+        self.h = self.layout.handle
+        self.n_out = int(number_of_outputs)
+        self._ws = None
+        self._ws_key = None
+        self.generation = 0
+
+    def _workspace(self, n, d, h, w, training, device):
+        key = (n, d, h, w, bool(training), str(device))
+        if self._ws is None or self._ws_key != key:
+            nbytes = L.load().ru_unet_workspace_bytes(self.h, n, d, h, w, int(training))
+            if nbytes == 0:
+                raise RuntimeError("ru_unet_workspace_bytes: " + L.last_error())
+            self._ws = None                      # release the old arena before allocating the new one
+            self._ws = L.workspace(nbytes, device)
+            self._ws_key = key
+        return self._ws
+
+    def forward(self, flat_params, x, training=False):
+        """x: [N,4,D,H,W] float32 device tensor -> sigmoid probabilities [N,n_out,D,H,W]."""
+        L.require_gpu()
+        if x.dim() != 5 or int(x.shape[1]) != 4:
+            raise ValueError("expected input [N,4,D,H,W] (model.py:336), got %s" % (tuple(x.shape),))
+        if flat_params.numel() != self.layout.total or flat_params.dtype != torch.float32:
+            raise ValueError("flat parameter buffer has the wrong size/dtype")
+        x = x.contiguous().float()
+        n, _, d, h, w = [int(v) for v in x.shape]
+        ws = self._workspace(n, d, h, w, training, x.device)
+        probs = torch.empty((n, self.n_out, d, h, w), dtype=torch.float32, device=x.device)
+        L.check(L.load().ru_unet_forward(self.h, L.f32(flat_params), L.f32(x), L.f32(probs), n, d, h, w, int(training),
+                                         L.ptr(ws), ws.numel(), L.stream()), "ru_unet_forward")
+        self.generation += 1
+        self._x = x                               # keep the input alive until backward (wgrad of conv_input reads it)
+        return probs
+
+    def backward(self, flat_params, dprobs, flat_grads=None, want_dx=False):
+        """dprobs = d(loss)/d(probs) -> flat gradient buffer (overwritten; dead parameters get zeros)."""
+        if flat_grads is None:
+            flat_grads = torch.empty_like(flat_params)
+        dprobs = dprobs.contiguous().float()
+        dx = torch.empty_like(self._x) if want_dx else None
+        L.check(L.load().ru_unet_backward(self.h, L.f32(flat_params), L.f32(dprobs), L.f32(flat_grads), L.ptr(dx, True), L.stream()),
+                "ru_unet_backward")
+        return (flat_grads, dx) if want_dx else flat_grads
+
+    def gn_stats(self):
+        """[(mean[N*8], rstd[N*8])] of every GroupNorm of the last forward, in execution order."""
+        lib = L.load()
+        cnt = lib.ru_unet_gn_stats(self.h, -1, None, None, L.stream())
+        n = int(self._x.shape[0])
+        out = []
+        for i in range(cnt):
+            m = torch.empty(n * 8, dtype=torch.float32, device=self._x.device)
+            r = torch.empty_like(m)
+            L.check(lib.ru_unet_gn_stats(self.h, i, L.f32(m), L.f32(r), L.stream()), "ru_unet_gn_stats")
+            out.append((m, r))
+        return out

@@ -1,0 +1,93 @@
+"""Drop-in for the reference's `loss` module on the hot path: `Dice_loss_joint(index, priority)` and
+`BCE_Loss(index, bg_weight)` with the reference call convention `forward(x_list, y_list) -> 0-dim tensor`
+(loss.py:64-79,98-122), backed by the two-phase HIP criterion kernels:
+
+  phase 1  ru_criterion_sums : per-class sum(p*g), sum(p^2+g) and the BCE log-sum of this rank's shard
+  (data-parallel: all-reduce the [2C+1] float64 sums -- the Dice sums couple the GLOBAL batch, loss.py:114-115)
+  phase 2  ru_criterion_grad : d loss / d p from the global sums
+
+`FusedCriterion` is the training criterion of main.py:126-128 -- (Dice + BCE(bg 1e-2)) / 2 -- in one pass of
+each phase; the separate modules stay available so `criterion=[Dice_loss_joint(), BCE_Loss()]` lists keep working
+(train.py:203-205).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _all_reduce_sums(sums, group):
+    import torch.distributed as dist
+    if group is not False and dist.is_available() and dist.is_initialized():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=None if group in (None, True) else group)
+        return dist.get_world_size(None if group in (None, True) else group)
+    return 1
+
+
+class _CriterionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, w_dice, w_bce, bg_weight, priority, group):
+        sums = ops.criterion_sums(pred, gt, bg_weight)
+        world = _all_reduce_sums(sums, group)
+        count = float(pred.numel()) * world
+        dice, bce = ops.criterion_value(sums, count, priority)
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.cfg = (count, w_dice, w_bce, bg_weight, priority)
+        return (w_dice * dice + w_bce * bce).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, gt, sums = ctx.saved_tensors
+        count, w_dice, w_bce, bg_weight, priority = ctx.cfg
+        dp = ops.criterion_grad(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority)
+        return dp.mul_(gout.to(dp.dtype)), None, None, None, None, None, None
+
+
+class _LossBase(nn.Module):
+    """`data_parallel`: False (reference semantics, single process), or True / a process group: all-reduce the partial
+    sums so that every rank forms the GLOBAL-batch loss the reference computes on GPU 0 under nn.DataParallel."""
+
+    def __init__(self):
+        super().__init__()
+        self.data_parallel = False
+
+    def _run(self, x, y, index, w_dice, w_bce, bg_weight, priority):
+        assert x[index].shape == y[index].shape                   # loss.py:71,107
+        return _CriterionFn.apply(x[index], y[index], w_dice, w_bce, bg_weight, priority, self.data_parallel)
+
+
+class Dice_loss_joint(_LossBase):
+    """loss.py:98-122: priority * (1 - mean_c 2(I_c+1e-6)/(U_c+2e-6)), sums over batch and space jointly."""
+
+    def __init__(self, index=0, priority=1):
+        super().__init__()
+        self.index = index
+        self.priority = priority
+
+    def forward(self, x, y):
+        return self._run(x, y, self.index, 1.0, 0.0, 1.0, float(self.priority))
+
+
+class BCE_Loss(_LossBase):
+    """loss.py:64-79: -mean(g log(p+1e-6) + bg_weight (1-g) log(1+1e-6-p))."""
+
+    def __init__(self, index=0, bg_weight=1):
+        super().__init__()
+        self.label_index = index
+        self.bg_weight = bg_weight
+
+    def forward(self, x, y):
+        return self._run(x, y, self.label_index, 0.0, 1.0, float(self.bg_weight), 1.0)
+
+
+class FusedCriterion(_LossBase):
+    """(Dice_loss_joint(priority) + BCE_Loss(bg_weight)) / 2 == train.py:203-205 applied to main.py:126-128."""
+
+    def __init__(self, index=0, priority=1, bg_weight=1e-2):
+        super().__init__()
+        self.index, self.priority, self.bg_weight = index, priority, bg_weight
+
+    def forward(self, x, y):
+        return self._run(x, y, self.index, 0.5, 0.5, float(self.bg_weight), float(self.priority))

@@ -1,0 +1,278 @@
+"""Drop-in for the reference's `model` module on the hot path: same public classes (`UNet`, `Residual`,
+`conv`, `Trilinear`), same constructor signatures, same state_dict() keys / shapes / order, same call
+convention (`forward(x)` takes a LIST and reads x[0]; returns a LIST with the sigmoid probabilities,
+model.py:407-433) -- but `UNet.forward` is ONE call into libresunet_hip.so (engine.py), not a chain of
+torch.nn ops.  The nn.Conv3d / nn.GroupNorm objects below only OWN the parameters (so checkpoints,
+optimizers and `weight_init` keep working); their storage is aliased onto one flat device buffer that
+the HIP executor reads directly.
+
+Reference checkpoints pickle whole module objects under the module name `model` (train.py:320-324);
+`brats2019_amd.compat.install_aliases()` registers this module under that name so they un-pickle into
+the classes here.  A UNet restored that way never ran __init__, so everything `forward` needs is
+derived lazily from the attributes the reference's __init__ sets (model.py:313-318).
+
+HIP-only: calling forward with CPU tensors raises (no CPU fallback; the CPU restatement is oracle/).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .engine import UNetEngine
+
+LEAKY_SLOPE = 1e-2
+
+
+# ---------------------------------------------------------------------- per-op autograd (building blocks used stand-alone)
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.conv3d(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k = int(w.shape[2])
+        dx = ops.conv3d_bwd_data(dy, w, x.shape[2:]) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            if ctx.has_bias:
+                dw, db = ops.conv3d_bwd_weight(x, dy, k, with_bias=True)
+            else:
+                dw = ops.conv3d_bwd_weight(x, dy, k)
+        return dx, dw, db
+
+
+class _GroupNormActFn(torch.autograd.Function):
+    """y = residual + lrelu(GroupNorm(x), slope)  (model.py:103-115 fused; slope 1 = no activation)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, groups, slope):
+        y, mean, rstd = ops.group_norm(x, gamma, beta, groups, 1e-5, slope, residual)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.groups, ctx.slope, ctx.has_res = groups, slope, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.group_norm_bwd(x, gamma, beta, mean, rstd, dy, ctx.groups, ctx.slope)
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2x_bwd(dy)
+
+
+class _LeakyReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        y = ops.leaky_relu(x, slope)
+        ctx.save_for_backward(y)          # the reference's in-place LeakyReLU keeps the OUTPUT (model.py:352)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.leaky_relu_bwd(y, dy, ctx.slope), None
+
+
+def conv3d_op(x, conv_module):
+    """Apply an nn.Conv3d parameter holder through the HIP kernels."""
+    return _ConvFn.apply(x, conv_module.weight, conv_module.bias)
+
+
+# ---------------------------------------------------------------------- reference-named modules
+class Trilinear(nn.Module):
+    """model.py:7-14: F.interpolate(scale_factor=scale, mode='trilinear'); only scale 2 exists in the path."""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, x):
+        if self.scale != 2:
+            raise NotImplementedError("only the x2 trilinear up-sampling of model.py:399 is implemented")
+        return _UpsampleFn.apply(x)
+
+
+class conv(nn.Module):
+    """model.py:66-79: 3x3x3, stride 1, pad 1, no bias; parameter key `conv1.weight`."""
+
+    def __init__(self, in_channels, out_channels, stride=1, groups=1):
+        super().__init__()
+        if stride != 1 or groups != 1:
+            raise NotImplementedError("the shipped configuration only uses stride=1, groups=1 (model.py:89-91)")
+        self.conv1 = nn.Conv3d(in_channels, out_channels, kernel_size=(3, 3, 3), stride=stride, padding=1, bias=False, groups=groups)
+
+    def forward(self, x):
+        return conv3d_op(x, self.conv1)
+
+
+class Residual(nn.Module):
+    """model.py:81-117.  Stand-alone forward = 2 x (conv -> fused GroupNorm+LeakyReLU) + skip add."""
+
+    def __init__(self, in_channels, out_channels, stride, downsample=None, conv_groups=1):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.downsample = downsample
+        self.conv1 = conv(in_channels=in_channels, out_channels=out_channels, stride=stride)
+        self.conv2 = conv(in_channels=out_channels, out_channels=out_channels, stride=1)
+        self.relu1 = nn.LeakyReLU(LEAKY_SLOPE, inplace=True)
+        self.relu2 = nn.LeakyReLU(LEAKY_SLOPE, inplace=True)
+        self.norm1 = nn.GroupNorm(num_groups=8, num_channels=out_channels)
+        self.norm2 = nn.GroupNorm(num_groups=8, num_channels=out_channels)
+
+    def forward(self, x):
+        if self.downsample is not None:
+            x = conv3d_op(x, self.downsample[0])
+        out = self.conv1(x)
+        out = _GroupNormActFn.apply(out, self.norm1.weight, self.norm1.bias, None, 8, LEAKY_SLOPE)
+        out = self.conv2(out)
+        return _GroupNormActFn.apply(out, self.norm2.weight, self.norm2.bias, x, 8, LEAKY_SLOPE)
+
+
+class _UNetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward/backward are single calls into the HIP executor."""
+
+    @staticmethod
+    def forward(ctx, net, training, x, *params):
+        eng = net._get_engine()
+        flat = net._flat_params()
+        probs = eng.forward(flat, x, training=training)
+        ctx.net, ctx.generation, ctx.training = net, eng.generation, training
+        ctx.x_needs_grad = x.requires_grad
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        net = ctx.net
+        eng = net._get_engine()
+        if not ctx.training:
+            raise RuntimeError("UNet forward ran in inference mode; no activations were kept for backward")
+        if eng.generation != ctx.generation:
+            raise RuntimeError("UNet.forward was called again before backward(): the executor keeps ONE forward state")
+        flat = net._flat_params()
+        res = eng.backward(flat, dprobs, want_dx=ctx.x_needs_grad)
+        grads, dx = res if ctx.x_needs_grad else (res, None)
+        views = eng.layout.views(grads)
+        out = []
+        for name in net._param_order():
+            _shape, _off, dead = eng.layout.entries[name]
+            out.append(None if dead else views[name])      # dead parameters keep grad=None like the reference (model.py:420)
+        return (None, None, dx) + tuple(out)
+
+
+class UNet(nn.Module):
+    """model.py:308-433 with block=Residual.  `forward(x)`: x is a list, x[0] = [N,4,D,H,W]; returns [probs]."""
+
+    def __init__(self, depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs, block=Residual):
+        super().__init__()
+        if block is not Residual:
+            raise NotImplementedError("only block=Residual is on the accelerated path (main.py:56-59)")
+        self.encoder_layers = encoder_layers
+        self.decoder_layers = decoder_layers
+        self.number_of_channels = number_of_channels
+        self.number_of_outputs = number_of_outputs
+        self.depth = depth
+        self.block = block
+        ch = number_of_channels
+        # registration order fixes the state_dict() key order (model.py:320-357)
+        self.encoder_convs = nn.ModuleList()
+        self.upsampling = nn.ModuleList()
+        self.decoder_convs = nn.ModuleList()
+        self.decoder_convs1x1 = nn.ModuleList()
+        self.attention_convs = nn.ModuleList()
+        self.upsampling_distance = nn.ModuleList()
+        self.conv_input = nn.Conv3d(4, ch[0], kernel_size=(3, 3, 3), stride=1, padding=(1, 1, 1), bias=False)
+        self.norm_input = nn.GroupNorm(num_groups=8, num_channels=ch[0])
+        self.conv_first = nn.Sequential(*[block(in_channels=ch[0], out_channels=ch[0], stride=1) for _ in range(encoder_layers[0])])
+        self.conv_output = nn.Conv3d(ch[0], number_of_outputs, kernel_size=3, stride=1, padding=1, bias=True, groups=1)
+        self.softmax = nn.Softmax(dim=1)
+        self.sigmoid = nn.Sigmoid()
+        self.relu = nn.LeakyReLU(LEAKY_SLOPE, inplace=True)
+        for i in range(depth):                                   # model.py:379-395 (the last stage is built but never run)
+            self.decoder_convs.append(nn.Sequential(*[block(in_channels=ch[i], out_channels=ch[i], stride=1)
+                                                      for _ in range(decoder_layers[i])]))
+            self.decoder_convs1x1.append(nn.Conv3d(2 * ch[i], ch[i], kernel_size=1, padding=0, bias=False))
+        for i in range(depth - 1):                               # model.py:359-377
+            down = nn.Sequential(nn.Conv3d(ch[i], ch[i + 1], kernel_size=2, stride=2, bias=False))
+            layers = [block(in_channels=ch[i + 1], out_channels=ch[i + 1], stride=1, downsample=down)]
+            layers += [block(in_channels=ch[i + 1], out_channels=ch[i + 1], stride=1) for _ in range(1, encoder_layers[i + 1])]
+            self.encoder_convs.append(nn.Sequential(*layers))
+        for i in range(depth - 1):                               # model.py:397-404
+            self.upsampling.append(nn.Sequential(Trilinear(scale=2), nn.Conv3d(ch[i + 1], ch[i], kernel_size=1, stride=1, bias=False)))
+
+    # ---- executor plumbing (all lazy: un-pickled instances never ran __init__)
+    def _get_engine(self):
+        eng = self.__dict__.get("_engine_obj")
+        if eng is None:
+            eng = UNetEngine(self.depth, list(self.encoder_layers), list(self.decoder_layers), list(self.number_of_channels),
+                             self.number_of_outputs)
+            names = [n for n, _ in self.named_parameters()]
+            if names != list(eng.layout.entries.keys()):
+                raise RuntimeError("parameter names/order differ from the executor's layout")
+            for n, p in self.named_parameters():
+                if tuple(p.shape) != eng.layout.entries[n][0]:
+                    raise RuntimeError("parameter %s has shape %s, executor expects %s" % (n, tuple(p.shape), eng.layout.entries[n][0]))
+            self.__dict__["_engine_obj"] = eng
+            self.__dict__["_param_names"] = names
+        return eng
+
+    def _param_order(self):
+        self._get_engine()
+        return self.__dict__["_param_names"]
+
+    def _flat_params(self):
+        """One flat float32 device buffer aliased by every nn.Parameter (re-built if .to()/.cuda() broke the aliasing)."""
+        eng = self._get_engine()
+        flat = self.__dict__.get("_flat_buf")
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        ok = flat is not None and flat.device == dev
+        if ok:
+            base = flat.data_ptr()
+            for name, (shape, off, _dead) in eng.layout.entries.items():
+                p = params[name]
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or not p.is_contiguous():
+                    ok = False
+                    break
+        if not ok:
+            if dev.type != "cuda":
+                raise RuntimeError("brats2019_amd.model.UNet runs on a ROCm GPU only: move the model with .cuda() first "
+                                   "(there is no CPU fallback for the HIP path)")
+            flat = torch.empty(eng.layout.total, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for name, view in eng.layout.views(flat).items():
+                    view.copy_(params[name].data)
+                    params[name].data = view
+            self.__dict__["_flat_buf"] = flat
+        return flat
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_engine_obj", "_flat_buf", "_param_names"):     # never pickle the ctypes handle / the alias buffer
+            state.pop(k, None)
+        return state
+
+    def forward(self, x):
+        L.require_gpu()
+        inp = x[0]                                                # model.py:410
+        if not inp.is_cuda:
+            raise RuntimeError("brats2019_amd.model.UNet: input must be a ROCm device tensor (HIP-only path)")
+        params = [p for _, p in self.named_parameters()]
+        training = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
+        probs = _UNetFn.apply(self, training, inp, *params)
+        return [probs]                                            # model.py:433

@@ -1,0 +1,181 @@
+"""Thin tensor-level wrappers over the op entry points of libresunet_hip.so.  They allocate outputs and
+scratch with torch (device memory plumbing) and pass raw pointers through the C-ABI; every function
+documents the reference call site it stands in for.  Used by loss.py / train.py and by the per-op parity
+tests; the network itself goes through engine.py (one C call per forward/backward)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+LEAKY_SLOPE = 1e-2
+
+
+def _dims5(x):
+    if x.dim() != 5:
+        raise ValueError("expected an NCDHW tensor, got shape %s" % (tuple(x.shape),))
+    return [int(v) for v in x.shape]
+
+
+def _prep(t):
+    L.require_gpu()
+    if t is None:
+        return None
+    return t.contiguous().float() if (not t.is_contiguous() or t.dtype != torch.float32) else t
+
+
+def conv3d(x, w, bias=None):
+    """nn.Conv3d forward as built at model.py:72-73,336,348 (k=3,s=1,p=1), :361-363 (k=2,s=2), :393,401 (k=1)."""
+    x, w, bias = _prep(x), _prep(w), _prep(bias)
+    lib = L.load()
+    n, cin, d, h, wd = _dims5(x)
+    cout, k = int(w.shape[0]), int(w.shape[2])
+    if int(w.shape[1]) != cin:
+        raise ValueError("weight expects %d input channels, input has %d" % (int(w.shape[1]), cin))
+    out_sp = (d, h, wd) if k != 2 else (d // 2, h // 2, wd // 2)
+    y = torch.empty((n, cout) + out_sp, dtype=torch.float32, device=x.device)
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), x.device)
+    L.check(lib.ru_conv3d_fwd(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, k,
+                              L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd")
+    return y
+
+
+def conv3d_bwd_data(dy, w, in_spatial):
+    """Data gradient of the conv above; `in_spatial` = (D,H,W) of the conv INPUT."""
+    dy, w = _prep(dy), _prep(w)
+    lib = L.load()
+    n = int(dy.shape[0])
+    cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    d, h, wd = [int(v) for v in in_spatial]
+    dx = torch.empty((n, cin, d, h, wd), dtype=torch.float32, device=dy.device)
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), dy.device)
+    L.check(lib.ru_conv3d_bwd_data(L.f32(dy), L.f32(w), L.f32(dx), n, cin, cout, d, h, wd, k, L.ptr(ws), ws.numel(), L.stream()),
+            "ru_conv3d_bwd_data")
+    return dx
+
+
+def conv3d_bwd_weight(x, dy, k, with_bias=False):
+    """Weight (and bias) gradient of the conv above."""
+    x, dy = _prep(x), _prep(dy)
+    lib = L.load()
+    n, cin, d, h, wd = _dims5(x)
+    cout = int(dy.shape[1])
+    dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if with_bias else None
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), x.device)
+    L.check(lib.ru_conv3d_bwd_weight(L.f32(x), L.f32(dy), L.f32(dw), L.ptr(db, True), n, cin, cout, d, h, wd, k,
+                                     L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_bwd_weight")
+    return (dw, db) if with_bias else dw
+
+
+def group_norm(x, gamma, beta, groups=8, eps=1e-5, slope=1.0, residual=None):
+    """nn.GroupNorm(8, C) (model.py:95-96,338) + LeakyReLU(slope) (model.py:93-94; 1.0 = none) + optional
+    residual add (model.py:115).  Returns (y, mean[N*G], rstd[N*G])."""
+    x, gamma, beta, residual = _prep(x), _prep(gamma), _prep(beta), _prep(residual)
+    lib = L.load()
+    n, c = int(x.shape[0]), int(x.shape[1])
+    v = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = L.workspace(lib.ru_groupnorm_workspace_bytes(n, c, v), x.device)
+    L.check(lib.ru_groupnorm_fwd(L.f32(x), L.f32(gamma), L.f32(beta), L.ptr(residual, True), L.f32(y), L.f32(mean), L.f32(rstd),
+                                 n, c, v, groups, eps, slope, L.ptr(ws), ws.numel(), L.stream()), "ru_groupnorm_fwd")
+    return y, mean, rstd
+
+
+def group_norm_bwd(x, gamma, beta, mean, rstd, dy, groups=8, slope=1.0):
+    """Backward of lrelu(GN(x)); returns (dx, dgamma, dbeta)."""
+    x, gamma, beta, dy = _prep(x), _prep(gamma), _prep(beta), _prep(dy)
+    lib = L.load()
+    n, c = int(x.shape[0]), int(x.shape[1])
+    v = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    ws = L.workspace(lib.ru_groupnorm_workspace_bytes(n, c, v), x.device)
+    L.check(lib.ru_groupnorm_bwd(L.f32(x), L.f32(gamma), L.f32(beta), L.f32(mean), L.f32(rstd), L.f32(dy), L.f32(dx), L.f32(dgamma),
+                                 L.f32(dbeta), n, c, v, groups, slope, L.ptr(ws), ws.numel(), L.stream()), "ru_groupnorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def leaky_relu(x, slope=LEAKY_SLOPE):
+    x = _prep(x)
+    y = torch.empty_like(x)
+    L.check(L.load().ru_leaky_relu_fwd(L.f32(x), L.f32(y), x.numel(), slope, L.stream()), "ru_leaky_relu_fwd")
+    return y
+
+
+def leaky_relu_bwd(y, dy, slope=LEAKY_SLOPE):
+    y, dy = _prep(y), _prep(dy)
+    dx = torch.empty_like(y)
+    L.check(L.load().ru_leaky_relu_bwd(L.f32(y), L.f32(dy), L.f32(dx), y.numel(), slope, L.stream()), "ru_leaky_relu_bwd")
+    return dx
+
+
+def upsample2x(x):
+    """model.Trilinear(scale=2) (model.py:7-14)."""
+    x = _prep(x)
+    n, c, d, h, w = _dims5(x)
+    y = torch.empty((n, c, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    L.check(L.load().ru_upsample2x_trilinear_fwd(L.f32(x), L.f32(y), n, c, d, h, w, L.stream()), "ru_upsample2x_trilinear_fwd")
+    return y
+
+
+def upsample2x_bwd(dy):
+    dy = _prep(dy)
+    n, c, d2, h2, w2 = _dims5(dy)
+    dx = torch.empty((n, c, d2 // 2, h2 // 2, w2 // 2), dtype=torch.float32, device=dy.device)
+    L.check(L.load().ru_upsample2x_trilinear_bwd(L.f32(dy), L.f32(dx), n, c, d2 // 2, h2 // 2, w2 // 2, L.stream()),
+            "ru_upsample2x_trilinear_bwd")
+    return dx
+
+
+def sigmoid(x):
+    x = _prep(x)
+    y = torch.empty_like(x)
+    L.check(L.load().ru_sigmoid_fwd(L.f32(x), L.f32(y), x.numel(), L.stream()), "ru_sigmoid_fwd")
+    return y
+
+
+def criterion_sums(p, g, bg_weight=1e-2):
+    """Phase 1 of the criterion (loss.py:76-79,114-115): float64 device tensor [2C+1] =
+    (sum p*g per class, sum p^2+g per class, BCE log-sum) over THIS shard, no epsilons."""
+    p, g = _prep(p), _prep(g)
+    if p.shape != g.shape:
+        raise AssertionError("prediction/target shape mismatch")      # loss.py:71,107 assert
+    lib = L.load()
+    n, c = int(p.shape[0]), int(p.shape[1])
+    v = p.numel() // (n * c)
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=p.device)
+    ws = L.workspace(lib.ru_criterion_workspace_bytes(n, c, v), p.device)
+    L.check(lib.ru_criterion_sums(L.f32(p), L.f32(g), L.ptr(sums), n, c, v, bg_weight, L.ptr(ws), ws.numel(), L.stream()),
+            "ru_criterion_sums")
+    return sums
+
+
+def criterion_grad(p, g, sums, count, w_dice=0.5, w_bce=0.5, bg_weight=1e-2, priority=1.0):
+    """Phase 2: d(w_dice*Dice + w_bce*BCE)/dp from GLOBAL sums / element count."""
+    p, g = _prep(p), _prep(g)
+    n, c = int(p.shape[0]), int(p.shape[1])
+    v = p.numel() // (n * c)
+    dp = torch.empty_like(p)
+    L.check(L.load().ru_criterion_grad(L.f32(p), L.f32(g), L.ptr(sums), float(count), w_dice, w_bce, bg_weight, priority,
+                                       L.f32(dp), n, c, v, L.stream()), "ru_criterion_grad")
+    return dp
+
+
+def criterion_value(sums, count, priority=1.0):
+    """(dice, bce) as float64 0-dim DEVICE tensors from (global) sums -- no host sync."""
+    c = (sums.numel() - 1) // 2
+    inter, union, bce = sums[:c], sums[c:2 * c], sums[2 * c]
+    dice = priority * (1.0 - torch.mean(2.0 * (inter + 1e-6) / (union + 2e-6)))    # loss.py:114-122
+    return dice, -bce / count                                                        # loss.py:79
+
+
+def adam_amsgrad_step(w, g, m, v, vmax, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam(amsgrad=True) update on flat float32 buffers (main.py:133-137)."""
+    L.check(L.load().ru_adam_amsgrad_step(L.f32(w), L.f32(g), L.f32(m), L.f32(v), L.f32(vmax), w.numel(), lr, betas[0], betas[1],
+                                          eps, weight_decay, int(step), L.stream()), "ru_adam_amsgrad_step")

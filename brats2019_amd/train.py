@@ -1,0 +1,250 @@
+"""Drop-in for the reference's `train` module: `TrainingState` and `Trainer` with the reference's public
+surface (train.py:14-23,27,54,59-61,129,145,320-339) and checkpoint layout
+`<models_root>/<name>/<name>{best_model,last_model,_epoch_N}.pth = torch.save({'state': TrainingState,
+'model': module})`, driving the HIP model/loss of this package.
+
+Differences that are deliberate:
+  * `torch.load(..., weights_only=False)`: under torch >= 2.6 the reference's own `_load` cannot read its own
+    whole-module pickles;
+  * the scheduler assert accepts `LRScheduler` (StepLR is no longer an `_LRScheduler` subclass instance);
+  * tensorboardX is optional (absent in this image): scalars go to a no-op writer when it cannot be imported;
+  * `eval_cpu=True` is refused: this path is HIP-only;
+  * tile geometry of `predict_tiled` is a parameter (defaults = the reference's literals 192/48/72).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+
+from . import tiling
+
+
+class TrainingState(object):
+    """train.py:14-23."""
+
+    def __init__(self):
+        self.epoch = 0
+        self.train_metric = dict()
+        self.val_metric = dict()
+        self.global_step = 0           # number of processed batches
+        self.best_val = 0
+        self.optimizer_state = None
+        self.cuda = True
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def _make_writer(logdir):
+    try:
+        from tensorboardX import SummaryWriter
+        return SummaryWriter(logdir=logdir)
+    except Exception:
+        return _NullWriter()
+
+
+def _log_metric(writer, metric, prefix, epoch):
+    """metrics.print_metrics analogue (metrics.py:273-280): one scalar per entry of metric.get()."""
+    val = np.atleast_1d(np.asarray(metric.get(), dtype=np.float64))
+    for i, v in enumerate(val):
+        writer.add_scalar("%s%s-%d" % (prefix, metric.name, i), float(v), epoch)
+    print("%s%s: %s" % (prefix, metric.name, np.array2string(val, precision=4)))
+
+
+class Trainer(object):
+    def __init__(self, name, models_root, model=None, rewrite=False, connect_tb=True):
+        assert isinstance(model, (list, tuple, torch.nn.Module)) or model is None
+        self.model = model
+        self.name = name
+        self.models_root = models_root
+        self.model_path = os.path.join(models_root, self.name)
+        self.logs_path = os.path.join(self.model_path, "logs")
+        self.state = TrainingState()
+        self.resume_training = False
+        if os.path.exists(self.model_path):
+            if rewrite:
+                shutil.rmtree(self.model_path)
+            else:
+                self.resume_training = True
+        if not os.path.exists(self.model_path):
+            os.makedirs(self.logs_path)
+        self.tb_writer = _make_writer(self.logs_path) if connect_tb else _NullWriter()
+        self.tile_shape, self.center_shape, self.border = (192, 192, 192), (48, 48, 48), (72, 72, 72)   # train.py:154-156
+
+    def cuda(self):
+        if self.model is not None:
+            self.model.cuda()
+        self.state.cuda = True
+
+    # ------------------------------------------------------------------ training (train.py:59-127)
+    def train(self, criterion, optimizer, optimizer_params, scheduler, scheduler_params, training_data_loader,
+              evaluation_data_loader, split_into_tiles, pretrained_weights, train_metrics, val_metrics,
+              track_metric, epoches, default_val, comparator, eval_cpu, continue_form_pretraining):
+        if eval_cpu:
+            raise NotImplementedError("eval_cpu=True needs a CPU model; this engine is HIP-only")
+        self.eval_cpu = eval_cpu
+        assert isinstance(criterion, (tuple, list, torch.nn.Module))
+        if self.resume_training:
+            self.load_latest()
+        elif pretrained_weights is not None:
+            self.model.load_state_dict(pretrained_weights)
+        elif continue_form_pretraining:
+            print("Continue from pretraining")
+        else:
+            self.state.best_val = default_val
+        if self.state.cuda:
+            self.model.cuda()
+        if isinstance(optimizer, type):
+            optimizer = optimizer(params=self.model.parameters(), **optimizer_params)
+        if scheduler is not None and isinstance(scheduler, type):
+            scheduler = scheduler(optimizer=optimizer, **scheduler_params)
+        assert isinstance(optimizer, torch.optim.Optimizer)
+        assert scheduler is None or isinstance(scheduler, torch.optim.lr_scheduler.LRScheduler)
+        if self.state.optimizer_state is not None and not continue_form_pretraining:
+            optimizer.load_state_dict(self.state.optimizer_state)
+            print("Loaded optimizer state")
+        if not self.state.train_metric:
+            for m in train_metrics:
+                self.state.train_metric[m.name] = []
+            for m in val_metrics:
+                self.state.val_metric[m.name] = []
+        for epoch in range(self.state.epoch, epoches):
+            tic = time.time()
+            self.state.global_step = self._train_one_epoch(criterion, optimizer, training_data_loader, train_metrics,
+                                                           self.state.train_metric, epoch, self.state.global_step, scheduler)
+            self._evaluate_and_save(evaluation_data_loader, split_into_tiles, val_metrics, track_metric,
+                                    self.state.val_metric, epoch, comparator)
+            print("Epoch %d, time %s \n" % (epoch, time.time() - tic))
+            self._save(suffix="_epoch_" + str(self.state.epoch))
+            self._save(suffix="last_model")
+            self.state.epoch = self.state.epoch + 1
+
+    def _to_device(self, tensors):
+        return [t.cuda(non_blocking=True) for t in tensors] if self.state.cuda else list(tensors)
+
+    def _train_one_epoch(self, criterion, optimizer, loader, train_metrics, results, epoch, global_step, scheduler):
+        for m in train_metrics:
+            m.reset()
+        if self.state.cuda:
+            self.model.cuda()
+        self.model.train()
+        optimizer.zero_grad()
+        for batch in loader:
+            assert isinstance(batch[0], list) and isinstance(batch[1], list)
+            data, target = self._to_device(batch[0]), self._to_device(batch[1])
+            output = self.model(data)                                        # train.py:201
+            if isinstance(criterion, (tuple, list)):
+                loss_val = [c(output, target) for c in criterion]            # train.py:203-205
+                loss = sum(loss_val) / len(loss_val)
+            else:
+                loss_val = [criterion(output, target)]
+                loss = loss_val[0]
+            loss.backward()                                                  # train.py:210
+            optimizer.step()
+            optimizer.zero_grad()
+            if scheduler is not None:
+                scheduler.step()                                             # per iteration (train.py:222-223)
+            for m in train_metrics:
+                m.update(output, target)
+            for i, lv in enumerate(loss_val):
+                self.tb_writer.add_scalar("loss/loss-%d" % i, lv.item(), global_step)
+            for i, group in enumerate(optimizer.param_groups):
+                self.tb_writer.add_scalar("misc/lr-%d" % i, group["lr"], global_step)
+            global_step += 1
+        for m in train_metrics:
+            results[m.name].append(m.get())
+            _log_metric(self.tb_writer, m, "train/", epoch)
+        self.state.optimizer_state = optimizer.state_dict()
+        return global_step
+
+    # ------------------------------------------------------------------ inference (train.py:129-176)
+    def predict(self, batch):
+        self.model.eval()
+        if self.state.cuda:
+            self.model.cuda()
+        with torch.no_grad():
+            assert isinstance(batch[0], list)
+            return self.model(self._to_device(batch[0]))
+
+    def predict_tiled(self, batch, output_shape, tile_shape=None, center_shape=None, border=None):
+        """train.py:145-176: per centre block, run the model on the zero-padded tile and paste the centre back.
+        The input volume is moved to the device once and every tile is cut there."""
+        tile_shape = tuple(tile_shape or self.tile_shape)
+        center_shape = tuple(center_shape or self.center_shape)
+        border = tuple(border or self.border)
+        inp = batch[0][0]
+        if self.state.cuda:
+            self.model.cuda()
+            inp = inp.cuda(non_blocking=True)
+        self.model.eval()
+        output = torch.zeros(output_shape, dtype=torch.float32, device=inp.device)
+        grid = tiling.grid_for(inp.shape[2:], center_shape)
+        with torch.no_grad():
+            for i in range(grid[0]):
+                for j in range(grid[1]):
+                    for k in range(grid[2]):
+                        lo, hi = tiling.get_indices((i, j, k), center_shape, border)
+                        tile = tiling.copy(inp, tile_shape, lo, hi)
+                        out = self.model([tile])[0]
+                        tiling.copy_back(output, out, center_shape, lo, hi, border)
+        return [output.cpu()]
+
+    def _evaluate_and_save(self, loader, split_into_tiles, val_metrics, track_metric, results, epoch, comparator):
+        for m in val_metrics:
+            m.reset()
+        self.model.eval()
+        for batch in loader:
+            assert isinstance(batch[0], list) and isinstance(batch[1], list)
+            if split_into_tiles:
+                output = self.predict_tiled(batch, tuple(batch[1][0].shape))
+                target = list(batch[1])
+            else:
+                output = self.predict(batch)
+                target = self._to_device(batch[1])
+            for m in val_metrics:
+                m.update(target, output)                                     # train.py:304: (ground, predict)
+        val = 0.0
+        for m in val_metrics:
+            if m.name == track_metric:
+                val = m.get()
+            _log_metric(self.tb_writer, m, "val/", epoch)
+            results[m.name].append(m.get())
+        if comparator(val, self.state.best_val):                             # train.py:315-318
+            self.state.best_val = val
+            self._save(suffix="best_model")
+            print("model saved")
+
+    # ------------------------------------------------------------------ checkpoints (train.py:320-339)
+    def _ckpt(self, suffix):
+        return os.path.join(self.model_path, self.name + suffix + ".pth")    # no separator, like the reference
+
+    def _save(self, suffix):
+        torch.save({"state": self.state, "model": self.model}, self._ckpt(suffix))
+
+    def _load(self, suffix):
+        from .compat import install_aliases
+        install_aliases()                      # reference pickles name the modules `model` and `train`
+        print("loading model %s" % suffix)
+        s = torch.load(self._ckpt(suffix), map_location=torch.device("cpu"), weights_only=False)
+        self.state = s["state"]
+        if self.model is None:
+            self.model = s["model"]
+        else:
+            src = s["model"].state_dict()
+            want = self.model.state_dict().keys()
+            # a DataParallel-saved checkpoint carries the `module.` prefix (export_onnx_group_norm.py:28-32)
+            if not any(k.startswith("module.") for k in want):
+                src = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in src.items()}
+            self.model.load_state_dict(src)
+
+    def load_latest(self):
+        self._load("last_model")
+
+    def load_best(self):
+        self._load("best_model")

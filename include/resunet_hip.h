@@ -1,0 +1,144 @@
+/* resunet_hip.h -- C-ABI of libresunet_hip.so, the MI355X (gfx950) implementation of the ResUNet hot path
+ * of lachinov/brats2019.
+ *
+ * The reference has no FFI of its own: the path is stock torch.nn calls inside model.py / loss.py.  This
+ * header is therefore the boundary a maintainer binds with ctypes; each entry point
+ * names the reference call site (file:line into the reference repo) whose arithmetic it replaces.
+ *
+ * Conventions:
+ *   - all tensors are contiguous NCDHW float32 DEVICE pointers owned by the caller (PyTorch-ROCm
+ *     `tensor.data_ptr()`); the library never allocates user-visible memory -- scratch comes from the
+ *     caller-provided workspace (`ws`, `ws_bytes`; sizes from the *_workspace_bytes queries);
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*; 0 = default stream), performs no
+ *     device synchronisation and no hipMalloc: calls are graph-capturable;
+ *   - return 0 on success, a negative RU_E* code on error; `ru_last_error()` returns the thread-local
+ *     message; nothing throws across the ABI.
+ */
+#ifndef RESUNET_HIP_H_
+#define RESUNET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RU_OK 0
+#define RU_EINVAL (-1)    /* bad argument / unsupported shape */
+#define RU_ENOMEM (-2)    /* workspace too small */
+#define RU_EHIP (-3)      /* HIP runtime error (launch failed ...) */
+#define RU_ESTATE (-4)    /* call order violated (backward without forward ...) */
+
+typedef void* ru_stream_t;                /* hipStream_t */
+typedef struct ru_unet* ru_unet_t;        /* opaque engine handle */
+
+const char* ru_last_error(void);
+int ru_version(void);                     /* 100*major + minor */
+/* 1 if a HIP device is usable by this process, 0 otherwise (never throws) */
+int ru_device_ok(void);
+
+/* ---------------------------------------------------------------- convolutions
+ * nn.Conv3d as the reference constructs it: (k=3,stride=1,pad=1) model.py:72-73,336,348;
+ * (k=2,stride=2,pad=0) model.py:361-363; (k=1,stride=1,pad=0) model.py:393,401.  Cross-correlation,
+ * zero padding, weight layout [Cout][Cin][k][k][k].  D,H,W are the INPUT extents; for k=2 they must be even.
+ * `bias` may be NULL.  Exact-f32 arithmetic (v_mfma_f32_16x16x4_f32 / v_fmac_f32).  */
+size_t ru_conv3d_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, int k);
+int ru_conv3d_fwd(const float* x, const float* w, const float* bias, float* y,
+                  int N, int Cin, int Cout, int D, int H, int W, int k,
+                  void* ws, size_t ws_bytes, ru_stream_t stream);
+/* dx = d(loss)/dx given dy (autograd of the calls above) */
+int ru_conv3d_bwd_data(const float* dy, const float* w, float* dx,
+                       int N, int Cin, int Cout, int D, int H, int W, int k,
+                       void* ws, size_t ws_bytes, ru_stream_t stream);
+/* dw [Cout][Cin][k][k][k] and (if db != NULL) db[Cout] */
+int ru_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                         int N, int Cin, int Cout, int D, int H, int W, int k,
+                         void* ws, size_t ws_bytes, ru_stream_t stream);
+
+/* ---------------------------------------------------------------- GroupNorm (+ fused LeakyReLU / residual)
+ * nn.GroupNorm(G, C), eps, affine (model.py:95-96,338) followed by LeakyReLU(slope) (model.py:93-94; pass
+ * slope = 1 for "no activation", as after norm_input, model.py:413) and, if residual != NULL, the Residual
+ * skip add `x + out` (model.py:115).  V = D*H*W.  mean/rstd: [N*G] outputs (saved for backward).  */
+size_t ru_groupnorm_workspace_bytes(int N, int C, size_t V);
+int ru_groupnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                     float* mean, float* rstd, int N, int C, size_t V, int G, float eps, float slope,
+                     void* ws, size_t ws_bytes, ru_stream_t stream);
+/* backward of y = lrelu(GN(x)): dy is d/d(activated output); the LeakyReLU mask is recomputed from the sign
+ * of the normalised value (== sign of the in-place output the reference keeps).
+ * dgamma/dbeta are OVERWRITTEN.  */
+int ru_groupnorm_bwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                     const float* dy, float* dx, float* dgamma, float* dbeta,
+                     int N, int C, size_t V, int G, float slope,
+                     void* ws, size_t ws_bytes, ru_stream_t stream);
+
+/* ---------------------------------------------------------------- LeakyReLU (model.py:352,422) */
+int ru_leaky_relu_fwd(const float* x, float* y, size_t n, float slope, ru_stream_t stream);
+int ru_leaky_relu_bwd(const float* y, const float* dy, float* dx, size_t n, float slope, ru_stream_t stream);
+
+/* ---------------------------------------------------------------- trilinear x2 (model.py:12-14)
+ * F.interpolate(scale_factor=2, mode='trilinear'), align_corners=False.  D,H,W = INPUT extents.  */
+int ru_upsample2x_trilinear_fwd(const float* x, float* y, int N, int C, int D, int H, int W, ru_stream_t stream);
+int ru_upsample2x_trilinear_bwd(const float* dy, float* dx, int N, int C, int D, int H, int W, ru_stream_t stream);
+
+/* ---------------------------------------------------------------- sigmoid (model.py:351,431) */
+int ru_sigmoid_fwd(const float* x, float* y, size_t n, ru_stream_t stream);
+
+/* ---------------------------------------------------------------- criterion (loss.py:64-79,98-122; train.py:203-205)
+ * Phase 1: per-class partial sums over THIS rank's shard, float64:
+ *     sums[0..C)  = sum_{n,v} p*g          (Dice intersection, no epsilon)
+ *     sums[C..2C) = sum_{n,v} (p*p + g)    (Dice union, no epsilon)
+ *     sums[2C]    = sum g*log(p+1e-6) + bg_weight*(1-g)*log((1+1e-6)-p)
+ * (all-reduce `sums` across data-parallel ranks between the phases).
+ * Phase 2: dp = w_dice * dDice/dp + w_bce * dBCE/dp with the GLOBAL sums and GLOBAL element count
+ * (`count` = N_global*C*V).  The reference's training criterion is w_dice = w_bce = 0.5, bg_weight 1e-2,
+ * priority 1 (main.py:126-128).  loss value: see ru_criterion_value().  */
+size_t ru_criterion_workspace_bytes(int N, int C, size_t V);
+int ru_criterion_sums(const float* p, const float* g, double* sums, int N, int C, size_t V, float bg_weight,
+                      void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_criterion_grad(const float* p, const float* g, const double* sums, double count,
+                      float w_dice, float w_bce, float bg_weight, float priority,
+                      float* dp, int N, int C, size_t V, ru_stream_t stream);
+/* host helper: (dice, bce) from global sums (host pointer) */
+int ru_criterion_value(const double* sums_host, int C, double count, double priority, double* dice, double* bce);
+
+/* ---------------------------------------------------------------- optimizer (main.py:133-142)
+ * torch.optim.Adam(amsgrad=True) with L2 weight decay added to the gradient; `step` is 1-based.  */
+int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vmax, size_t n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         ru_stream_t stream);
+
+/* ---------------------------------------------------------------- whole-network engine
+ * model.UNet(depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs) (model.py:309)
+ * with block=Residual and 4 input channels (model.py:336).  Parameters live in ONE flat float buffer in
+ * reference state_dict() order (ru_unet_param_* describe it); gradients are written to a flat buffer of
+ * the same layout (dead parameters -- decoder_convs.{depth-1}.*, decoder_convs1x1.{depth-1} -- get zeros,
+ * model.py:420: they are constructed but never executed).  */
+ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const int* decoder_layers,
+                         const int* number_of_channels, int number_of_outputs);
+void ru_unet_destroy(ru_unet_t h);
+int ru_unet_param_count(ru_unet_t h);
+const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
+int ru_unet_param_ndim(ru_unet_t h, int i);
+int ru_unet_param_dim(ru_unet_t h, int i, int d);
+size_t ru_unet_param_offset(ru_unet_t h, int i);             /* in floats, into the flat buffer */
+size_t ru_unet_param_total(ru_unet_t h);                     /* floats */
+int ru_unet_param_is_dead(ru_unet_t h, int i);
+size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int W, int training);
+/* UNet.forward (model.py:407-433): x [N,4,D,H,W] -> probs [N,n_out,D,H,W] (sigmoid).  D,H,W divisible by
+ * 2^(depth-1).  training != 0 keeps activations in `ws` for ru_unet_backward.  */
+int ru_unet_forward(ru_unet_t h, const float* params, const float* x, float* probs,
+                    int N, int D, int H, int W, int training,
+                    void* ws, size_t ws_bytes, ru_stream_t stream);
+/* loss.backward() through the network (train.py:210): dprobs = d(loss)/d(probs) -> grads (flat, overwritten).
+ * Must follow a training-mode ru_unet_forward with the same params/ws.  dx (may be NULL) = d/d(input).  */
+int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx,
+                     ru_stream_t stream);
+/* per-layer GroupNorm statistics of the last forward, for parity checks: copies mean/rstd [N*8] of the
+ * idx-th executed GroupNorm (execution order) into DEVICE buffers.  Returns number of GN layers if idx<0. */
+int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESUNET_HIP_H_ */

@@ -1,0 +1,173 @@
+"""GPU parity, whole network: UNet.forward / loss / backward through libresunet_hip.so vs (a) the reference's own
+outputs in tests/golden (unet32, unet_small, unet128) and (b) the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): probabilities within 1e-3 of the CPU path (we hold 2e-5 on the f32 path);
+masks (> 0.5) bit-exact, allowing only voxels whose reference probability lies within 1e-5 of the threshold
+(SURVEY section 7 'Bit-exact masks': the CPU path's own thread-order noise is 2-3e-7)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resunet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+SMALL = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[8, 16, 32], number_of_outputs=3)
+
+
+def build_model(cfg, seed):
+    from brats2019_amd import model as M
+    net = M.UNet(**cfg)
+    params = O.make_params(seed, **cfg)
+    net.load_state_dict({k: T(v) for k, v in params.items()})
+    return net.cuda(), params
+
+
+def run_train_step(cfg, n, dhw, seed):
+    from brats2019_amd import loss as L
+    net, params = build_model(cfg, seed)
+    x = T(O.make_input(n, *dhw, seed=seed)).cuda()
+    g = T(O.make_target(n, *dhw, seed=seed)).cuda()
+    net.train()
+    out = net([x])
+    crit = [L.Dice_loss_joint(index=0, priority=1), L.BCE_Loss(index=0, bg_weight=1e-2)]       # main.py:126-128
+    vals = [c(out, [g]) for c in crit]
+    loss = sum(vals) / len(vals)                                                                # train.py:203-205
+    loss.backward()
+    return net, out[0].detach(), loss, vals
+
+
+def check_against_fixture(g, net, probs, loss, vals, grad_rel):
+    p = probs.cpu().numpy()
+    err = np.abs(p - g["probs"]).max()
+    assert err <= 2e-5, "max |dp| = %.3e" % err
+    assert abs(float(loss) - float(g["loss"])) < 5e-6
+    assert abs(float(vals[0]) - float(g["loss_dice"])) < 5e-6 and abs(float(vals[1]) - float(g["loss_bce"])) < 5e-6
+    dead = set(g["dead_params"].tolist())
+    for k, prm in net.named_parameters():
+        if k in dead:
+            assert prm.grad is None, k                       # never-executed modules keep grad=None (model.py:420)
+            continue
+        assert prm.grad is not None, k
+        gr = prm.grad.detach().cpu().numpy().astype(np.float64).ravel()
+        ref = float(g["gnorm_" + k])
+        got = float(np.sqrt((gr ** 2).sum()))
+        assert abs(got - ref) <= grad_rel * ref + 1e-9, (k, got, ref)
+        if "gfull_" + k in g:
+            np.testing.assert_allclose(gr, g["gfull_" + k].ravel().astype(np.float64), rtol=0, atol=grad_rel * np.abs(g["gfull_" + k]).max() + 1e-9,
+                                       err_msg=k)
+        samp = gr[:: max(1, gr.size // 16)][:16]
+        np.testing.assert_allclose(samp, g["gsamp_" + k].astype(np.float64), rtol=0, atol=10 * grad_rel * ref / np.sqrt(gr.size) + 1e-9, err_msg=k)
+
+
+def test_unet32_train_step_matches_reference_fixture(golden):
+    g = golden("unet32")
+    net, probs, loss, vals = run_train_step(O.DEFAULT_CFG, 1, (32, 32, 32), 1337)
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-4)
+    assert int((probs.cpu().numpy() > 0.5).sum()) == int(g["mask_count"])
+
+
+def test_unet_small_config_train_step_matches_reference_fixture(golden):
+    g = golden("unet_small")
+    net, probs, loss, vals = run_train_step(SMALL, 2, (16, 24, 16), 7)
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-4)
+
+
+def test_gn_statistics_match_reference(golden):
+    g = golden("unet32")
+    net, _ = build_model(O.DEFAULT_CFG, 1337)
+    x = T(O.make_input(1, 32, 32, 32, seed=1337)).cuda()
+    with torch.no_grad():
+        net([x])
+    stats = net._get_engine().gn_stats()
+    # execution order of the GroupNorm layers (model.py:407-433)
+    order = ["norm_input", "conv_first.0.norm1", "conv_first.0.norm2"]
+    for i, nb in enumerate([2, 2, 4]):
+        for j in range(nb):
+            order += ["encoder_convs.%d.%d.norm1" % (i, j), "encoder_convs.%d.%d.norm2" % (i, j)]
+    for i in (2, 1, 0):
+        order += ["decoder_convs.%d.0.norm1" % i, "decoder_convs.%d.0.norm2" % i]
+    assert len(stats) == len(order)
+    for name, (mean, rstd) in zip(order, stats):
+        ref = g["gnstat_" + name]
+        np.testing.assert_allclose(mean.cpu().numpy(), ref[0].ravel(), rtol=1e-4, atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(rstd.cpu().numpy(), ref[1].ravel(), rtol=1e-4, err_msg=name)
+
+
+def test_unet128_forward_mask_bit_exact_vs_reference(golden):
+    """BASELINE config 2: fp32 forward, batch 1, 128^3 x 4ch; labels bit-exact vs the CPU path."""
+    g = golden("unet128")
+    net, _ = build_model(O.DEFAULT_CFG, 1337)
+    x = T(O.make_input(1, 128, 128, 128, seed=1337)).cuda()
+    net.eval()
+    with torch.no_grad():
+        probs = net([x])[0].cpu().numpy()
+    flat = probs.ravel()
+    samp = flat[:: int(g["sample_stride"])][:4096]
+    assert np.abs(samp - g["samples"]).max() <= 2e-5
+    mask = probs > 0.5
+    ref_mask = np.unpackbits(g["mask_packed"])[: mask.size].astype(bool).reshape(mask.shape)
+    diff = mask != ref_mask
+    ndiff = int(diff.sum())
+    assert ndiff <= int(g["near_half_1e-5"]), "%d differing voxels" % ndiff
+    assert (np.abs(probs[diff] - 0.5) < 1e-5).all()
+    print("unet128: %d / %d mask voxels differ (all within 1e-5 of 0.5); sha256 equal: %s" % (
+        ndiff, mask.size, hashlib.sha256(np.packbits(mask.ravel()).tobytes()).hexdigest() == str(g["mask_sha256"])))
+    # metrics.Dice yardstick between our masks and the reference's: 1.0 up to the threshold voxels
+    d = O.dice_metric(mask.astype(np.float32), ref_mask.astype(np.float32))
+    assert (d > 1.0 - 1e-5).all()
+
+
+def test_unet_vs_oracle_odd_extents_batch2():
+    """extents that are multiples of 8 but not of the tile sizes; batch 2; fwd+bwd vs the CPU oracle (autograd)."""
+    cfg = O.DEFAULT_CFG
+    n, dhw, seed = 2, (24, 40, 16), 99
+    net, probs, loss, vals = run_train_step(cfg, n, dhw, seed)
+    params = O.make_params(seed, **cfg)
+    ref_probs, ref_loss, ref_grads = O.forward_backward(params, O.make_input(n, *dhw, seed=seed), O.make_target(n, *dhw, seed=seed), **cfg)
+    assert np.abs(probs.cpu().numpy() - ref_probs).max() <= 2e-5
+    assert abs(float(loss) - ref_loss) < 5e-6
+    for k, prm in net.named_parameters():
+        if ref_grads[k] is None:
+            assert prm.grad is None
+            continue
+        ref = ref_grads[k].astype(np.float64)
+        got = prm.grad.detach().cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-9, k
+
+
+def test_engine_dx_and_second_step_determinism():
+    """d/d(input) against oracle autograd; two identical steps give bit-identical gradients (fixed-order reductions)."""
+    from brats2019_amd.engine import UNetEngine
+    from brats2019_amd import ops
+    cfg, seed, dhw = SMALL, 3, (16, 16, 16)
+    params = O.make_params(seed, **cfg)
+    eng = UNetEngine(**cfg)
+    flat = torch.empty(eng.layout.total, dtype=torch.float32, device="cuda")
+    for k, v in eng.layout.views(flat).items():
+        v.copy_(T(params[k]))
+    x = T(O.make_input(1, *dhw, seed=seed)).cuda()
+    g = T(O.make_target(1, *dhw, seed=seed)).cuda()
+    grads = []
+    for _ in range(2):
+        probs = eng.forward(flat, x, training=True)
+        sums = ops.criterion_sums(probs, g, 1e-2)
+        dp = ops.criterion_grad(probs, g, sums, float(probs.numel()))
+        gr, dx = eng.backward(flat, dp, want_dx=True)
+        grads.append((gr.clone(), dx.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    p = O.to_torch(params, requires_grad=True)
+    xt = T(O.make_input(1, *dhw, seed=seed)).requires_grad_(True)
+    O.criterion(O.unet_forward(p, xt, **cfg), T(O.make_target(1, *dhw, seed=seed))).backward()
+    ref = xt.grad.numpy()
+    assert np.abs(grads[0][1].cpu().numpy() - ref).max() <= 5e-4 * np.abs(ref).max()
+
+
+def test_cpu_input_fails_loudly():
+    from brats2019_amd import model as M
+    net = M.UNet(**SMALL)
+    with pytest.raises(RuntimeError):
+        net([torch.zeros(1, 4, 8, 8, 8)])
