@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table: v_mfma_f32_16x16x4_f32, dense
+CPU_BASELINE_THREADS = 32         # default cap, see cpu_baseline()
 FWD_GFLOP_PER_VOL = 299.37        # algorithmic conv FLOPs per 128^3 volume, forward
 FWDBWD_GFLOP_PER_VOL = 890.87     # forward + backward
 
@@ -115,10 +116,12 @@ def roofline_probe(batch, size, launches=20):
             "algorithmic_bytes_per_launch": int(2 * 16 * batch * size ** 3 * 4)}
 
 
-def cpu_baseline(size):
-    """The CPU oracle = the reference's op sequence on torch CPU, fwd+loss+bwd, batch 1."""
+def cpu_baseline(size, threads=0):
+    """The CPU oracle = the reference's op sequence on torch CPU, fwd+loss+bwd, batch 1.
+    `cores` = torch threads actually used: on a many-core host the oneDNN/OpenMP path of this op mix is fastest well
+    below the hardware thread count (tools/cpu_threads_probe.py), so the default caps it."""
     from oracle import resunet_oracle as O
-    cores = os.cpu_count() or 1
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)
     params = O.make_params(1337, **O.DEFAULT_CFG)
     x, g = O.make_input(1, size, size, size), O.make_target(1, size, size, size)
@@ -146,6 +149,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[2]: 4)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
     args = ap.parse_args()
 
@@ -199,7 +203,7 @@ def main():
                       "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2)}
         out["roofline"] = roofline_probe(args.batch, args.size)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.size)
+            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

@@ -1,0 +1,162 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol that
+include/resunet_hip.h declares; the ctypes table covers the header; the host mirrors keep the reference's
+surface (state-dict keys/order, checkpoint layout, list-in/list-out) and fail loudly without a GPU."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resunet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "resunet_hip.h")
+T = torch.from_numpy
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ru_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from brats2019_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from brats2019_amd import build
+        build.build(verbose=False)
+    return L.load()
+
+
+def test_library_exports_every_header_symbol(lib):
+    from brats2019_amd import _lib as L
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libresunet_hip.so does not export %s" % n
+    assert sorted(L.SIGNATURES.keys()) == names, "ctypes table and header disagree"
+    assert lib.ru_version() >= 100
+    assert isinstance(lib.ru_last_error(), bytes)
+
+
+def test_param_layout_matches_reference_state_dict_order(lib):
+    from brats2019_amd.engine import ParamLayout
+    for cfg in (O.DEFAULT_CFG, dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[8, 16, 32], number_of_outputs=3)):
+        lay = ParamLayout(**cfg)
+        spec = O.state_dict_spec(**cfg)                       # pinned to the reference by tests/test_oracle_golden.py
+        assert [k for k, _ in spec] == list(lay.entries.keys())
+        off = 0
+        for k, shape in spec:
+            assert lay.entries[k][0] == tuple(shape) and lay.entries[k][1] == off
+            off += int(np.prod(shape))
+        assert lay.total == off
+        dead = {k for k, v in lay.entries.items() if v[2]}
+        d = cfg["depth"] - 1
+        assert dead == {k for k, _ in spec if k.startswith("decoder_convs.%d." % d) or k.startswith("decoder_convs1x1.%d." % d)}
+    full = ParamLayout(**O.DEFAULT_CFG)
+    assert full.total == 5427955 and sum(int(np.prod(v[0])) for v in full.entries.values() if v[2]) == 918016
+
+
+def test_unet_module_surface(golden):
+    from brats2019_amd import model as M
+    g = golden("unet32")
+    net = M.UNet(**O.DEFAULT_CFG)
+    keys = list(net.state_dict().keys())
+    assert keys == [k for k, _ in O.state_dict_spec(**O.DEFAULT_CFG)]
+    assert set(g["dead_params"].tolist()) <= set(keys)
+    for name in ("UNet", "Residual", "conv", "Trilinear"):
+        assert hasattr(M, name)
+    # HIP-only: a CPU forward must fail loudly, not fall back
+    with pytest.raises(RuntimeError):
+        net([torch.zeros(1, 4, 8, 8, 8)])
+    with pytest.raises(RuntimeError):
+        M.Residual(8, 8, 1)(torch.zeros(1, 8, 4, 4, 4))
+
+
+def test_bad_configuration_is_rejected(lib):
+    from brats2019_amd.engine import ParamLayout
+    with pytest.raises(RuntimeError):
+        ParamLayout(depth=3, encoder_layers=[1, 1, 1], decoder_layers=[1, 1, 1], number_of_channels=[12, 24, 48], number_of_outputs=3)
+    from brats2019_amd.engine import UNetEngine
+    eng = UNetEngine(**O.DEFAULT_CFG)
+    assert lib.ru_unet_workspace_bytes(eng.h, 1, 20, 16, 16, 0) == 0          # 20 is not divisible by 8
+    assert b"divisible" in lib.ru_last_error()
+    assert lib.ru_unet_workspace_bytes(eng.h, 1, 16, 16, 16, 1) > lib.ru_unet_workspace_bytes(eng.h, 1, 16, 16, 16, 0) > 0
+
+
+def test_reference_checkpoint_unpickles_into_host_mirror(golden, tmp_path):
+    """tests/golden/ckpt/tiny/tinybest_model.pth was written by the REFERENCE's Trainer._save (train.py:320-324)."""
+    import shutil
+    from brats2019_amd import train as TR, model as M
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "ckpt", "tiny"), tmp_path / "tiny")
+    saved = {k: sys.modules.get(k) for k in ("model", "train", "loss")}
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        tr = TR.Trainer(name="tiny", models_root=str(tmp_path), model=None, rewrite=False, connect_tb=False)
+        assert tr.resume_training
+        tr.load_best()
+        assert isinstance(tr.model, M.UNet) and isinstance(tr.state, TR.TrainingState)
+        assert (tr.state.epoch, tr.state.global_step, tr.state.best_val, tr.state.cuda) == (3, 77, 1.25, False)
+        cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
+        params = O.make_params(23, **cfg)
+        sd = tr.model.state_dict()
+        assert list(sd.keys()) == list(params.keys())
+        for k, v in params.items():
+            assert np.array_equal(sd[k].numpy(), v), k
+        # state-dict route into a freshly constructed mirror, incl. the DataParallel `module.` prefix
+        net = M.UNet(**cfg)
+        tr2 = TR.Trainer(name="tiny", models_root=str(tmp_path), model=net, rewrite=False, connect_tb=False)
+        tr2.load_best()
+        assert all(np.array_equal(net.state_dict()[k].numpy(), v) for k, v in params.items())
+        # our own save -> load round trip keeps the reference file naming (no separator)
+        tr2.state.epoch = 9
+        tr2._save("last_model")
+        assert os.path.exists(tmp_path / "tiny" / "tinylast_model.pth")
+        tr3 = TR.Trainer(name="tiny", models_root=str(tmp_path), model=None, connect_tb=False)
+        tr3.load_latest()
+        assert tr3.state.epoch == 9 and list(tr3.model.state_dict().keys()) == list(params.keys())
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+
+
+def test_tiling_helpers_match_reference(golden):
+    from brats2019_amd import tiling
+    g = golden("tiling")
+    grid = tiling.grid_for(g["shape"], g["center"])
+    assert grid == list(g["grid"])
+    idx = 0
+    for i in range(grid[0]):
+        for j in range(grid[1]):
+            for k in range(grid[2]):
+                lo, hi = tiling.get_indices((i, j, k), g["center"], g["border"])
+                assert lo == list(g["index_min"][idx]) and hi == list(g["index_max"][idx])
+                idx += 1
+    data = T(g["small_data"])
+    res = torch.zeros_like(data)
+    c, b, tl = (8, 8, 8), (4, 4, 4), (16, 16, 16)
+    g2 = tiling.grid_for(data.shape[2:], c)
+    n = 0
+    for i in range(g2[0]):
+        for j in range(g2[1]):
+            for k in range(g2[2]):
+                lo, hi = tiling.get_indices((i, j, k), c, b)
+                tile = tiling.copy(data, tl, lo, hi)
+                assert np.array_equal(tile.numpy(), g["small_tiles"][n])
+                tiling.copy_back(res, tile, c, lo, hi, b)
+                n += 1
+    assert np.array_equal(res.numpy(), g["small_result"])
+
+
+def test_shard_assignment():
+    from brats2019_amd.parallel import DataParallelStep as S
+    assert [S.shard(32, r, 8) for r in range(8)] == [slice(4 * r, 4 * r + 4) for r in range(8)]
+    with pytest.raises(ValueError):
+        S.shard(6, 0, 4)
