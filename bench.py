@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table: v_mfma_f32_16x16x4_f32, dense
-CPU_BASELINE_THREADS = 32         # default cap, see cpu_baseline()
+CPU_BASELINE_THREADS = 16         # tools/cpu_threads_probe.py on the MI355X host: 8-16 threads are fastest (256 hw threads: 20x slower)
 FWD_GFLOP_PER_VOL = 299.37        # algorithmic conv FLOPs per 128^3 volume, forward
 FWDBWD_GFLOP_PER_VOL = 890.87     # forward + backward
 
@@ -78,7 +78,11 @@ def time_region(fn, iters, distributed):
     return dt
 
 
-def roofline_probe(batch, size, launches=20):
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
+HBM_PEAK_GBPS = 8000.0
+
+
+def roofline_probe(batch, size, precision, launches=20):
     """Dominant kernel: 3x3x3 conv 16->16 at size^3 (4 forward + 4 data-gradient launches of it per L0 block pair per step).
     Timed with HIP events on the stream the kernel is launched on (torch's current stream)."""
     from brats2019_amd import _lib as L
@@ -90,7 +94,8 @@ def roofline_probe(batch, size, launches=20):
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(batch, 16, 16, size, size, size, 3), dev)
 
     def launch():
-        L.check(lib.ru_conv3d_fwd(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "conv")
+        L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.PRECISIONS[precision],
+                                    L.ptr(ws), ws.numel(), L.stream()), "conv")
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -110,10 +115,22 @@ def roofline_probe(batch, size, launches=20):
             traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    abytes = 2 * 16 * batch * size ** 3 * 4
+    gbps = abytes / (ms * 1e-3) / 1e9
+    if precision == "bf16x3":
+        # executed MFMA work = 3 products x (28/27 tap padding) x algorithmic; at the dense bf16 peak that is 144 us for
+        # batch 4, the fp32 NCDHW in+out traffic at 8 TB/s is 134 us: the kernel sits on the ridge.  Reported against the
+        # bf16 MFMA peak with ALGORITHMIC flops (so frac <= 1/3.11 by construction) and against HBM with algorithmic bytes.
+        return {"bound": "mfma", "kernel": "conv3_sb_kernel<4,8> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3)" % (batch, size),
+                "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+                "algorithmic_bytes_per_launch": int(abytes), "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
+                "executed_mfma_frac": round(achieved * 3 * 28 / 27 / BF16_MFMA_PEAK_TFLOPS, 4),
+                "hbm_algorithmic_gbps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 4)}
     return {"bound": "mfma", "kernel": "conv3_f32_kernel<4,8,8,1> (3x3x3 conv 16->16, %d x %d^3)" % (batch, size),
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
-            "algorithmic_bytes_per_launch": int(2 * 16 * batch * size ** 3 * 4)}
+            "algorithmic_bytes_per_launch": int(abytes), "hbm_algorithmic_gbps": round(gbps, 1)}
 
 
 def cpu_baseline(size, threads=0):
@@ -148,6 +165,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[2]: 4)")
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="arithmetic of the 3x3x3 convolutions: split-bf16 3-product MFMA (default; |dp| ~ 5e-5, bar 1e-3) or exact f32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
@@ -161,7 +180,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    backend = P.HipBackend(device=dev)
+    backend = P.HipBackend(device=dev, precision=args.precision)
     flat = init_params(backend)                      # same seed on every rank: identical replicas
     stepper = P.DataParallelStep(backend, flat)
     x, g = synth(args.batch, args.size, 1000 + rank, dev)
@@ -183,11 +202,13 @@ def main():
     out = {
         "metric": "volumes_per_sec_fwd_bwd_128cubed_x4ch", "value": round(value, 3), "unit": "volumes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16x3" else "f32", "data": "synthetic",
         "config": {"workload": "ResUNet([1,2,2,4],[1,1,1,1],[16,32,64,128],3) training step: fwd + Dice/BCE + bwd + grad all-reduce + Adam(amsgrad); "
                                "%d^3 x 4ch synthetic crops, per-GPU batch %d (BASELINE configs[2], weak-scaled as configs[3])" % (args.size, args.batch),
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "in_channels": 4,
-                   "parallelism": "dp%d" % world, "precision": "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
+                   "parallelism": "dp%d" % world,
+                   "precision": ("fp32 tensors in HBM; 3x3x3 conv fwd+dgrad on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 accumulate); "
+                                 "weight gradients and everything else fp32") if args.precision == "bf16x3" else "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
         "final_loss": round(loss, 6),
         "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
     }
@@ -201,7 +222,7 @@ def main():
         dtf = time_region(fwd, it, False)
         out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3),
                       "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2)}
-        out["roofline"] = roofline_probe(args.batch, args.size)
+        out["roofline"] = roofline_probe(args.batch, args.size, args.precision)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if rank == 0:

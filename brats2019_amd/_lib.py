@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libresunet_hip.so")
 
 _lib = None
+PRECISIONS = {"f32": 0, "bf16x3": 1}      # RU_PREC_F32 / RU_PREC_BF16X3
 
 _vp, _f, _d, _i, _sz = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_size_t
 
@@ -24,6 +25,8 @@ SIGNATURES = {
     "ru_conv3d_workspace_bytes": (_sz, [_i] * 7),
     "ru_conv3d_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
+    "ru_conv3d_fwd_p": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
+    "ru_conv3d_bwd_data_p": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
     "ru_groupnorm_workspace_bytes": (_sz, [_i, _i, _sz]),
     "ru_groupnorm_fwd": (_i, [_vp] * 7 + [_i, _i, _sz, _i, _f, _f, _vp, _sz, _vp]),
@@ -40,6 +43,8 @@ SIGNATURES = {
     "ru_adam_amsgrad_step": (_i, [_vp] * 5 + [_sz] + [_f] * 5 + [_i, _vp]),
     "ru_unet_create": (_vp, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
     "ru_unet_destroy": (None, [_vp]),
+    "ru_unet_set_precision": (_i, [_vp, _i]),
+    "ru_unet_get_precision": (_i, [_vp]),
     "ru_unet_param_count": (_i, [_vp]),
     "ru_unet_param_name": (C.c_char_p, [_vp, _i]),
     "ru_unet_param_ndim": (_i, [_vp, _i]),

@@ -16,11 +16,9 @@
 // Fusions: optional per-(n,c) affine + LeakyReLU on the INPUT while staging (GroupNorm-apply + activation of
 // the producer, model.py:92-94, never materialised); optional per-tile (sum, sumsq) of the OUTPUT for the
 // consumer GroupNorm's statistics; optional bias, residual add and sigmoid (model.py:431) in the epilogue.
-#include "ru_common.h"
+#include "conv3_epilogue.hpp"
 
 namespace ru {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int TZ, int TY, int KC, int NT>
 struct C3 {
@@ -34,12 +32,6 @@ struct C3 {
     static_assert(CS >= HVOL && CS % 32 == 16 && WS % 32 == 16, "bank layout");
     static_assert(KC % 4 == 0, "K chunk is a multiple of the MFMA K");
 };
-
-__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
-    // give each XCD (block b runs on XCD b % 8) a contiguous run of tiles so halo re-reads hit its L2
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
 
 template <int TZ, int TY, int KC, int NT>
 __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, int ntz, int nty, int ntx) {
@@ -60,19 +52,41 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
     const int D = a.D, H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
 
-    // per-thread staging slots: halo-linear index s = tid + 256 j  ->  global offset inside one channel
+    // ---- per-thread staging slots, computed once (they do not depend on the channel).
+    // Vector path (W % 4 == 0): a halo row [x0-1, x0+17) is covered by six 16-byte aligned segments [x0-4+4q, +4);
+    // one slot = one float4 load; all KC channels' loads of a thread are issued before the first LDS store.
+    // Scalar path (ragged W): one slot = one element.
+    constexpr int NROW = P::HZ * HY;
+    constexpr int NSV = (NROW * 6 + 255) / 256;
     constexpr int NS = (HVOL + 255) / 256;
-    int goff[NS];
+    const bool vec = (W & 3) == 0;
+    int goff[NS];     // scalar path: global offset inside one channel, -1 = zero fill
+    int gv[NSV];      // vector path: global offset of the float4, -1 = zero fill, -2 = no slot
+    int lv[NSV];      // vector path: LDS offset of element 0 of the float4 (may point 3 before the row start)
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = tid + j * 256;
-        const int hz = s / (HY * HX);
-        const int r = s - hz * (HY * HX);
-        const int hy = r / HX;
-        const int hx = r - hy * HX;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-        const bool ok = (s < HVOL) && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        goff[j] = ok ? (gz * H + gy) * W + gx : -1;
+        for (int j = 0; j < NSV; ++j) {
+            const int item = tid + j * 256;
+            const int row = item / 6, q = item - row * 6;
+            const int hz = row / HY, hy = row - hz * HY;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
+            const bool slot = item < NROW * 6;
+            const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+            gv[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
+            lv[j] = row * HX + 4 * q - 3;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int s = tid + j * 256;
+            const int hz = s / (HY * HX);
+            const int r = s - hz * (HY * HX);
+            const int hy = r / HX;
+            const int hx = r - hy * HX;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = (s < HVOL) && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            goff[j] = ok ? (gz * H + gy) * W + gx : -1;
+        }
     }
 
     f32x4 acc[MT][NT];
@@ -90,25 +104,63 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
     for (int c0 = 0; c0 < a.CinP; c0 += KC) {
         if (c0) __syncthreads();
         // ---- stage the input halo tile (zero padding AFTER the fused transform: the reference pads the activated tensor)
-#pragma unroll 2
-        for (int c = 0; c < KC; ++c) {
-            const int cg = c0 + c;
-            const bool cok = cg < a.Cin;
-            const float* xp = a.x + ((size_t)n * a.Cin + (cok ? cg : 0)) * DHW;
-            float sc = 1.f, sh = 0.f;
-            if (xform && cok) { sc = a.in_scale[n * a.Cin + cg]; sh = a.in_shift[n * a.Cin + cg]; }
-            float v[NS];
+        if (vec) {
+            float4 v[KC][NSV];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) v[j] = (cok && goff[j] >= 0) ? xp[goff[j]] : 0.f;
+            for (int c = 0; c < KC; ++c) {
+                // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed by select below: a conditional load makes
+                // hipcc branch around it and wait vmcnt(0) per load (one load in flight per thread)
+                const int cg = c0 + c;
+                const float* xp = a.x + ((size_t)n * a.Cin + (cg < a.Cin ? cg : 0)) * DHW;
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                float t = v[j];
-                if (xform) {
-                    t = t * sc + sh;
-                    t = t > 0.f ? t : t * slope;
-                    if (goff[j] < 0) t = 0.f;
+                for (int j = 0; j < NSV; ++j) v[c][j] = *reinterpret_cast<const float4*>(xp + (gv[j] > 0 ? gv[j] : 0));
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int cg = c0 + c;
+                float sc = 1.f, sh = 0.f;
+                if (xform && cg < a.Cin) { sc = a.in_scale[n * a.Cin + cg]; sh = a.in_shift[n * a.Cin + cg]; }
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) {
+                    if (gv[j] == -2) continue;
+                    float t[4] = {v[c][j].x, v[c][j].y, v[c][j].z, v[c][j].w};
+                    const bool live = gv[j] >= 0 && cg < a.Cin;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (xform) {
+                            t[e] = t[e] * sc + sh;
+                            t[e] = t[e] > 0.f ? t[e] : t[e] * slope;
+                        }
+                        t[e] = live ? t[e] : 0.f;
+                    }
+                    const int q = (tid + j * 256) % 6;
+                    float* dst = xs + c * CS + lv[j];
+                    if (q == 0) dst[3] = t[3];                 // only x0-1 of the first segment is inside the halo row
+                    else if (q == 5) dst[0] = t[0];            // only x0+16 of the last one
+                    else { dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3]; }
                 }
-                if (tid + j * 256 < HVOL) xs[c * CS + tid + j * 256] = t;
+            }
+        } else {
+#pragma unroll 2
+            for (int c = 0; c < KC; ++c) {
+                const int cg = c0 + c;
+                const bool cok = cg < a.Cin;
+                const float* xp = a.x + ((size_t)n * a.Cin + (cok ? cg : 0)) * DHW;
+                float sc = 1.f, sh = 0.f;
+                if (xform && cok) { sc = a.in_scale[n * a.Cin + cg]; sh = a.in_shift[n * a.Cin + cg]; }
+                float v[NS];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) v[j] = xp[goff[j] > 0 ? goff[j] : 0];       // unconditional, clamped (see above)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    float t = v[j];
+                    if (xform) {
+                        t = t * sc + sh;
+                        t = t > 0.f ? t : t * slope;
+                    }
+                    t = (cok && goff[j] >= 0) ? t : 0.f;
+                    if (tid + j * 256 < HVOL) xs[c * CS + tid + j * 256] = t;
+                }
             }
         }
         // ---- stage the weight chunk  wp[tap][c0+kc][co0 ..]  ->  ws[tap][kc][WS]
@@ -142,77 +194,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
         }
     }
 
-    // ---- epilogue
-    const int zz = z0 + mz;
-    const int xq = x0 + (lane >> 4) * 4;
-    const bool vec = (W & 3) == 0;
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int yy = y0 + my0 + i;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int co = co0 + t * 16 + (lane & 15);
-            const bool ok = zz < D && yy < H && co < a.Cout && xq < W;
-            if (!ok) continue;
-            const size_t idx = (((size_t)n * a.Cout + co) * D + zz) * HW + (size_t)yy * W + xq;
-            f32x4 v = acc[i][t];
-            if (a.bias) { const float bv = a.bias[co]; v += bv; }
-            const int nvalid = (W - xq) < 4 ? (W - xq) : 4;
-            if (a.add) {
-                if (vec) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(a.add + idx);
-                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-                } else {
-                    for (int r = 0; r < nvalid; ++r) v[r] += a.add[idx + r];
-                }
-            }
-            if (a.stat_partials) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) { s1[t] += v[r]; s2[t] += v[r] * v[r]; }
-            }
-            if (a.sigmoid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + expf(-v[r]));
-            }
-            if (vec) {
-                *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                for (int r = 0; r < nvalid; ++r) a.y[idx + r] = v[r];
-            }
-        }
-    }
-    if (a.stat_partials) {
-        // lanes sharing (lane & 15) hold the same output channel: fold the 4 row groups, then the 4 waves
-        __syncthreads();   // all waves are done reading xs/ws
-        float* red = smem;  // [4 waves][NT*16][2]
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float u1 = s1[t], u2 = s2[t];
-            u1 += __shfl_xor(u1, 16); u2 += __shfl_xor(u2, 16);
-            u1 += __shfl_xor(u1, 32); u2 += __shfl_xor(u2, 32);
-            if (lane < 16) {
-                red[(wave * NT * 16 + t * 16 + lane) * 2 + 0] = u1;
-                red[(wave * NT * 16 + t * 16 + lane) * 2 + 1] = u2;
-            }
-        }
-        __syncthreads();
-        if (tid < NT * 16) {
-            const int co = co0 + tid;
-            if (co < a.Cout) {
-                float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { u1 += red[(w * NT * 16 + tid) * 2]; u2 += red[(w * NT * 16 + tid) * 2 + 1]; }
-                const int nblk = ntz * nty * ntx;
-                const int t = (tz * nty + ty) * ntx + tx;
-                float* p = a.stat_partials + (((size_t)n * a.Cout + co) * nblk + t) * 2;
-                p[0] = u1; p[1] = u2;
-            }
-        }
-    }
+    // ---- epilogue (bias / residual / GN tile statistics / sigmoid / store)
+    conv3_epilogue<MT, NT>(a, acc, smem, n, z0, y0, x0, mz, my0, co0, tz, ty, tx, ntz, nty, ntx);
 }
 
 // ------------------------------------------------------------------ host side
@@ -236,7 +219,8 @@ static C3Choice conv3_choose(int N, int Cin, int Cout, int D, int H, int W) {
     return {2, 4, kc, nt};
 }
 
-int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
+int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int mode) {
+    if (conv3_effective_mode(mode, W) == RU_PREC_BF16X3) return conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W);
     const C3Choice c = conv3_choose(N, Cin, Cout, D, H, W);
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16);
 }
@@ -269,6 +253,11 @@ int conv3_launch(const Conv3Args& a_in, hipStream_t s) {
     a.CoutP = conv3_cout_pad(a.Cout);
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.D > 0 && a.H > 0 && a.W > 0, "conv3: bad shape");
     RU_REQUIRE((size_t)a.D * a.H * a.W < (1u << 31), "conv3: volume too large for 32-bit voxel offsets");
+    if (conv3_effective_mode(a.mode, a.W) == RU_PREC_BF16X3) {
+        RU_REQUIRE(a.wfrag != nullptr, "conv3: bf16x3 mode needs packed weight fragments");
+        return conv3_sb_launch(a, s);
+    }
+    RU_REQUIRE(a.wp != nullptr, "conv3: f32 mode needs packed weights");
     const C3Choice c = conv3_choose(a.N, a.Cin, a.Cout, a.D, a.H, a.W);
 #define RU_C3_CASE(TZ, TY, KC, NT) \
     if (c.tz == TZ && c.ty == TY && c.kc == KC && c.nt == NT) return launch_cfg<TZ, TY, KC, NT>(a, s);

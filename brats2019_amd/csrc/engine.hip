@@ -88,6 +88,7 @@ struct BlockP {           // parameter indices of one Residual (model.py:81-97)
     int cin_down = 0, c = 0;
     // packed-weight slots (offsets in floats into the pack region)
     size_t pk_f1 = 0, pk_f2 = 0, pk_d1 = 0, pk_d2 = 0, pk_downT = 0;
+    size_t fk_f1 = 0, fk_f2 = 0, fk_d1 = 0, fk_d2 = 0;     // byte offsets of the split-bf16 weight fragments
 };
 
 struct GNSave {
@@ -122,6 +123,9 @@ struct ru_unet {
     std::vector<size_t> pk_upT, pk_decT;
     int conv_in = -1, nin_w = -1, nin_b = -1, conv_out_w = -1, conv_out_b = -1;
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
+    size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
+    int precision = RU_PREC_F32;
+    char* fpack = nullptr;
 
     // state of the last forward
     bool have_fwd = false, training = false;
@@ -183,6 +187,11 @@ static void assign_block_packs(ru_unet* h, BlockP& b) {
     b.pk_d1 = h->pk_total; h->pk_total += n;
     b.pk_d2 = h->pk_total; h->pk_total += n;
     if (b.down >= 0) { b.pk_downT = h->pk_total; h->pk_total += (size_t)8 * b.cin_down * b.c; }
+    const size_t f = conv3_sb_frag_bytes(b.c, b.c);
+    b.fk_f1 = h->fk_total; h->fk_total += f;
+    b.fk_f2 = h->fk_total; h->fk_total += f;
+    b.fk_d1 = h->fk_total; h->fk_total += f;
+    b.fk_d2 = h->fk_total; h->fk_total += f;
 }
 
 extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const int* decoder_layers,
@@ -228,6 +237,10 @@ extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const 
     h->pk_in = h->pk_total; h->pk_total += conv3_packed_floats(kInCh, ch[0]);
     h->pk_out = h->pk_total; h->pk_total += conv3_packed_floats(ch[0], number_of_outputs);
     h->pk_out_d = h->pk_total; h->pk_total += conv3_packed_floats(number_of_outputs, ch[0]);
+    h->fk_total = 0;
+    h->fk_in = h->fk_total; h->fk_total += conv3_sb_frag_bytes(kInCh, ch[0]);
+    h->fk_out = h->fk_total; h->fk_total += conv3_sb_frag_bytes(ch[0], number_of_outputs);
+    h->fk_out_d = h->fk_total; h->fk_total += conv3_sb_frag_bytes(number_of_outputs, ch[0]);
     for (auto& b : h->first_blocks) assign_block_packs(h, b);
     for (auto& lv : h->enc_blocks) for (auto& b : lv) assign_block_packs(h, b);
     for (int i = 0; i < depth - 1; ++i) for (auto& b : h->dec_blocks[i]) assign_block_packs(h, b);
@@ -239,6 +252,13 @@ extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const 
 }
 
 extern "C" void ru_unet_destroy(ru_unet_t h) { delete h; }
+extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
+    RU_REQUIRE(h && (precision == RU_PREC_F32 || precision == RU_PREC_BF16X3), "ru_unet_set_precision: bad argument");
+    h->precision = precision;
+    h->have_fwd = false;
+    return RU_OK;
+}
+extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
 extern "C" int ru_unet_param_count(ru_unet_t h) { return h ? (int)h->params.size() : 0; }
 extern "C" const char* ru_unet_param_name(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr; }
 extern "C" int ru_unet_param_ndim(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].ndim : 0; }
@@ -253,19 +273,26 @@ static inline float* G(const ru_unet* h, float* grads, int idx) { return grads ?
 
 static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     float* pk = h->pack;
+    // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments)
+    auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
+        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
+        // the f32 layout is always kept: ragged W falls back to the f32 kernel
+        RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
+        return RU_OK;
+    };
     auto blk = [&](const BlockP& b) -> int {
-        RU_RUN(conv3_pack_weights(P(h, params, b.conv1), pk + b.pk_f1, b.c, b.c, 0, s));
-        RU_RUN(conv3_pack_weights(P(h, params, b.conv2), pk + b.pk_f2, b.c, b.c, 0, s));
+        int rc = pack3(b.conv1, b.pk_f1, b.fk_f1, b.c, b.c, 0); if (rc) return rc;
+        rc = pack3(b.conv2, b.pk_f2, b.fk_f2, b.c, b.c, 0); if (rc) return rc;
         if (h->training) {
-            RU_RUN(conv3_pack_weights(P(h, params, b.conv1), pk + b.pk_d1, b.c, b.c, 1, s));
-            RU_RUN(conv3_pack_weights(P(h, params, b.conv2), pk + b.pk_d2, b.c, b.c, 1, s));
+            rc = pack3(b.conv1, b.pk_d1, b.fk_d1, b.c, b.c, 1); if (rc) return rc;
+            rc = pack3(b.conv2, b.pk_d2, b.fk_d2, b.c, b.c, 1); if (rc) return rc;
         }
         if (b.down >= 0) RU_RUN(transpose_launch(P(h, params, b.down), pk + b.pk_downT, b.c, 8 * b.cin_down, s));
         return RU_OK;
     };
-    RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), pk + h->pk_in, kInCh, h->ch[0], 0, s));
-    RU_RUN(conv3_pack_weights(P(h, params, h->conv_out_w), pk + h->pk_out, h->ch[0], h->nout, 0, s));
-    if (h->training) RU_RUN(conv3_pack_weights(P(h, params, h->conv_out_w), pk + h->pk_out_d, h->ch[0], h->nout, 1, s));
+    { int rc = pack3(h->conv_in, h->pk_in, h->fk_in, kInCh, h->ch[0], 0); if (rc) return rc; }
+    { int rc = pack3(h->conv_out_w, h->pk_out, h->fk_out, h->ch[0], h->nout, 0); if (rc) return rc; }
+    if (h->training) { int rc = pack3(h->conv_out_w, h->pk_out_d, h->fk_out_d, h->ch[0], h->nout, 1); if (rc) return rc; }
     for (auto& b : h->first_blocks) { int rc = blk(b); if (rc) return rc; }
     for (auto& lv : h->enc_blocks) for (auto& b : lv) { int rc = blk(b); if (rc) return rc; }
     for (int i = 0; i < h->depth - 1; ++i) for (auto& b : h->dec_blocks[i]) { int rc = blk(b); if (rc) return rc; }
@@ -277,16 +304,16 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
 }
 
 // y = conv3(x) with optional fused input transform, tile statistics -> GNSave (mean/rstd/scale/shift)
-static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, float* y, const GNSave* in_gn,
+static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, const char* wf, float* y, const GNSave* in_gn,
                     const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W) {
-    const int nblk = conv3_tiles_per_sample(N, Cin, Cout, D, H, W);
+    const int nblk = conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
     out_gn.mean = A.alloc((size_t)N * kGroups);
     out_gn.rstd = A.alloc((size_t)N * kGroups);
     out_gn.scale = A.alloc((size_t)N * Cout);
     out_gn.shift = A.alloc((size_t)N * Cout);
     Conv3Args a{};
-    a.x = x; a.wp = wp; a.y = y;
+    a.x = x; a.wp = wp; a.y = y; a.mode = h->precision; a.wfrag = wf;
     a.in_scale = in_gn ? in_gn->scale : nullptr;
     a.in_shift = in_gn ? in_gn->shift : nullptr;
     a.in_slope = kSlope;
@@ -321,10 +348,10 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     const size_t V = (size_t)D * H * W;
     sv.x = x; sv.N = N; sv.C = C; sv.D = D; sv.H = H; sv.W = W;
     sv.y1 = A.alloc((size_t)N * C * V);
-    int rc = conv3_gn(h, A, s, x, h->pack + bp.pk_f1, sv.y1, nullptr, P(h, params, bp.n1w), P(h, params, bp.n1b), sv.g1, N, C, C, D, H, W);
+    int rc = conv3_gn(h, A, s, x, h->pack + bp.pk_f1, h->fpack + bp.fk_f1, sv.y1, nullptr, P(h, params, bp.n1w), P(h, params, bp.n1b), sv.g1, N, C, C, D, H, W);
     if (rc) return rc;
     sv.y2 = A.alloc((size_t)N * C * V);
-    rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
+    rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, h->fpack + bp.fk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
     if (rc) return rc;
     sv.out = A.alloc((size_t)N * C * V);
     RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
@@ -339,6 +366,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
     h->gn_order.clear();
     h->pack = A.alloc(h->pk_total);
+    h->fpack = reinterpret_cast<char*>(A.alloc(h->fk_total / sizeof(float) + 64));
     int rc = pack_all(h, params, A, s);
     if (rc) return rc;
 
@@ -346,7 +374,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     const int C0 = h->ch[0];
     h->x_in = x;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
     if (rc) return rc;
     h->t0 = A.alloc((size_t)N * C0 * Vl(0));
     RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
@@ -402,6 +430,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     if (h->training) { h->probs = A.alloc((size_t)N * h->nout * Vl(0)); pdst = h->probs; }
     Conv3Args a{};
     a.x = cur; a.wp = h->pack + h->pk_out; a.bias = P(h, params, h->conv_out_b); a.y = pdst; a.sigmoid = 1;
+    a.mode = h->precision; a.wfrag = h->fpack + h->fk_out;
     a.N = N; a.Cin = C0; a.Cout = h->nout; a.D = Dl[0]; a.H = Hl[0]; a.W = Wl[0];
     RU_RUN(conv3_launch(a, s));
     if (h->training && !A.dry) {
@@ -458,7 +487,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
@@ -467,7 +496,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
-    d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout;       // skip path: dx = dout + dgrad(conv1)
+    d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
@@ -504,7 +533,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     }
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
-    dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
+    dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
     std::vector<const float*> dskip(depth - 1, nullptr);
@@ -662,6 +691,7 @@ extern "C" size_t ru_conv3d_workspace_bytes(int N, int Cin, int Cout, int D, int
     size_t b = 4096;
     if (k == 3) {
         b += align_up(conv3_packed_floats(Cin, Cout) * 4, 256) + align_up(conv3_packed_floats(Cout, Cin) * 4, 256);
+        b += align_up(conv3_sb_frag_bytes(Cin, Cout), 256) + align_up(conv3_sb_frag_bytes(Cout, Cin), 256);
         b += align_up(wgrad3_workspace_bytes(N, Cin, Cout, D, H, W), 256) + align_up(bias_grad_workspace_bytes(N, Cout, (size_t)D * H * W), 256);
     } else if (k == 1) {
         b += align_up((size_t)Cin * Cout * 4, 256) + align_up(wgrad1_workspace_bytes(N, Cin, Cout, (size_t)D * H * W), 256);
@@ -674,16 +704,36 @@ extern "C" size_t ru_conv3d_workspace_bytes(int N, int Cin, int Cout, int D, int
 
 extern "C" int ru_conv3d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int D, int H, int W, int k,
                              void* ws, size_t ws_bytes, ru_stream_t stream) {
+    return ru_conv3d_fwd_p(x, w, bias, y, N, Cin, Cout, D, H, W, k, RU_PREC_F32, ws, ws_bytes, stream);
+}
+
+// pack one 3x3x3 weight for `precision` into the workspace and fill the weight fields of `a`
+static int prep_conv3_weights(Conv3Args& a, const float* w, int Cin_f, int Cout_f, int mode, int precision, int W, WsCarver& C, hipStream_t s) {
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    a.mode = precision;
+    if (conv3_effective_mode(precision, W) == RU_PREC_BF16X3) {
+        void* wf = C.take(conv3_sb_frag_bytes(cin_conv, cout_conv) / 4 + 64);
+        RU_WS_OK(C);
+        a.wfrag = wf;
+        return conv3_sb_pack_weights(w, wf, Cin_f, Cout_f, mode, s);
+    }
+    float* wp = C.take(conv3_packed_floats(cin_conv, cout_conv));
+    RU_WS_OK(C);
+    a.wp = wp;
+    return conv3_pack_weights(w, wp, Cin_f, Cout_f, mode, s);
+}
+
+extern "C" int ru_conv3d_fwd_p(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int D, int H, int W, int k,
+                               int precision, void* ws, size_t ws_bytes, ru_stream_t stream) {
     RU_REQUIRE(x && w && y, "ru_conv3d_fwd: null argument");
+    RU_REQUIRE(precision == RU_PREC_F32 || precision == RU_PREC_BF16X3, "ru_conv3d_fwd: bad precision");
     hipStream_t s = (hipStream_t)stream;
     WsCarver C(ws, ws_bytes);
     if (k == 3) {
-        float* wp = C.take(conv3_packed_floats(Cin, Cout));
-        RU_WS_OK(C);
-        int rc = conv3_pack_weights(w, wp, Cin, Cout, 0, s);
-        if (rc) return rc;
         Conv3Args a{};
-        a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+        int rc = prep_conv3_weights(a, w, Cin, Cout, 0, precision, W, C, s);
+        if (rc) return rc;
+        a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
         return conv3_launch(a, s);
     }
     RU_REQUIRE(!bias, "ru_conv3d_fwd: bias only supported for k=3 (model.py:348)");
@@ -716,16 +766,20 @@ extern "C" int ru_conv3d_fwd(const float* x, const float* w, const float* bias, 
 
 extern "C" int ru_conv3d_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int D, int H, int W, int k,
                                   void* ws, size_t ws_bytes, ru_stream_t stream) {
+    return ru_conv3d_bwd_data_p(dy, w, dx, N, Cin, Cout, D, H, W, k, RU_PREC_F32, ws, ws_bytes, stream);
+}
+
+extern "C" int ru_conv3d_bwd_data_p(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int D, int H, int W, int k,
+                                    int precision, void* ws, size_t ws_bytes, ru_stream_t stream) {
     RU_REQUIRE(dy && w && dx, "ru_conv3d_bwd_data: null argument");
+    RU_REQUIRE(precision == RU_PREC_F32 || precision == RU_PREC_BF16X3, "ru_conv3d_bwd_data: bad precision");
     hipStream_t s = (hipStream_t)stream;
     WsCarver C(ws, ws_bytes);
     if (k == 3) {
-        float* wp = C.take(conv3_packed_floats(Cout, Cin));
-        RU_WS_OK(C);
-        int rc = conv3_pack_weights(w, wp, Cin, Cout, 1, s);
-        if (rc) return rc;
         Conv3Args a{};
-        a.x = dy; a.wp = wp; a.y = dx; a.N = N; a.Cin = Cout; a.Cout = Cin; a.D = D; a.H = H; a.W = W;
+        int rc = prep_conv3_weights(a, w, Cin, Cout, 1, precision, W, C, s);
+        if (rc) return rc;
+        a.x = dy; a.y = dx; a.N = N; a.Cin = Cout; a.Cout = Cin; a.D = D; a.H = H; a.W = W;
         return conv3_launch(a, s);
     }
     if (k == 1) {

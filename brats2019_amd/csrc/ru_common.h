@@ -47,12 +47,21 @@ struct Conv3Args {
     int sigmoid;             // apply 1/(1+exp(-v)) in the epilogue
     int N, Cin, Cout, D, H, W;
     int CinP, CoutP;
+    int mode;                // RU_PREC_F32: exact-f32 MFMA (wp); RU_PREC_BF16X3: split-bf16, 3 MFMA products (wfrag)
+    const void* wfrag;       // packed bf16 hi/lo weight fragments (conv3_sb.hip) when mode == RU_PREC_BF16X3
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
+// effective mode for a shape (the split-bf16 kernel needs W % 4 == 0; otherwise the f32 kernel runs)
+static inline int conv3_effective_mode(int mode, int W) { return (mode == RU_PREC_BF16X3 && (W & 3) == 0) ? RU_PREC_BF16X3 : RU_PREC_F32; }
 // number of spatial tiles per sample the kernel will use (== nblk of stat_partials)
-int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int mode);
 int conv3_launch(const Conv3Args& a, hipStream_t s);
+// split-bf16 path (conv3_sb.hip)
+int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_sb_launch(const Conv3Args& a, hipStream_t s);
+size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);
+int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);   // mode 0 fwd, 1 data-gradient
 // pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:
 // the packed conv maps Cout_f input channels to Cin_f output channels).
 int conv3_pack_weights(const float* w, float* wp, int Cin_f, int Cout_f, int mode, hipStream_t s);

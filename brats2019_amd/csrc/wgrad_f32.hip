@@ -28,11 +28,27 @@ struct W3 {
     static constexpr int LDS_FLOATS = OT * 16 * DS + CT * 16 * CS;
 };
 
+// One tile's staging state of a thread (vector path): global offsets of its float4 slots (clamped loads are always
+// valid; `live` says whether the value is used) and where they land in LDS.
+template <int NSX, int NSD>
+struct W3Slots {
+    int gx[NSX];     // x halo: float offset inside one channel volume (>= 0), -1 = zero fill, -2 = no slot
+    int lx[NSX];     // LDS offset of element 0 of the segment inside one channel (may start 3 before the row)
+    long gd[NSD];    // dy: absolute float offset, -1 = zero fill / no slot
+    int n;           // sample index of the tile
+};
+
 template <int TZ, int TY, int OT, int CT>
 __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, float* __restrict__ partials,
                                                            int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = W3<TZ, TY, OT, CT>;
     constexpr int DS = P::DS, CS = P::CS, HY = P::HY, HX = P::HX, HVOL = P::HVOL, TVOL = P::TVOL;
+    constexpr int NROW = P::HZ * HY;
+    constexpr int NSX = (NROW * 6 + 255) / 256;          // x halo: six aligned 16-byte segments per row (as conv3_f32)
+    constexpr int Q4 = TVOL / 4;
+    constexpr int NSD = (OT * 16 * Q4 + 255) / 256;       // dy tile: float4 per thread
+    constexpr int NCH = CT * 16;
+    constexpr int PFC = NCH <= 16 ? NCH : 8;              // channels whose loads are prefetched one tile ahead (register budget)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dys = smem;
     float* xs = smem + OT * 16 * DS;
@@ -44,6 +60,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     const int D = a.D, H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
     const bool xform = a.in_scale != nullptr;
+    const bool vec = (W & 3) == 0;
 
     // this wave's taps
     int toff[7];
@@ -67,44 +84,87 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     const int bbase = (lane & 15) * CS + (lane >> 4);
     const int ntile = a.N * ntz * nty * ntx;
 
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
         int b = tile;
         const int tx = b % ntx; b /= ntx;
         const int ty = b % nty; b /= nty;
         const int tz = b % ntz;
-        const int n = b / ntz;
-        const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;
-        __syncthreads();   // previous tile's MFMA reads are done
-        // ---- stage dy tile: OT*16 channels x TVOL voxels (zero outside the volume / beyond Cout)
-        for (int e = tid; e < OT * 16 * TVOL; e += 256) {
-            const int ch = e / TVOL;
-            const int r = e - ch * TVOL;
+        n = b / ntz;
+        z0 = tz * TZ; y0 = ty * TY; x0 = tx * 16;
+    };
+    auto make_slots = [&](int tile, W3Slots<NSX, NSD>& sl) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        sl.n = n;
+#pragma unroll
+        for (int j = 0; j < NSX; ++j) {
+            const int item = tid + j * 256;
+            const int row = item / 6, q = item - row * 6;
+            const int hz = row / HY, hy = row - hz * HY;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
+            const bool slot = item < NROW * 6;
+            const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+            sl.gx[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
+            sl.lx[j] = row * HX + 4 * q - 3;
+        }
+#pragma unroll
+        for (int j = 0; j < NSD; ++j) {
+            const int e4 = tid + j * 256;
+            const int ch = e4 / Q4, r = (e4 - ch * Q4) * 4;
             const int z = r / (TY * 16), y = (r / 16) % TY, x = r & 15;
             const int gz = z0 + z, gy = y0 + y, gx = x0 + x, o = o0 + ch;
-            float v = 0.f;
-            if (o < a.Cout && gz < D && gy < H && gx < W) v = a.dy[((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx];
-            dys[ch * DS + r] = v;
+            const bool ok = e4 < OT * 16 * Q4 && o < a.Cout && gz < D && gy < H && gx < W;
+            sl.gd[j] = ok ? (long)(((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx) : -1;
         }
-        // ---- stage x halo tile: CT*16 channels x HVOL (fused producer transform, zero padding after it)
-        for (int e = tid; e < CT * 16 * HVOL; e += 256) {
-            const int ch = e / HVOL;
-            const int s = e - ch * HVOL;
-            const int hz = s / (HY * HX);
-            const int r = s - hz * (HY * HX);
-            const int hy = r / HX, hx = r - hy * HX;
-            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1, c = c0 + ch;
-            float v = 0.f;
-            if (c < a.Cin && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-                v = a.x[((size_t)n * a.Cin + c) * DHW + (size_t)gz * HW + (size_t)gy * W + gx];
+    };
+    // unconditional loads from clamped addresses (a conditional load serialises: hipcc waits vmcnt(0) after each)
+    auto load_x = [&](const W3Slots<NSX, NSD>& sl, int cb, float4 (&v)[NSX]) {
+        const int cg = c0 + cb;
+        const float* xp = a.x + ((size_t)sl.n * a.Cin + (cg < a.Cin ? cg : 0)) * DHW;
+#pragma unroll
+        for (int j = 0; j < NSX; ++j) v[j] = *reinterpret_cast<const float4*>(xp + (sl.gx[j] > 0 ? sl.gx[j] : 0));
+    };
+    auto store_x = [&](const W3Slots<NSX, NSD>& sl, int cb, const float4 (&v)[NSX]) {
+        const int cg = c0 + cb;
+        float sc = 1.f, sh = 0.f;
+        if (xform && cg < a.Cin) { sc = a.in_scale[sl.n * a.Cin + cg]; sh = a.in_shift[sl.n * a.Cin + cg]; }
+#pragma unroll
+        for (int j = 0; j < NSX; ++j) {
+            if (sl.gx[j] == -2) continue;
+            float t[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            const bool live = sl.gx[j] >= 0 && cg < a.Cin;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
                 if (xform) {
-                    v = v * a.in_scale[n * a.Cin + c] + a.in_shift[n * a.Cin + c];
-                    v = v > 0.f ? v : v * a.in_slope;
+                    t[e] = t[e] * sc + sh;
+                    t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope;
                 }
+                t[e] = live ? t[e] : 0.f;          // zero padding applies to the ACTIVATED tensor
             }
-            xs[ch * CS + s] = v;
+            const int q = (tid + j * 256) % 6;
+            float* dst = xs + cb * CS + sl.lx[j];
+            if (q == 0) dst[3] = t[3];
+            else if (q == 5) dst[0] = t[0];
+            else { dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3]; }
         }
-        __syncthreads();
-        // ---- K loop over the tile's voxels, 4 per MFMA
+    };
+    auto load_dy = [&](const W3Slots<NSX, NSD>& sl, float4 (&dv)[NSD]) {
+#pragma unroll
+        for (int j = 0; j < NSD; ++j) dv[j] = *reinterpret_cast<const float4*>(a.dy + (sl.gd[j] > 0 ? sl.gd[j] : 0));
+    };
+    auto store_dy = [&](const W3Slots<NSX, NSD>& sl, const float4 (&dv)[NSD]) {
+#pragma unroll
+        for (int j = 0; j < NSD; ++j) {
+            const int e4 = tid + j * 256;
+            if (e4 >= OT * 16 * Q4) continue;
+            const int ch = e4 / Q4, r = (e4 - ch * Q4) * 4;
+            const bool live = sl.gd[j] >= 0;
+            float2* dst = reinterpret_cast<float2*>(dys + ch * DS + r);     // DS is even and r % 4 == 0: 8-byte aligned
+            dst[0] = live ? make_float2(dv[j].x, dv[j].y) : make_float2(0.f, 0.f);
+            dst[1] = live ? make_float2(dv[j].z, dv[j].w) : make_float2(0.f, 0.f);
+        }
+    };
+    auto compute = [&]() {
 #pragma unroll 1
         for (int zy = 0; zy < TZ * TY; ++zy) {
             const int z = zy / TY, y = zy - z * TY;
@@ -117,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
                 for (int p = 0; p < OT; ++p) af[p] = dys[az + p * 16 * DS + xq * 4];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    if (!tval[j]) continue;
+                    // no branch here: the 4th wave's 7th tap (tap 27) runs on tap 0's data into an accumulator that is
+                    // never written out -- a branch per tap puts every MFMA in its own basic block (LDS latency exposed)
                     float bf[CT];
 #pragma unroll
                     for (int q = 0; q < CT; ++q) bf[q] = xs[bz + toff[j] + q * 16 * CS + xq * 4];
@@ -128,6 +189,79 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
                             acc[j][p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p], bf[q], acc[j][p][q], 0, 0, 0);
                 }
             }
+        }
+    };
+
+    if (vec) {
+        // ---- software-pipelined persistent loop: the global loads of tile t+1 (dy and the first PFC channels of x) are in
+        // flight while tile t is on the matrix cores; they are consumed (transform + LDS store) after the next barrier.
+        W3Slots<NSX, NSD> sl;
+        float4 pdy[NSD];
+        float4 px[PFC][NSX];
+        int tile = blockIdx.x;
+        if (tile < ntile) {
+            make_slots(tile, sl);
+            load_dy(sl, pdy);
+#pragma unroll
+            for (int c = 0; c < PFC; ++c) load_x(sl, c, px[c]);
+        }
+        for (; tile < ntile; tile += gridDim.x) {
+            __syncthreads();                       // previous tile's MFMA reads are done
+            store_dy(sl, pdy);
+#pragma unroll
+            for (int c = 0; c < PFC; ++c) store_x(sl, c, px[c]);
+#pragma unroll 1
+            for (int cb = PFC; cb < NCH; cb += 8) {    // channels beyond the prefetch budget: load + store now, 8 at a time
+                float4 v[8][NSX];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) load_x(sl, cb + c, v[c]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) store_x(sl, cb + c, v[c]);
+            }
+            __syncthreads();
+            const int next = tile + gridDim.x;
+            if (next < ntile) {
+                make_slots(next, sl);
+                load_dy(sl, pdy);
+#pragma unroll
+                for (int c = 0; c < PFC; ++c) load_x(sl, c, px[c]);
+            }
+            compute();
+        }
+    } else {
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+            int n, z0, y0, x0;
+            tile_origin(tile, n, z0, y0, x0);
+            __syncthreads();
+            // ---- scalar staging (ragged W): dy tile (zero outside the volume / beyond Cout), then the x halo tile
+            for (int e = tid; e < OT * 16 * TVOL; e += 256) {
+                const int ch = e / TVOL;
+                const int r = e - ch * TVOL;
+                const int z = r / (TY * 16), y = (r / 16) % TY, x = r & 15;
+                const int gz = z0 + z, gy = y0 + y, gx = x0 + x, o = o0 + ch;
+                float v = 0.f;
+                if (o < a.Cout && gz < D && gy < H && gx < W) v = a.dy[((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx];
+                dys[ch * DS + r] = v;
+            }
+            for (int e = tid; e < NCH * HVOL; e += 256) {
+                const int ch = e / HVOL;
+                const int s = e - ch * HVOL;
+                const int hz = s / (HY * HX);
+                const int r = s - hz * (HY * HX);
+                const int hy = r / HX, hx = r - hy * HX;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1, c = c0 + ch;
+                float v = 0.f;
+                if (c < a.Cin && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                    v = a.x[((size_t)n * a.Cin + c) * DHW + (size_t)gz * HW + (size_t)gy * W + gx];
+                    if (xform) {
+                        v = v * a.in_scale[n * a.Cin + c] + a.in_shift[n * a.Cin + c];
+                        v = v > 0.f ? v : v * a.in_slope;
+                    }
+                }
+                xs[ch * CS + s] = v;
+            }
+            __syncthreads();
+            compute();
         }
     }
     // ---- write this workgroup's partial: partials[blockIdx.x][tap][o][c]
@@ -150,27 +284,35 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     }
 }
 
-// dw[o*so + c*sc + tap] = sum_parts partials[part][tap][o][c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
-                                    int Cout, int Cin, float* __restrict__ dw, int so, int sc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// dw[o*so + c*sc + tap] = sum_parts partials[part][tap][o][c].  256 threads = 64 outputs x 4 partial slices (the slices are
+// combined in a fixed order through LDS: deterministic), so a 512-partial reduction is 128 loads deep instead of 512.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
+                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc) {
+    __shared__ float red[4][64];
+    const int lane_o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane_o;
     const int total = taps * Cout * Cin;
-    if (i >= total) return;
-    const int c = i % Cin;
-    const int o = (i / Cin) % Cout;
-    const int tap = i / (Cin * Cout);
+    const bool ok = i < total;
+    const int ii = ok ? i : 0;
+    const int c = ii % Cin;
+    const int o = (ii / Cin) % Cout;
+    const int tap = ii / (Cin * Cout);
     const size_t stride = (size_t)taps * CoP * CiP;
     const float* p = partials + ((size_t)tap * CoP + o) * CiP + c;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // fixed-order 4-way interleaved sum
-    int k = 0;
-    for (; k + 3 < nparts; k += 4) {
+    const int per = (nparts + 3) / 4;
+    const int k0 = slice * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
         s0 += p[(size_t)k * stride];
         s1 += p[(size_t)(k + 1) * stride];
         s2 += p[(size_t)(k + 2) * stride];
         s3 += p[(size_t)(k + 3) * stride];
     }
-    for (; k < nparts; ++k) s0 += p[(size_t)k * stride];
-    dw[(size_t)o * so + (size_t)c * sc + tap] = (s0 + s1) + (s2 + s3);
+    for (; k < k1; ++k) s0 += p[(size_t)k * stride];
+    red[slice][lane_o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && ok) dw[(size_t)o * so + (size_t)c * sc + tap] = (red[0][lane_o] + red[1][lane_o]) + (red[2][lane_o] + red[3][lane_o]);
 }
 
 struct W3Choice { int tz, ty, ot, ct, nbx, ngroups, ncg; };
@@ -213,7 +355,7 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
                        cdiv(a.D, TZ), cdiv(a.H, TY), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
     const int total = 27 * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
                        a.Cout, a.Cin, a.dw, a.Cin * 27, 27);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
@@ -257,19 +399,52 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
         const int n = (int)(t / nchunk);
         const size_t v0 = (size_t)(t % nchunk) * W1_VC;
         __syncthreads();
+        if ((V & 3) == 0) {
+            // aligned float4 loads, all issued before the first LDS store (row stride 258: 8-byte aligned float2 stores)
+            constexpr int Q4 = W1_VC / 4;
+            constexpr int ND = OT * 16 * Q4 / 256, NX = CT * 16 * Q4 / 256;
+            float4 dv[ND], xv[NX];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int e4 = tid + j * 256, ch = e4 / Q4, r = (e4 % Q4) * 4, o = o0 + ch;
+                const bool ok = o < a.Cout && v0 + r < V;
+                const float4 t4 = *reinterpret_cast<const float4*>(a.dy + (ok ? ((size_t)n * a.Cout + o) * V + v0 + r : 0));   // unconditional, clamped
+                dv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int e4 = tid + j * 256, ch = e4 / Q4, r = (e4 % Q4) * 4, c = c0 + ch;
+                const bool ok = c < a.Cin && v0 + r < V;
+                const float4 t4 = *reinterpret_cast<const float4*>(a.x + (ok ? ((size_t)n * a.Cin + c) * V + v0 + r : 0));
+                xv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int e4 = tid + j * 256, ch = e4 / Q4, r = (e4 % Q4) * 4;
+                float2* d = reinterpret_cast<float2*>(dys + ch * W1_RS + r);
+                d[0] = make_float2(dv[j].x, dv[j].y); d[1] = make_float2(dv[j].z, dv[j].w);
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int e4 = tid + j * 256, ch = e4 / Q4, r = (e4 % Q4) * 4;
+                float2* d = reinterpret_cast<float2*>(xs + ch * W1_RS + r);
+                d[0] = make_float2(xv[j].x, xv[j].y); d[1] = make_float2(xv[j].z, xv[j].w);
+            }
+        } else {
         for (int e = tid; e < OT * 16 * W1_VC; e += 256) {
-            const int ch = e / W1_VC, r = e % W1_VC;
-            const int o = o0 + ch;
-            float v = 0.f;
-            if (o < a.Cout && v0 + r < V) v = a.dy[((size_t)n * a.Cout + o) * V + v0 + r];
-            dys[ch * W1_RS + r] = v;
-        }
-        for (int e = tid; e < CT * 16 * W1_VC; e += 256) {
-            const int ch = e / W1_VC, r = e % W1_VC;
-            const int c = c0 + ch;
-            float v = 0.f;
-            if (c < a.Cin && v0 + r < V) v = a.x[((size_t)n * a.Cin + c) * V + v0 + r];
-            xs[ch * W1_RS + r] = v;
+                const int ch = e / W1_VC, r = e % W1_VC;
+                const int o = o0 + ch;
+                float v = 0.f;
+                if (o < a.Cout && v0 + r < V) v = a.dy[((size_t)n * a.Cout + o) * V + v0 + r];
+                dys[ch * W1_RS + r] = v;
+            }
+            for (int e = tid; e < CT * 16 * W1_VC; e += 256) {
+                const int ch = e / W1_VC, r = e % W1_VC;
+                const int c = c0 + ch;
+                float v = 0.f;
+                if (c < a.Cin && v0 + r < V) v = a.x[((size_t)n * a.Cin + c) * V + v0 + r];
+                xs[ch * W1_RS + r] = v;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -337,7 +512,7 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad1_f32_kernel<OT, CT>), dim3(c.nbx, c.ngroups), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad1_f32_kernel");
     const int total = a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)a.ws, c.nbx * 4, 1, CoP, CiP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx * 4, 1, CoP, CiP,
                        a.Cout, a.Cin, a.dw, a.ldw, 1);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;

@@ -61,13 +61,19 @@ class UNetEngine:
     """forward()/backward() on device buffers.  One engine == one in-flight forward state."""
 
     def __init__(self, depth=4, encoder_layers=(1, 2, 2, 4), decoder_layers=(1, 1, 1, 1),
-                 number_of_channels=(16, 32, 64, 128), number_of_outputs=3):
+                 number_of_channels=(16, 32, 64, 128), number_of_outputs=3, precision="f32"):
         self.layout = ParamLayout(depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs)
         self.h = self.layout.handle
+        self.set_precision(precision)
         self.n_out = int(number_of_outputs)
         self._ws = None
         self._ws_key = None
         self.generation = 0
+
+    def set_precision(self, precision):
+        """"f32": exact-f32 MFMA convolutions; "bf16x3": split-bf16 3-product convolutions (|dp| ~ 5e-5)."""
+        L.check(L.load().ru_unet_set_precision(self.h, L.PRECISIONS[precision]), "ru_unet_set_precision")
+        self.precision = precision
 
     def _workspace(self, n, d, h, w, training, device):
         key = (n, d, h, w, bool(training), str(device))

@@ -220,7 +220,7 @@ class UNet(nn.Module):
         eng = self.__dict__.get("_engine_obj")
         if eng is None:
             eng = UNetEngine(self.depth, list(self.encoder_layers), list(self.decoder_layers), list(self.number_of_channels),
-                             self.number_of_outputs)
+                             self.number_of_outputs, precision=self.__dict__.get("precision", "f32"))
             names = [n for n, _ in self.named_parameters()]
             if names != list(eng.layout.entries.keys()):
                 raise RuntimeError("parameter names/order differ from the executor's layout")
@@ -230,6 +230,14 @@ class UNet(nn.Module):
             self.__dict__["_engine_obj"] = eng
             self.__dict__["_param_names"] = names
         return eng
+
+    def set_precision(self, precision):
+        """Arithmetic of the 3x3x3 convolutions: "f32" (default, exact) or "bf16x3" (split-bf16, ~5x the MFMA rate)."""
+        self.__dict__["precision"] = precision
+        eng = self.__dict__.get("_engine_obj")
+        if eng is not None:
+            eng.set_precision(precision)
+        return self
 
     def _param_order(self):
         self._get_engine()

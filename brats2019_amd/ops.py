@@ -26,8 +26,9 @@ def _prep(t):
     return t.contiguous().float() if (not t.is_contiguous() or t.dtype != torch.float32) else t
 
 
-def conv3d(x, w, bias=None):
-    """nn.Conv3d forward as built at model.py:72-73,336,348 (k=3,s=1,p=1), :361-363 (k=2,s=2), :393,401 (k=1)."""
+def conv3d(x, w, bias=None, precision="f32"):
+    """nn.Conv3d forward as built at model.py:72-73,336,348 (k=3,s=1,p=1), :361-363 (k=2,s=2), :393,401 (k=1).
+    `precision`: "f32" (exact) or "bf16x3" (split-bf16, 3 MFMA products; k=3 only)."""
     x, w, bias = _prep(x), _prep(w), _prep(bias)
     lib = L.load()
     n, cin, d, h, wd = _dims5(x)
@@ -37,12 +38,12 @@ def conv3d(x, w, bias=None):
     out_sp = (d, h, wd) if k != 2 else (d // 2, h // 2, wd // 2)
     y = torch.empty((n, cout) + out_sp, dtype=torch.float32, device=x.device)
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), x.device)
-    L.check(lib.ru_conv3d_fwd(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, k,
-                              L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd")
+    L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, k, L.PRECISIONS[precision],
+                                L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd")
     return y
 
 
-def conv3d_bwd_data(dy, w, in_spatial):
+def conv3d_bwd_data(dy, w, in_spatial, precision="f32"):
     """Data gradient of the conv above; `in_spatial` = (D,H,W) of the conv INPUT."""
     dy, w = _prep(dy), _prep(w)
     lib = L.load()
@@ -51,8 +52,8 @@ def conv3d_bwd_data(dy, w, in_spatial):
     d, h, wd = [int(v) for v in in_spatial]
     dx = torch.empty((n, cin, d, h, wd), dtype=torch.float32, device=dy.device)
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), dy.device)
-    L.check(lib.ru_conv3d_bwd_data(L.f32(dy), L.f32(w), L.f32(dx), n, cin, cout, d, h, wd, k, L.ptr(ws), ws.numel(), L.stream()),
-            "ru_conv3d_bwd_data")
+    L.check(lib.ru_conv3d_bwd_data_p(L.f32(dy), L.f32(w), L.f32(dx), n, cin, cout, d, h, wd, k, L.PRECISIONS[precision],
+                                     L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_bwd_data")
     return dx
 
 

@@ -24,12 +24,12 @@ import torch.distributed as dist
 class HipBackend:
     """Arithmetic of the step on the local GPU through the C-ABI (no CPU fallback)."""
 
-    def __init__(self, cfg=None, device=None):
+    def __init__(self, cfg=None, device=None, precision="f32"):
         from . import _lib as L
         from .engine import UNetEngine, DEFAULT_CFG
         L.require_gpu()
         self.cfg = dict(cfg or DEFAULT_CFG)
-        self.engine = UNetEngine(**self.cfg)
+        self.engine = UNetEngine(precision=precision, **self.cfg)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.total = self.engine.layout.total
         # contiguous runs of LIVE parameters: the reference's Adam skips tensors whose grad is None (the never-executed

@@ -30,6 +30,14 @@ extern "C" {
 #define RU_EHIP (-3)      /* HIP runtime error (launch failed ...) */
 #define RU_ESTATE (-4)    /* call order violated (backward without forward ...) */
 
+/* arithmetic of the 3x3x3 convolutions (everything else is always float32):
+ *   RU_PREC_F32    exact float32 products on v_mfma_f32_16x16x4_f32 (bit-for-bit an fmaf chain)
+ *   RU_PREC_BF16X3 split-bf16: v = hi + lo (2 x bf16), products hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16 with
+ *                  float32 accumulation; ~2^-16 relative per product, |dp| ~ 5e-5 on the whole network (bar: 1e-3).
+ *                  Needs W % 4 == 0, otherwise the f32 kernel runs.  HBM tensors stay float32 in both modes. */
+#define RU_PREC_F32 0
+#define RU_PREC_BF16X3 1
+
 typedef void* ru_stream_t;                /* hipStream_t */
 typedef struct ru_unet* ru_unet_t;        /* opaque engine handle */
 
@@ -47,6 +55,13 @@ size_t ru_conv3d_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W, 
 int ru_conv3d_fwd(const float* x, const float* w, const float* bias, float* y,
                   int N, int Cin, int Cout, int D, int H, int W, int k,
                   void* ws, size_t ws_bytes, ru_stream_t stream);
+/* same as ru_conv3d_fwd / ru_conv3d_bwd_data with an explicit RU_PREC_* for k=3 (k=1,2 are always float32) */
+int ru_conv3d_fwd_p(const float* x, const float* w, const float* bias, float* y,
+                    int N, int Cin, int Cout, int D, int H, int W, int k, int precision,
+                    void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_conv3d_bwd_data_p(const float* dy, const float* w, float* dx,
+                         int N, int Cin, int Cout, int D, int H, int W, int k, int precision,
+                         void* ws, size_t ws_bytes, ru_stream_t stream);
 /* dx = d(loss)/dx given dy (autograd of the calls above) */
 int ru_conv3d_bwd_data(const float* dy, const float* w, float* dx,
                        int N, int Cin, int Cout, int D, int H, int W, int k,
@@ -117,6 +132,10 @@ int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vm
 ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const int* decoder_layers,
                          const int* number_of_channels, int number_of_outputs);
 void ru_unet_destroy(ru_unet_t h);
+/* RU_PREC_* used by the 3x3x3 convolutions (forward and data gradient) of subsequent forward/backward calls;
+ * default RU_PREC_F32.  Change it only between steps (not between a forward and its backward).  */
+int ru_unet_set_precision(ru_unet_t h, int precision);
+int ru_unet_get_precision(ru_unet_t h);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
 int ru_unet_param_ndim(ru_unet_t h, int i);

@@ -224,3 +224,42 @@ def test_residual_module_golden(golden, tag):
     close(x.grad, g[tag + "_dx"], rtol=1e-4, atol=2e-5, name=tag + " dx")
     for k, p in blk.named_parameters():
         close_rel_max(p.grad, g["%s_g_%s" % (tag, k)], rel=3e-4, name="%s grad %s" % (tag, k))
+
+
+# ---------------------------------------------------------------- split-bf16 (bf16x3) convolution path
+# hi+lo operands carry 16 mantissa bits -> each product is accurate to ~2^-16; over K <= 3456 products of random sign the
+# output error is ~2^-16 * sqrt(K) * rms(x) * rms(w): we hold max|err| <= 1e-4 * max|ref| (plain bf16 operands: ~5e-3).
+@pytest.mark.parametrize("case", [(1, 4, 16, 12, 20, 32), (2, 16, 16, 9, 17, 32), (1, 32, 32, 8, 16, 32), (1, 64, 64, 8, 8, 16),
+                                  (1, 128, 128, 4, 8, 16), (1, 16, 3, 7, 9, 20), (1, 8, 8, 6, 6, 8), (2, 3, 16, 5, 8, 16),
+                                  (1, 16, 16, 32, 32, 32), (1, 24, 40, 6, 10, 12)])
+def test_conv3_bf16x3_vs_oracle(ops, case):
+    n, cin, cout, d, h, w = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x = rng.standard_normal((n, cin, d, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((n, cout, d, h, w)).astype(np.float32)
+    xt, wtt = T(x).requires_grad_(True), T(wt)
+    y = O.conv3x3x3(xt, wtt, T(b))
+    y.backward(T(dy))
+    close_rel_max(ops.conv3d(dev(x), dev(wt), dev(b), precision="bf16x3"), y.detach().numpy(), rel=1e-4, name="bf16x3 fwd %s" % (case,))
+    close_rel_max(ops.conv3d_bwd_data(dev(dy), dev(wt), (d, h, w), precision="bf16x3"), xt.grad.numpy(), rel=1e-4, name="bf16x3 dgrad %s" % (case,))
+
+
+def test_conv3_bf16x3_is_not_plain_bf16(ops):
+    """The lo terms matter: the result must be far closer to fp32 than single-bf16 operands could be."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((1, 16, 8, 16, 32)).astype(np.float32)
+    wt = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(432)).astype(np.float32)
+    ref = O.conv3x3x3(T(x), T(wt)).numpy().astype(np.float64)
+    got = ops.conv3d(dev(x), dev(wt), precision="bf16x3").cpu().numpy()
+    plain = O.conv3x3x3(T(x).bfloat16().float(), T(wt).bfloat16().float()).numpy()
+    e_split, e_plain = np.abs(got - ref).max(), np.abs(plain - ref).max()
+    assert e_split < e_plain / 50, (e_split, e_plain)
+
+
+def test_conv3_bf16x3_ragged_w_falls_back_to_f32(ops):
+    rng = np.random.default_rng(78)
+    x = rng.standard_normal((1, 16, 4, 6, 18)).astype(np.float32)        # W % 4 != 0
+    wt = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(432)).astype(np.float32)
+    close(ops.conv3d(dev(x), dev(wt), precision="bf16x3"), O.conv3x3x3(T(x), T(wt)), name="fallback")
