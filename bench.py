@@ -121,7 +121,7 @@ def roofline_probe(batch, size, precision, launches=20):
         # executed MFMA work = 3 products x (28/27 tap padding) x algorithmic; at the dense bf16 peak that is 144 us for
         # batch 4, the fp32 NCDHW in+out traffic at 8 TB/s is 134 us: the kernel sits on the ridge.  Reported against the
         # bf16 MFMA peak with ALGORITHMIC flops (so frac <= 1/3.11 by construction) and against HBM with algorithmic bytes.
-        return {"bound": "mfma", "kernel": "conv3_sb_kernel<4,8> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3)" % (batch, size),
+        return {"bound": "mfma", "kernel": "conv3_sb2_kernel<4,8> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3)" % (batch, size),
                 "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
                 "algorithmic_bytes_per_launch": int(abytes), "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
@@ -207,8 +207,8 @@ def main():
                                "%d^3 x 4ch synthetic crops, per-GPU batch %d (BASELINE configs[2], weak-scaled as configs[3])" % (args.size, args.batch),
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "in_channels": 4,
                    "parallelism": "dp%d" % world,
-                   "precision": ("fp32 tensors in HBM; 3x3x3 conv fwd+dgrad on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 accumulate); "
-                                 "weight gradients and everything else fp32") if args.precision == "bf16x3" else "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
+                   "precision": ("fp32 tensors in HBM; 3x3x3 conv fwd + data gradient + weight gradient on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 accumulate); "
+                                 "the 1x1 / 2x2x2 convolutions, GroupNorm, trilinear, criterion and Adam in fp32") if args.precision == "bf16x3" else "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
         "final_loss": round(loss, 6),
         "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
     }

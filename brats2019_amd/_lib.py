@@ -28,6 +28,7 @@ SIGNATURES = {
     "ru_conv3d_fwd_p": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_data_p": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
+    "ru_conv3d_bwd_weight_p": (_i, [_vp, _vp, _vp, _vp] + [_i] * 8 + [_vp, _sz, _vp]),
     "ru_groupnorm_workspace_bytes": (_sz, [_i, _i, _sz]),
     "ru_groupnorm_fwd": (_i, [_vp] * 7 + [_i, _i, _sz, _i, _f, _f, _vp, _sz, _vp]),
     "ru_groupnorm_bwd": (_i, [_vp] * 9 + [_i, _i, _sz, _i, _f, _vp, _sz, _vp]),

@@ -16,8 +16,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libresunet_hip.so")
-SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "pointwise.hip", "engine.hip"]
-HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
+SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "wgrad_sb.hip", "pointwise.hip", "engine.hip"]
+HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(CSRC, "conv3_epilogue.hpp"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
     const int abase = (lane >> 4) * CS + (lane & 15) + mz * (HY * HX) + my0 * HX;
     const int bbase = (lane >> 4) * WS + (lane & 15);
     const bool xform = a.in_scale != nullptr;
-    const float slope = a.in_slope;
+    const float slope = xform ? a.in_slope : 1.f;    // neutral constants (1, 0, 1) make the fused transform branch-free and exact
 
     for (int c0 = 0; c0 < a.CinP; c0 += KC) {
         if (c0) __syncthreads();
@@ -127,10 +127,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
                     const bool live = gv[j] >= 0 && cg < a.Cin;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (xform) {
-                            t[e] = t[e] * sc + sh;
-                            t[e] = t[e] > 0.f ? t[e] : t[e] * slope;
-                        }
+                        t[e] = fmaf(t[e], sc, sh);
+                        t[e] = fmaxf(t[e], t[e] * slope);       // LeakyReLU for 0 < slope <= 1
                         t[e] = live ? t[e] : 0.f;
                     }
                     const int q = (tid + j * 256) % 6;
@@ -153,11 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
                 for (int j = 0; j < NS; ++j) v[j] = xp[goff[j] > 0 ? goff[j] : 0];       // unconditional, clamped (see above)
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    float t = v[j];
-                    if (xform) {
-                        t = t * sc + sh;
-                        t = t > 0.f ? t : t * slope;
-                    }
+                    float t = fmaf(v[j], sc, sh);
+                    t = fmaxf(t, t * slope);
                     t = (cok && goff[j] >= 0) ? t : 0.f;
                     if (tid + j * 256 < HVOL) xs[c * CS + tid + j * 256] = t;
                 }

@@ -18,6 +18,7 @@
 //         registers: 14 K-steps x 2 x 4 VGPRs.
 //   C/D: lane holds 4 consecutive x voxels of output channel l&15 -> shared epilogue (conv3_epilogue.hpp).
 #include "conv3_epilogue.hpp"
+#include <stdlib.h>
 
 namespace ru {
 
@@ -38,15 +39,25 @@ struct SB {
     static_assert(MT >= 1 && TY % MT == 0, "a wave's M-tiles must lie in one z-slab");
 };
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// v = hi + lo with hi = bf16_rne(v), lo = bf16_rne(v - hi); two values per v_cvt_pk_bf16_f32, the hi halves are
+// re-expanded with one shift / one mask (3 VALU per value in total)
 __device__ __forceinline__ void split8(const float (&t)[8], u32x4& hi, u32x4& lo) {
-    bf16x8 h, l;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = (__bf16)t[i];
-        l[i] = (__bf16)(t[i] - (float)h[i]);
+    for (int i = 0; i < 4; ++i) {
+        bf16x2 h;
+        h[0] = (__bf16)t[2 * i];
+        h[1] = (__bf16)t[2 * i + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hb << 16);
+        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+        bf16x2 l;
+        l[0] = (__bf16)(t[2 * i] - h0);
+        l[1] = (__bf16)(t[2 * i + 1] - h1);
+        hi[i] = hb;
+        lo[i] = __builtin_bit_cast(unsigned, l);
     }
-    hi = __builtin_bit_cast(u32x4, h);
-    lo = __builtin_bit_cast(u32x4, l);
 }
 
 template <int TZ, int TY>
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool xform = a.in_scale != nullptr;
-    const float slope = a.in_slope;
+    const float slope = xform ? a.in_slope : 1.f;    // neutral constants make the fused transform branch-free
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk) __syncthreads();
@@ -146,10 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         float u = e == 0 ? v[j][c].x : (e == 1 ? v[j][c].y : (e == 2 ? v[j][c].z : v[j][c].w));
-                        if (xform) {
-                            u = u * sc[c] + sh[c];
-                            u = u > 0.f ? u : u * slope;
-                        }
+                        u = fmaf(u, sc[c], sh[c]);                          // branch-free: (1, 0, slope 1) when no transform
+                        u = fmaxf(u, u * slope);                            // LeakyReLU for 0 < slope <= 1
                         t[c] = (inb && cb + c < a.Cin) ? u : 0.f;          // zero padding applies to the ACTIVATED tensor
                     }
                     u32x4 hi, lo;
@@ -180,6 +189,257 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
         }
     }
     conv3_epilogue<MT, 1>(a, acc, smem, n, z0, y0, x0, mz, my0, co0, tz, ty, tx, ntz, nty, ntx);
+}
+
+// ------------------------------------------------------------------ v2: persistent producer / consumer workgroups
+// 512 threads: waves 0-3 are CONSUMERS (A fragments from LDS, weights in registers, 3 MFMAs per K-step, epilogue),
+// waves 4-7 are PRODUCERS (global float4 loads -> fused affine + LeakyReLU -> hi/lo split -> transposed LDS image).
+// A workgroup walks a contiguous run of tiles (halo re-reads stay in its XCD's L2); the LDS image is double buffered:
+// while the consumers are on item w the producers finish item w+1 in the other buffer and already have the global
+// loads of item w+2 in flight.  One __syncthreads per item.  Each SIMD hosts one consumer and one producer wave, so
+// the matrix pipe and the VALU/LDS-store work of the staging overlap instead of alternating.
+// Per-tile GroupNorm statistics are written per consumer WAVE (no cross-wave reduction -> no extra barrier).
+template <int MT>
+__device__ __forceinline__ void sb2_epilogue(const Conv3Args& a, f32x4 (&acc)[MT], int n, int z0, int y0, int x0, int mz, int my0,
+                                             int co0, int tile_in_sample, int nblk, int wave, int lane) {
+    const int D = a.D, H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const int zz = z0 + mz;
+    const int xq = x0 + (lane >> 4) * 4;
+    const int co = co0 + (lane & 15);
+    float s1 = 0.f, s2 = 0.f;
+    const float bv = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    float4 radd[MT];
+    if (a.add) {       // residual: all loads first (unconditional, clamped), then use
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int yy = y0 + my0 + i;
+            const bool ok = zz < D && yy < H && co < a.Cout && xq < W;
+            const size_t idx = ok ? (((size_t)n * a.Cout + co) * D + zz) * HW + (size_t)yy * W + xq : 0;
+            radd[i] = *reinterpret_cast<const float4*>(a.add + idx);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int yy = y0 + my0 + i;
+        const bool ok = zz < D && yy < H && co < a.Cout && xq < W;       // W % 4 == 0: the 4 voxels are in or out together
+        if (!ok) continue;
+        const size_t idx = (((size_t)n * a.Cout + co) * D + zz) * HW + (size_t)yy * W + xq;
+        f32x4 v = acc[i];
+        v += bv;
+        if (a.add) { v[0] += radd[i].x; v[1] += radd[i].y; v[2] += radd[i].z; v[3] += radd[i].w; }
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (a.sigmoid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + expf(-v[r]));
+        }
+        *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (a.stat_partials) {
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lane < 16 && co < a.Cout) {
+            float* p = a.stat_partials + (((size_t)n * a.Cout + co) * nblk + tile_in_sample * 4 + wave) * 2;
+            p[0] = s1; p[1] = s2;
+        }
+    }
+}
+
+template <int TZ, int TY>
+__global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg) {
+    // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
+    // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
+    using P = SB<TZ, TY>;
+    constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NSV = P::NSV, NROW = P::NROW;
+    constexpr int BUF = 4 * HVOLP;                      // packets per LDS buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int rw = wave & 3;                             // wave index inside its role group
+    const int ptid = tid & 255;
+    const int cog = blockIdx.y, co0 = cog * 16;
+    const int D = a.D, H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
+    const int tiles_per_sample = ntz * nty * ntx;
+    const int ntile = a.N * tiles_per_sample;
+    // tile of step k: k*G + swz(b).  Workgroup b runs on XCD b % 8 (observed, used for speed only): at every step the 256
+    // resident workgroups cover 256 consecutive tiles and each XCD a compact run of G/8 of them, so the x/y halos of
+    // neighbouring tiles are shared in that XCD's L2 while they are hot.
+    const int G = gridDim.x;
+    const int swz = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int t_begin = swz;
+    const int nsteps = swz < ntile ? (ntile - swz + G - 1) / G : 0;
+    const int nitems = nsteps * nchunk;
+    const bool xform = a.in_scale != nullptr;
+    const float slope = xform ? a.in_slope : 1.f;    // neutral constants make the fused transform branch-free
+
+    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0, int& tis) {
+        int b = tile;
+        n = b / tiles_per_sample;
+        tis = b - n * tiles_per_sample;
+        b = tis;
+        const int tx = b % ntx; b /= ntx;
+        const int ty = b % nty;
+        const int tz = b / nty;
+        z0 = tz * TZ; y0 = ty * TY; x0 = tx * 16;
+    };
+
+    if (producer) {
+        // ---------------------------------------------------------------- producers
+        int gv[NSV], lp[NSV];           // slots of the item whose loads are in flight
+        int n_cur = 0;
+        float4 v[2][NSV][8];            // [channel half][slot][channel]: 16 channels x 4 voxels per slot in flight
+        auto issue = [&](int item) {    // compute slots + issue every load of `item` (no waits)
+            if (dbg & 2) return;
+            const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
+            int z0, y0, x0, tis;
+            tile_origin(tile, n_cur, z0, y0, x0, tis);
+#pragma unroll
+            for (int j = 0; j < NSV; ++j) {
+                const int it = ptid + j * 256;
+                const int row = it / 6, q = it - row * 6;
+                const int hz = row / HY, hy = row - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
+                const bool slot = it < NROW * 6;
+                const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+                gv[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
+                lp[j] = row * HX + 4 * q - 3;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < NSV; ++j)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int cc = chunk * 16 + half * 8 + c;
+                        const int cg = cc < a.Cin ? cc : a.Cin - 1;            // unconditional, clamped (see v1)
+                        v[half][j][c] = *reinterpret_cast<const float4*>(a.x + ((size_t)n_cur * a.Cin + cg) * DHW + (gv[j] > 0 ? gv[j] : 0));
+                    }
+        };
+        auto store = [&](int item, u32x4* buf) {   // consume the in-flight loads of `item`: transform, split, transpose
+            if (dbg & 1) { if (!(dbg & 2)) { float acc0 = 0.f;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < NSV; ++j)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc0 += v[h2][j][c].x;
+                if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u}; } return; }
+            const int chunk = item % nchunk;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int cb = chunk * 16 + half * 8;
+                // affine constants of the 8 channels; channels beyond Cin get (0, 0) -> exact zeros without a select
+                float sc[8], sh[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool cok = cb + c < a.Cin;
+                    sc[c] = cok ? 1.f : 0.f; sh[c] = 0.f;
+                    if (xform && cok) { sc[c] = a.in_scale[n_cur * a.Cin + cb + c]; sh[c] = a.in_shift[n_cur * a.Cin + cb + c]; }
+                }
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) {
+                    if (gv[j] == -2) continue;
+                    // zero padding applies to the ACTIVATED tensor: out-of-volume lanes use (0, 0) too (their clamped loads are finite)
+                    const float m = gv[j] >= 0 ? 1.f : 0.f;
+                    float scm[8], shm[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { scm[c] = sc[c] * m; shm[c] = sh[c] * m; }
+                    const int q = (ptid + j * 256) % 6;
+                    const int e0 = q == 0 ? 3 : 0, e1 = q == 5 ? 1 : 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < e0 || e >= e1) continue;
+                        float t[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float u = e == 0 ? v[half][j][c].x : (e == 1 ? v[half][j][c].y : (e == 2 ? v[half][j][c].z : v[half][j][c].w));
+                            u = fmaf(u, scm[c], shm[c]);
+                            t[c] = fmaxf(u, u * slope);                     // LeakyReLU for 0 < slope <= 1 (slope 1: identity)
+                        }
+                        u32x4 hi, lo;
+                        split8(t, hi, lo);
+                        buf[half * HVOLP + lp[j] + e] = hi;
+                        buf[(2 + half) * HVOLP + lp[j] + e] = lo;
+                    }
+                }
+            }
+        };
+        if (nitems > 0) {
+            issue(0);
+            store(0, lds);
+            if (nitems > 1) issue(1);
+        }
+        __syncthreads();
+        for (int w = 0; w < nitems; ++w) {
+            if (w + 1 < nitems) {
+                store(w + 1, lds + ((w + 1) & 1) * BUF);
+                if (w + 2 < nitems) issue(w + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------------------------------------------------------- consumers
+        const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
+        const int kg = lane >> 4;
+        int aoff[SB_KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+            int tap = 2 * ks + (kg >> 1);
+            if (tap > 26) tap = 26;
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            aoff[ks] = (kg & 1) * HVOLP + ((mz + dz) * HY + my0 + dy) * HX + dx + (lane & 15);
+        }
+        u32x4 wreg[SB_KSTEPS][2];
+        auto load_w = [&](int chunk) {
+            const u32x4* wp = wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+                wreg[ks][0] = wp[(ks * 2 + 0) * 64];
+                wreg[ks][1] = wp[(ks * 2 + 1) * 64];
+            }
+        };
+        if (nchunk == 1) load_w(0);                     // one chunk: the weights stay in registers for the whole run of tiles
+        f32x4 acc[MT];
+        __syncthreads();                                // item 0 is staged
+        for (int w = 0; w < nitems; ++w) {
+            const int chunk = w % nchunk;
+            if (chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (nchunk > 1) load_w(chunk);
+            const u32x4* buf = lds + (w & 1) * BUF;
+            if (!(dbg & 4))
+#pragma unroll
+            for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                bf16x8 ah[MT], al[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks] + i * HX]);
+                    al[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks] + 2 * HVOLP + i * HX]);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i], 0, 0, 0);
+            }
+            if (chunk == nchunk - 1 && !(dbg & 8)) {
+                int n, z0, y0, x0, tis;
+                tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
+                sb2_epilogue<MT>(a, acc, n, z0, y0, x0, mz, my0, co0, tis, tiles_per_sample * 4, rw, lane);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------ weight fragments
@@ -235,10 +495,41 @@ static SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
     return {2, 4};
 }
 
+// v2 (persistent producer/consumer) handles the large-tile case; it writes one statistics partial per consumer wave
+static bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
+
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     (void)Cin;
     const SBChoice c = sb_choose(N, Cout, D, H, W);
-    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16);
+    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * (sb_use_v2(c) ? 4 : 1);
+}
+
+template <int TZ, int TY>
+static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
+    using P = SB<TZ, TY>;
+    static bool attr_done = false;
+    static int ncu = 256;
+    constexpr int LDS2 = 2 * P::LDS_BYTES;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        attr_done = true;
+    }
+    const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
+    const long ntile = (long)a.N * ntz * nty * ntx;
+    const int ncog = cdiv(a.Cout, 16);
+    long gx = ncu / (ncog < ncu ? ncog : ncu);          // one resident workgroup per CU in total
+    if (gx < 1) gx = 1;
+    if (gx > ntile) gx = ntile;
+    dim3 grid((unsigned)gx, (unsigned)ncog);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    RU_CHECK_LAUNCH("conv3_sb2_kernel");
+    return RU_OK;
 }
 
 template <int TZ, int TY>
@@ -260,7 +551,7 @@ static int sb_cfg(const Conv3Args& a, hipStream_t s) {
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE((a.W & 3) == 0, "conv3_sb: W must be a multiple of 4");
     const SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
-    if (c.tz == 4) return sb_cfg<4, 8>(a, s);
+    if (sb_use_v2(c)) return sb2_cfg<4, 8>(a, s);
     if (c.ty == 8) return sb_cfg<2, 8>(a, s);
     return sb_cfg<2, 4>(a, s);
 }

@@ -453,9 +453,9 @@ static int gn_bwd(Arena& A, hipStream_t s, const float* yraw, const float* dact,
     return RU_OK;
 }
 
-static int wgrad3_run(Arena& A, hipStream_t s, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W) {
+static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W) {
     Wgrad3Args w{};
-    w.x = x; w.dy = dy; w.dw = dw;
+    w.x = x; w.dy = dy; w.dw = dw; w.mode = mode;
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -483,7 +483,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     float* dy2 = A.alloc((size_t)N * C * V);
     int rc = gn_bwd(A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W);
+    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
@@ -492,7 +492,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W);
+    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
@@ -524,7 +524,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // head
     float* dlog = A.alloc((size_t)N * h->nout * Vl(0));
     RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
-    int rc = wgrad3_run(A, s, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0]);
+    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0]);
     if (rc) return rc;
     {
         const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
@@ -593,7 +593,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
     rc = gn_bwd(A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks
@@ -804,12 +804,18 @@ extern "C" int ru_conv3d_bwd_data_p(const float* dy, const float* w, float* dx, 
 
 extern "C" int ru_conv3d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int Cout, int D, int H, int W, int k,
                                     void* ws, size_t ws_bytes, ru_stream_t stream) {
+    return ru_conv3d_bwd_weight_p(x, dy, dw, db, N, Cin, Cout, D, H, W, k, RU_PREC_F32, ws, ws_bytes, stream);
+}
+
+extern "C" int ru_conv3d_bwd_weight_p(const float* x, const float* dy, float* dw, float* db, int N, int Cin, int Cout, int D, int H, int W, int k,
+                                      int precision, void* ws, size_t ws_bytes, ru_stream_t stream) {
     RU_REQUIRE(x && dy && dw, "ru_conv3d_bwd_weight: null argument");
+    RU_REQUIRE(precision == RU_PREC_F32 || precision == RU_PREC_BF16X3, "ru_conv3d_bwd_weight: bad precision");
     hipStream_t s = (hipStream_t)stream;
     WsCarver C(ws, ws_bytes);
     if (k == 3) {
         Wgrad3Args a{};
-        a.x = x; a.dy = dy; a.dw = dw; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+        a.x = x; a.dy = dy; a.dw = dw; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.mode = precision;
         a.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
         a.ws = C.take(a.ws_bytes / 4);
         RU_WS_OK(C);

@@ -79,9 +79,12 @@ struct Wgrad3Args {
     void* ws;                // partials
     size_t ws_bytes;
     int N, Cin, Cout, D, H, W;
+    int mode;                // RU_PREC_F32 / RU_PREC_BF16X3 (split-bf16 kernel, wgrad_sb.hip; needs W % 4 == 0)
 };
-size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
+size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s);
 
 // 1x1x1: dw[o][c] = sum_{n,v} dy[n][o][v] * x[n][c][v]; result written to dw[o*ldw + c] (ldw >= Cin)
 struct Wgrad1Args {

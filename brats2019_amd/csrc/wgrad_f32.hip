@@ -39,16 +39,20 @@ struct W3Slots {
 };
 
 template <int TZ, int TY, int OT, int CT>
-__global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, float* __restrict__ partials,
+__global__ __launch_bounds__(512, 4) void wgrad3_f32_kernel(const Wgrad3Args a, float* __restrict__ partials,
                                                            int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = W3<TZ, TY, OT, CT>;
     constexpr int DS = P::DS, CS = P::CS, HY = P::HY, HX = P::HX, HVOL = P::HVOL, TVOL = P::TVOL;
     constexpr int NROW = P::HZ * HY;
-    constexpr int NSX = (NROW * 6 + 255) / 256;          // x halo: six aligned 16-byte segments per row (as conv3_f32)
+    constexpr int NT = 512;                               // 8 waves: tap group (wave & 3) x voxel half (wave >> 2)
+    constexpr int NSX = (NROW * 6 + NT - 1) / NT;         // x halo: six aligned 16-byte segments per row (as conv3_f32)
     constexpr int Q4 = TVOL / 4;
-    constexpr int NSD = (OT * 16 * Q4 + 255) / 256;       // dy tile: float4 per thread
+    constexpr int NSD = (OT * 16 * Q4 + NT - 1) / NT;     // dy tile: float4 per thread
     constexpr int NCH = CT * 16;
-    constexpr int PFC = NCH <= 16 ? NCH : 8;              // channels whose loads are prefetched one tile ahead (register budget)
+    // second wave group (waves 4-7): for one (o,c) tile pair it takes the other voxel half; with OT == 2 it takes the
+    // other output-channel tile instead (halves the accumulator registers: 2x2 pairs x 7 taps would not fit 128 VGPRs)
+    constexpr bool SPLIT_O = OT == 2;
+    constexpr int OTW = SPLIT_O ? 1 : OT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dys = smem;
     float* xs = smem + OT * 16 * DS;
@@ -61,26 +65,28 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
     const bool xform = a.in_scale != nullptr;
     const bool vec = (W & 3) == 0;
+    const float slope_eff = xform ? a.in_slope : 1.f;
 
-    // this wave's taps
+    // this wave's taps and voxel half / output-channel tile
+    const int tg = wave & 3, vh = wave >> 2;
     int toff[7];
     bool tval[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-        const int tap = wave + 4 * j;
+        const int tap = tg + 4 * j;
         tval[j] = tap < 27;
         const int t = tval[j] ? tap : 0;
         toff[j] = ((t / 9) * HY + (t / 3) % 3) * HX + t % 3;
     }
-    f32x4 acc[7][OT][CT];
+    f32x4 acc[7][OTW][CT];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int p = 0; p < OT; ++p)
+        for (int p = 0; p < OTW; ++p)
 #pragma unroll
             for (int q = 0; q < CT; ++q) acc[j][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int abase = (lane & 15) * DS + (lane >> 4);
+    const int abase = (lane & 15) * DS + (lane >> 4) + (SPLIT_O ? vh * 16 * DS : 0);
     const int bbase = (lane & 15) * CS + (lane >> 4);
     const int ntile = a.N * ntz * nty * ntx;
 
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
         sl.n = n;
 #pragma unroll
         for (int j = 0; j < NSX; ++j) {
-            const int item = tid + j * 256;
+            const int item = tid + j * NT;
             const int row = item / 6, q = item - row * 6;
             const int hz = row / HY, hy = row - hz * HY;
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
         }
 #pragma unroll
         for (int j = 0; j < NSD; ++j) {
-            const int e4 = tid + j * 256;
+            const int e4 = tid + j * NT;
             const int ch = e4 / Q4, r = (e4 - ch * Q4) * 4;
             const int z = r / (TY * 16), y = (r / 16) % TY, x = r & 15;
             const int gz = z0 + z, gy = y0 + y, gx = x0 + x, o = o0 + ch;
@@ -135,13 +141,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
             const bool live = sl.gx[j] >= 0 && cg < a.Cin;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (xform) {
-                    t[e] = t[e] * sc + sh;
-                    t[e] = t[e] > 0.f ? t[e] : t[e] * a.in_slope;
-                }
-                t[e] = live ? t[e] : 0.f;          // zero padding applies to the ACTIVATED tensor
+                t[e] = fmaf(t[e], sc, sh);                       // branch-free: (1, 0, slope 1) when no transform
+                t[e] = fmaxf(t[e], t[e] * slope_eff);            // LeakyReLU for 0 < slope <= 1
+                t[e] = live ? t[e] : 0.f;                        // zero padding applies to the ACTIVATED tensor
             }
-            const int q = (tid + j * 256) % 6;
+            const int q = (tid + j * NT) % 6;
             float* dst = xs + cb * CS + sl.lx[j];
             if (q == 0) dst[3] = t[3];
             else if (q == 5) dst[0] = t[0];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     auto store_dy = [&](const W3Slots<NSX, NSD>& sl, const float4 (&dv)[NSD]) {
 #pragma unroll
         for (int j = 0; j < NSD; ++j) {
-            const int e4 = tid + j * 256;
+            const int e4 = tid + j * NT;
             if (e4 >= OT * 16 * Q4) continue;
             const int ch = e4 / Q4, r = (e4 - ch * Q4) * 4;
             const bool live = sl.gd[j] >= 0;
@@ -165,16 +169,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
         }
     };
     auto compute = [&]() {
+        const int zy0 = SPLIT_O ? 0 : vh * (TZ * TY / 2), zy1 = SPLIT_O ? TZ * TY : (vh + 1) * (TZ * TY / 2);
 #pragma unroll 1
-        for (int zy = 0; zy < TZ * TY; ++zy) {
+        for (int zy = zy0; zy < zy1; ++zy) {
             const int z = zy / TY, y = zy - z * TY;
             const int az = abase + zy * 16;
             const int bz = bbase + (z * HY + y) * HX;
 #pragma unroll
             for (int xq = 0; xq < 4; ++xq) {
-                float af[OT];
+                float af[OTW];
 #pragma unroll
-                for (int p = 0; p < OT; ++p) af[p] = dys[az + p * 16 * DS + xq * 4];
+                for (int p = 0; p < OTW; ++p) af[p] = dys[az + p * 16 * DS + xq * 4];
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
                     // no branch here: the 4th wave's 7th tap (tap 27) runs on tap 0's data into an accumulator that is
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
 #pragma unroll
                     for (int q = 0; q < CT; ++q) bf[q] = xs[bz + toff[j] + q * 16 * CS + xq * 4];
 #pragma unroll
-                    for (int p = 0; p < OT; ++p)
+                    for (int p = 0; p < OTW; ++p)
 #pragma unroll
                         for (int q = 0; q < CT; ++q)
                             acc[j][p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p], bf[q], acc[j][p][q], 0, 0, 0);
@@ -195,37 +200,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
     if (vec) {
         // ---- software-pipelined persistent loop: the global loads of tile t+1 (dy and the first PFC channels of x) are in
         // flight while tile t is on the matrix cores; they are consumed (transform + LDS store) after the next barrier.
+        // two workgroups of 8 waves per CU (4 waves per SIMD): while one stages a tile the other is on the matrix cores, and
+        // inside the MFMA loop the co-resident waves cover each other's LDS latency
         W3Slots<NSX, NSD> sl;
-        float4 pdy[NSD];
-        float4 px[PFC][NSX];
-        int tile = blockIdx.x;
-        if (tile < ntile) {
+        for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
             make_slots(tile, sl);
+            float4 pdy[NSD];
             load_dy(sl, pdy);
-#pragma unroll
-            for (int c = 0; c < PFC; ++c) load_x(sl, c, px[c]);
-        }
-        for (; tile < ntile; tile += gridDim.x) {
             __syncthreads();                       // previous tile's MFMA reads are done
-            store_dy(sl, pdy);
-#pragma unroll
-            for (int c = 0; c < PFC; ++c) store_x(sl, c, px[c]);
+            constexpr int CBATCH = SPLIT_O ? 4 : 8;   // channels x NSX float4 in flight per thread (register budget: 128)
 #pragma unroll 1
-            for (int cb = PFC; cb < NCH; cb += 8) {    // channels beyond the prefetch budget: load + store now, 8 at a time
-                float4 v[8][NSX];
+            for (int cb = 0; cb < NCH; cb += CBATCH) {
+                float4 v[CBATCH][NSX];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) load_x(sl, cb + c, v[c]);
+                for (int c = 0; c < CBATCH; ++c) load_x(sl, cb + c, v[c]);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) store_x(sl, cb + c, v[c]);
+                for (int c = 0; c < CBATCH; ++c) store_x(sl, cb + c, v[c]);
             }
+            store_dy(sl, pdy);
             __syncthreads();
-            const int next = tile + gridDim.x;
-            if (next < ntile) {
-                make_slots(next, sl);
-                load_dy(sl, pdy);
-#pragma unroll
-                for (int c = 0; c < PFC; ++c) load_x(sl, c, px[c]);
-            }
             compute();
         }
     } else {
@@ -234,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
             tile_origin(tile, n, z0, y0, x0);
             __syncthreads();
             // ---- scalar staging (ragged W): dy tile (zero outside the volume / beyond Cout), then the x halo tile
-            for (int e = tid; e < OT * 16 * TVOL; e += 256) {
+            for (int e = tid; e < OT * 16 * TVOL; e += NT) {
                 const int ch = e / TVOL;
                 const int r = e - ch * TVOL;
                 const int z = r / (TY * 16), y = (r / 16) % TY, x = r & 15;
@@ -243,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
                 if (o < a.Cout && gz < D && gy < H && gx < W) v = a.dy[((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx];
                 dys[ch * DS + r] = v;
             }
-            for (int e = tid; e < NCH * HVOL; e += 256) {
+            for (int e = tid; e < NCH * HVOL; e += NT) {
                 const int ch = e / HVOL;
                 const int s = e - ch * HVOL;
                 const int hz = s / (HY * HX);
@@ -264,21 +257,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3_f32_kernel(const Wgrad3Args a, 
             compute();
         }
     }
-    // ---- write this workgroup's partial: partials[blockIdx.x][tap][o][c]
+    // ---- write this workgroup's two partials (one per voxel half): partials[2*blockIdx.x + vh][tap][o][c]
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         if (!tval[j]) continue;
-        const int tap = wave + 4 * j;
+        const int tap = tg + 4 * j;
+        const size_t part = SPLIT_O ? (size_t)blockIdx.x : (size_t)(2 * blockIdx.x + vh);
 #pragma unroll
-        for (int p = 0; p < OT; ++p)
+        for (int p = 0; p < OTW; ++p)
 #pragma unroll
             for (int q = 0; q < CT; ++q) {
                 const int c = c0 + q * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int o = o0 + p * 16 + (lane >> 4) * 4 + r;
+                    const int o = o0 + (p + (SPLIT_O ? vh : 0)) * 16 + (lane >> 4) * 4 + r;
                     if (o < CoP && c < CiP)
-                        partials[(((size_t)blockIdx.x * 27 + tap) * CoP + o) * CiP + c] = acc[j][p][q][r];
+                        partials[((part * 27 + tap) * CoP + o) * CiP + c] = acc[j][p][q][r];
                 }
             }
     }
@@ -333,9 +327,13 @@ static W3Choice wgrad3_choose(int N, int Cin, int Cout, int D, int H, int W) {
     return c;
 }
 
-size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
+static size_t wgrad3_f32_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
     const W3Choice c = wgrad3_choose(N, Cin, Cout, D, H, W);
-    return (size_t)c.nbx * 27 * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
+    return (size_t)2 * c.nbx * 27 * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
+}
+size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
+    const size_t a = wgrad3_f32_workspace_bytes(N, Cin, Cout, D, H, W), b = wgrad3_sb_workspace_bytes(N, Cin, Cout, D, H, W);
+    return a > b ? a : b;
 }
 
 template <int TZ, int TY, int OT, int CT>
@@ -351,11 +349,11 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     dim3 grid(c.nbx, c.ngroups);
-    hipLaunchKernelGGL((wgrad3_f32_kernel<TZ, TY, OT, CT>), grid, dim3(256), lds, s, a, (float*)a.ws,
+    hipLaunchKernelGGL((wgrad3_f32_kernel<TZ, TY, OT, CT>), grid, dim3(512), lds, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, TY), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
     const int total = 27 * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP,
                        a.Cout, a.Cin, a.dw, a.Cin * 27, 27);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
@@ -363,8 +361,9 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
 
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.D > 0 && a.H > 0 && a.W > 0, "wgrad3: bad shape");
+    if (a.mode == RU_PREC_BF16X3 && (a.W & 3) == 0) return wgrad3_sb_launch(a, s);
     const W3Choice c = wgrad3_choose(a.N, a.Cin, a.Cout, a.D, a.H, a.W);
-    if (a.ws_bytes < wgrad3_workspace_bytes(a.N, a.Cin, a.Cout, a.D, a.H, a.W) || !a.ws) {
+    if (a.ws_bytes < wgrad3_f32_workspace_bytes(a.N, a.Cin, a.Cout, a.D, a.H, a.W) || !a.ws) {
         set_error("wgrad3: workspace too small");
         return RU_ENOMEM;
     }

@@ -57,7 +57,7 @@ def conv3d_bwd_data(dy, w, in_spatial, precision="f32"):
     return dx
 
 
-def conv3d_bwd_weight(x, dy, k, with_bias=False):
+def conv3d_bwd_weight(x, dy, k, with_bias=False, precision="f32"):
     """Weight (and bias) gradient of the conv above."""
     x, dy = _prep(x), _prep(dy)
     lib = L.load()
@@ -66,8 +66,8 @@ def conv3d_bwd_weight(x, dy, k, with_bias=False):
     dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if with_bias else None
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, k), x.device)
-    L.check(lib.ru_conv3d_bwd_weight(L.f32(x), L.f32(dy), L.f32(dw), L.ptr(db, True), n, cin, cout, d, h, wd, k,
-                                     L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_bwd_weight")
+    L.check(lib.ru_conv3d_bwd_weight_p(L.f32(x), L.f32(dy), L.f32(dw), L.ptr(db, True), n, cin, cout, d, h, wd, k, L.PRECISIONS[precision],
+                                       L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_bwd_weight")
     return (dw, db) if with_bias else dw
 
 

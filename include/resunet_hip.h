@@ -62,6 +62,9 @@ int ru_conv3d_fwd_p(const float* x, const float* w, const float* bias, float* y,
 int ru_conv3d_bwd_data_p(const float* dy, const float* w, float* dx,
                          int N, int Cin, int Cout, int D, int H, int W, int k, int precision,
                          void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_conv3d_bwd_weight_p(const float* x, const float* dy, float* dw, float* db,
+                           int N, int Cin, int Cout, int D, int H, int W, int k, int precision,
+                           void* ws, size_t ws_bytes, ru_stream_t stream);
 /* dx = d(loss)/dx given dy (autograd of the calls above) */
 int ru_conv3d_bwd_data(const float* dy, const float* w, float* dx,
                        int N, int Cin, int Cout, int D, int H, int W, int k,
@@ -132,7 +135,7 @@ int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vm
 ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const int* decoder_layers,
                          const int* number_of_channels, int number_of_outputs);
 void ru_unet_destroy(ru_unet_t h);
-/* RU_PREC_* used by the 3x3x3 convolutions (forward and data gradient) of subsequent forward/backward calls;
+/* RU_PREC_* used by the 3x3x3 convolutions (forward, data gradient, weight gradient) of subsequent forward/backward calls;
  * default RU_PREC_F32.  Change it only between steps (not between a forward and its backward).  */
 int ru_unet_set_precision(ru_unet_t h, int precision);
 int ru_unet_get_precision(ru_unet_t h);

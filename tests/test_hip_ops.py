@@ -244,6 +244,9 @@ def test_conv3_bf16x3_vs_oracle(ops, case):
     y.backward(T(dy))
     close_rel_max(ops.conv3d(dev(x), dev(wt), dev(b), precision="bf16x3"), y.detach().numpy(), rel=1e-4, name="bf16x3 fwd %s" % (case,))
     close_rel_max(ops.conv3d_bwd_data(dev(dy), dev(wt), (d, h, w), precision="bf16x3"), xt.grad.numpy(), rel=1e-4, name="bf16x3 dgrad %s" % (case,))
+    wtt2 = T(wt).requires_grad_(True)
+    O.conv3x3x3(T(x), wtt2).backward(T(dy))
+    close_rel_max(ops.conv3d_bwd_weight(dev(x), dev(dy), 3, precision="bf16x3"), wtt2.grad.numpy(), rel=2e-4, name="bf16x3 wgrad %s" % (case,))
 
 
 def test_conv3_bf16x3_is_not_plain_bf16(ops):
