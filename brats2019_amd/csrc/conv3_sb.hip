@@ -290,82 +290,98 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 
     if (producer) {
         // ---------------------------------------------------------------- producers
-        int gv[NSV], lp[NSV];           // slots of the item whose loads are in flight
-        int n_cur = 0;
-        float4 v[2][NSV][8];            // [channel half][slot][channel]: 16 channels x 4 voxels per slot in flight
-        auto issue = [&](int item) {    // compute slots + issue every load of `item` (no waits)
+        // Work items of one (tile, 16-channel chunk):
+        //   interior: halo row x 4 aligned float4 segments [x0+4q, +4)  -> NROW*4 items, every lane has 4 valid voxels
+        //   edge    : halo row x {x0-1, x0+16}                           -> NROW*2 items, one scalar per channel
+        // (the six-segment cover of the 18-wide row wasted 6 of 24 loaded floats and half of the lanes' VALU work)
+        constexpr int NI = NROW * 4, NE = NROW * 2;
+        static_assert(NI <= 256 && NE <= 128, "one interior and one edge item per producer thread");
+        const bool has_i = ptid < NI;
+        const int e_id = ptid - (256 - NE);                  // edge items live on the last NE producer threads
+        const bool has_e = e_id >= 0;
+        const int irow = ptid / 4, iq = ptid & 3;
+        const int erow = has_e ? e_id >> 1 : 0, eside = e_id & 1;
+        int gi = -1, ge = -1, n_cur = 0;                     // global offsets inside one channel volume (-1: zero fill)
+        float4 vi[16];
+        float ve[16];
+        auto issue = [&](int item) {                          // issue every load of `item` (no waits)
             if (dbg & 2) return;
             const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
             int z0, y0, x0, tis;
             tile_origin(tile, n_cur, z0, y0, x0, tis);
-#pragma unroll
-            for (int j = 0; j < NSV; ++j) {
-                const int it = ptid + j * 256;
-                const int row = it / 6, q = it - row * 6;
-                const int hz = row / HY, hy = row - hz * HY;
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
-                const bool slot = it < NROW * 6;
-                const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
-                gv[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
-                lp[j] = row * HX + 4 * q - 3;
+            {
+                const int hz = irow / HY, hy = irow - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 4 * iq;
+                const bool ok = has_i && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx < W;
+                gi = ok ? (gz * H + gy) * W + gx : -1;
+            }
+            {
+                const int hz = erow / HY, hy = erow - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = eside ? x0 + 16 : x0 - 1;
+                const bool ok = has_e && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                ge = ok ? (gz * H + gy) * W + gx : -1;
             }
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int j = 0; j < NSV; ++j)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const int cc = chunk * 16 + half * 8 + c;
-                        const int cg = cc < a.Cin ? cc : a.Cin - 1;            // unconditional, clamped (see v1)
-                        v[half][j][c] = *reinterpret_cast<const float4*>(a.x + ((size_t)n_cur * a.Cin + cg) * DHW + (gv[j] > 0 ? gv[j] : 0));
-                    }
+            for (int c = 0; c < 16; ++c) {
+                const int cc = chunk * 16 + c;
+                const float* xp = a.x + ((size_t)n_cur * a.Cin + (cc < a.Cin ? cc : a.Cin - 1)) * DHW;   // unconditional, clamped
+                vi[c] = *reinterpret_cast<const float4*>(xp + (gi > 0 ? gi : 0));
+                ve[c] = xp[ge > 0 ? ge : 0];
+            }
         };
-        auto store = [&](int item, u32x4* buf) {   // consume the in-flight loads of `item`: transform, split, transpose
-            if (dbg & 1) { if (!(dbg & 2)) { float acc0 = 0.f;
+        auto store = [&](int item, u32x4* buf) {              // consume the in-flight loads: transform, split, transpose
+            if (dbg & 1) {
+                if (!(dbg & 2)) {
+                    float acc0 = 0.f;
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int j = 0; j < NSV; ++j)
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) acc0 += v[h2][j][c].x;
-                if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u}; } return; }
+                    for (int c = 0; c < 16; ++c) acc0 += vi[c].x + ve[c];
+                    if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u};
+                }
+                return;
+            }
             const int chunk = item % nchunk;
+            const float mi = gi >= 0 ? 1.f : 0.f, me = ge >= 0 ? 1.f : 0.f;   // zero padding applies to the ACTIVATED tensor
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int cb = chunk * 16 + half * 8;
-                // affine constants of the 8 channels; channels beyond Cin get (0, 0) -> exact zeros without a select
-                float sc[8], sh[8];
+                float sci[8], shi[8], sce[8], she[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const bool cok = cb + c < a.Cin;
-                    sc[c] = cok ? 1.f : 0.f; sh[c] = 0.f;
-                    if (xform && cok) { sc[c] = a.in_scale[n_cur * a.Cin + cb + c]; sh[c] = a.in_shift[n_cur * a.Cin + cb + c]; }
+                    float sc = cok ? 1.f : 0.f, sh = 0.f;     // channels beyond Cin: (0, 0) -> exact zeros without a select
+                    if (xform && cok) { sc = a.in_scale[n_cur * a.Cin + cb + c]; sh = a.in_shift[n_cur * a.Cin + cb + c]; }
+                    sci[c] = sc * mi; shi[c] = sh * mi; sce[c] = sc * me; she[c] = sh * me;
                 }
-#pragma unroll
-                for (int j = 0; j < NSV; ++j) {
-                    if (gv[j] == -2) continue;
-                    // zero padding applies to the ACTIVATED tensor: out-of-volume lanes use (0, 0) too (their clamped loads are finite)
-                    const float m = gv[j] >= 0 ? 1.f : 0.f;
-                    float scm[8], shm[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) { scm[c] = sc[c] * m; shm[c] = sh[c] * m; }
-                    const int q = (ptid + j * 256) % 6;
-                    const int e0 = q == 0 ? 3 : 0, e1 = q == 5 ? 1 : 4;
+                if (has_i) {
+                    const int lp = irow * HX + 4 * iq + 1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (e < e0 || e >= e1) continue;
                         float t[8];
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
-                            float u = e == 0 ? v[half][j][c].x : (e == 1 ? v[half][j][c].y : (e == 2 ? v[half][j][c].z : v[half][j][c].w));
-                            u = fmaf(u, scm[c], shm[c]);
-                            t[c] = fmaxf(u, u * slope);                     // LeakyReLU for 0 < slope <= 1 (slope 1: identity)
+                            const float4 f = vi[half * 8 + c];
+                            float u = e == 0 ? f.x : (e == 1 ? f.y : (e == 2 ? f.z : f.w));
+                            u = fmaf(u, sci[c], shi[c]);
+                            t[c] = fmaxf(u, u * slope);       // LeakyReLU for 0 < slope <= 1 (slope 1: identity)
                         }
                         u32x4 hi, lo;
                         split8(t, hi, lo);
-                        buf[half * HVOLP + lp[j] + e] = hi;
-                        buf[(2 + half) * HVOLP + lp[j] + e] = lo;
+                        buf[half * HVOLP + lp + e] = hi;
+                        buf[(2 + half) * HVOLP + lp + e] = lo;
                     }
+                }
+                if (has_e) {
+                    const int lp = erow * HX + (eside ? 17 : 0);
+                    float t[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float u = fmaf(ve[half * 8 + c], sce[c], she[c]);
+                        t[c] = fmaxf(u, u * slope);
+                    }
+                    u32x4 hi, lo;
+                    split8(t, hi, lo);
+                    buf[half * HVOLP + lp] = hi;
+                    buf[(2 + half) * HVOLP + lp] = lo;
                 }
             }
         };
@@ -414,23 +430,54 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             }
             if (nchunk > 1) load_w(chunk);
             const u32x4* buf = lds + (w & 1) * BUF;
-            if (!(dbg & 4))
+            if (!(dbg & 4)) {
+                // software pipeline over two register sets (M-tiles 0..MT/2-1 and MT/2..MT-1): the A fragments of the next
+                // K-step are read while the other set's MFMAs run (one wave per SIMD cannot hide LDS latency by itself)
+                constexpr int HM = MT / 2;
+                bf16x8 ah0[HM], al0[HM], ah1[HM], al1[HM];
 #pragma unroll
-            for (int ks = 0; ks < SB_KSTEPS; ++ks) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                bf16x8 ah[MT], al[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks] + i * HX]);
-                    al[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks] + 2 * HVOLP + i * HX]);
+                for (int i = 0; i < HM; ++i) {
+                    ah0[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + i * HX]);
+                    al0[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + i * HX]);
                 }
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i], 0, 0, 0);
+                for (int i = 0; i < HM; ++i) {
+                    ah1[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (HM + i) * HX]);
+                    al1[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (HM + i) * HX]);
+                }
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i], 0, 0, 0);
+                for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0[i], bl, acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0[i], bh, acc[i], 0, 0, 0);
+                    if (ks + 1 < SB_KSTEPS) {
+#pragma unroll
+                        for (int i = 0; i < HM; ++i) {
+                            ah0[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + i * HX]);
+                            al0[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + 2 * HVOLP + i * HX]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1[i], bh, acc[HM + i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1[i], bl, acc[HM + i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1[i], bh, acc[HM + i], 0, 0, 0);
+                    if (ks + 1 < SB_KSTEPS) {
+#pragma unroll
+                        for (int i = 0; i < HM; ++i) {
+                            ah1[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + (HM + i) * HX]);
+                            al1[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + 2 * HVOLP + (HM + i) * HX]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (chunk == nchunk - 1 && !(dbg & 8)) {
                 int n, z0, y0, x0, tis;

@@ -44,21 +44,21 @@ static inline unsigned grid1d(size_t n, int per_block, unsigned cap = 1u << 20) 
 // Each thread owns VEC consecutive voxels and 16 output channels; the weight of (c, o) is wave-uniform, so it is
 // fetched by scalar loads and used as the SGPR operand of v_fmac_f32.  The channel concat of model.py:424 is the
 // two-pointer input (x0 then x1) -- the cat is never materialised.
-template <int VEC>
+template <int VEC, int COT>
 __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
     const int n = blockIdx.z;
-    const int co0 = blockIdx.y * 16;
+    const int co0 = blockIdx.y * COT;
     const size_t V = a.V;
     const size_t v = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (v >= V) return;
-    float acc[16][VEC];
+    float acc[COT][VEC];
 #pragma unroll
-    for (int o = 0; o < 16; ++o)
+    for (int o = 0; o < COT; ++o)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[o][k] = 0.f;
-    int widx[16];
+    int widx[COT];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) widx[o] = (co0 + o < a.Cout) ? co0 + o : a.Cout - 1;
+    for (int o = 0; o < COT; ++o) widx[o] = (co0 + o < a.Cout) ? co0 + o : a.Cout - 1;
 
     const float* xp = a.x0 + (size_t)n * a.C0 * V + v;
     const float* wr = a.wT;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
             xv[0] = xp[(size_t)c * V];
         }
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
+        for (int o = 0; o < COT; ++o) {
             const float w = wr[(size_t)c * a.ldw + widx[o]];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[o][k] += w * xv[k];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
                 xv[0] = xq[(size_t)c * V];
             }
 #pragma unroll
-            for (int o = 0; o < 16; ++o) {
+            for (int o = 0; o < COT; ++o) {
                 const float w = wq[(size_t)c * a.ldw + widx[o]];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[o][k] += w * xv[k];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
         }
     }
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
+    for (int o = 0; o < COT; ++o) {
         if (co0 + o >= a.Cout) continue;
         const size_t idx = ((size_t)n * a.Cout + co0 + o) * V + v;
         float r[VEC];
@@ -117,10 +117,16 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
 int conv1_launch(const Conv1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cout, "conv1: bad shape");
     const bool vec = (a.V % 4) == 0;
-    const size_t nthreads = vec ? a.V / 4 : a.V;
-    dim3 grid((unsigned)((nthreads + 255) / 256), (unsigned)cdiv(a.Cout, 16), (unsigned)a.N);
-    if (vec) hipLaunchKernelGGL(conv1_kernel<4>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv1_kernel<1>, grid, dim3(256), 0, s, a);
+    // few voxels x many channels (deep levels): one voxel and 4 outputs per thread, otherwise the launch is a handful of
+    // workgroups each walking hundreds of input channels serially (latency-bound)
+    const long wg_big = (long)((a.V / 4 + 255) / 256) * cdiv(a.Cout, 16) * a.N;
+    if (!vec || wg_big < 256) {
+        dim3 grid((unsigned)((a.V + 255) / 256), (unsigned)cdiv(a.Cout, 4), (unsigned)a.N);
+        hipLaunchKernelGGL((conv1_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((unsigned)((a.V / 4 + 255) / 256), (unsigned)cdiv(a.Cout, 16), (unsigned)a.N);
+        hipLaunchKernelGGL((conv1_kernel<4, 16>), grid, dim3(256), 0, s, a);
+    }
     RU_CHECK_LAUNCH("conv1_kernel");
     return RU_OK;
 }
@@ -235,7 +241,7 @@ int gn_stats_launch(const float* x, float* partials, int N, int C, size_t V, hip
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ scale, float* __restrict__ shift, int C, size_t V, int G, float eps) {
-    __shared__ double buf[4];
+    __shared__ double buf[4][2];
     __shared__ float sh[2];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
@@ -243,9 +249,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const int cnt = cpg * nblk;
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < cnt; i += 256) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
-    s1 = block_sum_d(s1, buf);
-    s2 = block_sum_d(s2, buf);
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { buf[threadIdx.x >> 6][0] = s1; buf[threadIdx.x >> 6][1] = s2; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        s1 = (buf[0][0] + buf[1][0]) + (buf[2][0] + buf[3][0]);
+        s2 = (buf[0][1] + buf[1][1]) + (buf[2][1] + buf[3][1]);
         const double m = (double)cpg * (double)V;
         const double mu = s1 / m;
         double var = s2 / m - mu * mu;
@@ -360,55 +370,56 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
     return RU_OK;
 }
 
-// one workgroup per group g, walking the batch in order (deterministic dgamma/dbeta)
+// one workgroup per group g.  Every (sample, channel-of-group) pair is reduced by ONE wave with shuffles only (fixed order:
+// deterministic), one barrier, then the per-sample coefficients and the batch-ordered dgamma/dbeta sums.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G) {
-    __shared__ double buf[4];
-    __shared__ double S[2][256];
+    extern __shared__ double S[];            // [N][cpg][2]
     const int g = blockIdx.x;
     const int cpg = C / G;
-    double dg_acc = 0.0, db_acc = 0.0;   // threads < cpg accumulate their channel over n
-    for (int n = 0; n < N; ++n) {
-        for (int j = 0; j < cpg; ++j) {
-            const float* p = partials + ((size_t)n * C + g * cpg + j) * nblk * 2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = threadIdx.x; i < nblk; i += 256) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
-            s1 = block_sum_d(s1, buf);
-            s2 = block_sum_d(s2, buf);
-            if (threadIdx.x == 0) { S[0][j] = s1; S[1][j] = s2; }
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int item = wave; item < N * cpg; item += 4) {
+        const int n = item / cpg, j = item - n * cpg;
+        const float* p = partials + ((size_t)n * C + g * cpg + j) * nblk * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = lane; i < nblk; i += 64) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane == 0) { S[item * 2] = s1; S[item * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    const double m = (double)cpg * (double)V;
+    for (int n = threadIdx.x; n < N; n += 256) {
         double m1 = 0.0, m2 = 0.0;
         for (int j = 0; j < cpg; ++j) {
             const double gm = (double)gamma[g * cpg + j];
-            m1 += gm * S[0][j];
-            m2 += gm * S[1][j];
+            m1 += gm * S[(n * cpg + j) * 2];
+            m2 += gm * S[(n * cpg + j) * 2 + 1];
         }
-        const double m = (double)cpg * (double)V;
         m1 /= m; m2 /= m;
         const double mu = (double)mean[n * G + g], rs = (double)rstd[n * G + g];
-        if (threadIdx.x < cpg) {
-            const int c = g * cpg + threadIdx.x;
+        for (int j = 0; j < cpg; ++j) {
+            const int c = g * cpg + j;
             float* q = coef + ((size_t)n * C + c) * 3;
             q[0] = (float)(rs * (double)gamma[c]);
             q[1] = (float)(-rs * rs * m2);
             q[2] = (float)(rs * rs * m2 * mu - rs * m1);
-            db_acc += S[0][threadIdx.x];
-            dg_acc += S[1][threadIdx.x];
         }
-        __syncthreads();
     }
-    if (threadIdx.x < cpg) {
-        const int c = g * cpg + threadIdx.x;
-        if (dgamma) dgamma[c] = (float)dg_acc;
-        if (dbeta) dbeta[c] = (float)db_acc;
+    for (int j = threadIdx.x; j < cpg; j += 256) {
+        double dg = 0.0, db = 0.0;
+        for (int n = 0; n < N; ++n) { db += S[(n * cpg + j) * 2]; dg += S[(n * cpg + j) * 2 + 1]; }
+        if (dgamma) dgamma[g * cpg + j] = (float)dg;
+        if (dbeta) dbeta[g * cpg + j] = (float)db;
     }
 }
 int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
                            float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s) {
     RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    const size_t shm = (size_t)N * (C / G) * 2 * sizeof(double);
+    RU_REQUIRE(shm <= 60000, "groupnorm backward: batch x channels-per-group too large for the finalize kernel");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
     RU_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     return RU_OK;
 }
@@ -515,7 +526,49 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
         *reinterpret_cast<float2*>(yp) = make_float2(ev, ov);
     }
 }
+// W even: one thread per FOUR consecutive outputs (coarse k = 2m, 2m+1): 16 cached loads, one 16-byte store
+__global__ __launch_bounds__(256) void up2_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wh = W / 2;
+    const size_t total = (size_t)NC * Do * Ho * Wh;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i % Wh);
+        size_t r = i / Wh;
+        const int yo = (int)(r % Ho); r /= Ho;
+        const int zo = (int)(r % Do);
+        const size_t nc = r / Do;
+        int z0, z1, y0, y1; float lz0, lz1, ly0, ly1;
+        up2_src(zo, D, z0, z1, lz0, lz1);
+        up2_src(yo, H, y0, y1, ly0, ly1);
+        const int k = 2 * m;
+        const int km = k > 0 ? k - 1 : 0, kpp = k + 2 < W ? k + 2 : W - 1;
+        const float* rows[4] = {x + ((nc * D + z0) * H + y0) * (size_t)W, x + ((nc * D + z0) * H + y1) * (size_t)W,
+                                x + ((nc * D + z1) * H + y0) * (size_t)W, x + ((nc * D + z1) * H + y1) * (size_t)W};
+        const float wgt[4] = {lz0 * ly0, lz0 * ly1, lz1 * ly0, lz1 * ly1};
+        // same nesting as the scalar kernel: z (y (x)))
+        float o[4];
+        float rowv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a0 = rows[q][km], a1 = rows[q][k], a2 = rows[q][k + 1], a3 = rows[q][kpp];
+            rowv[q][0] = k > 0 ? 0.25f * a0 + 0.75f * a1 : 1.f * a1 + 0.f * a2;      // output 2k   (k == 0: x[0] with weight 1)
+            rowv[q][1] = 0.75f * a1 + 0.25f * a2;                                     // output 2k+1
+            rowv[q][2] = 0.25f * a1 + 0.75f * a2;                                     // output 2k+2 = 2(k+1)
+            rowv[q][3] = 0.75f * a2 + 0.25f * a3;                                     // output 2k+3 (a3 clamped at the end)
+        }
+        (void)wgt;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            o[t] = lz0 * (ly0 * rowv[0][t] + ly1 * rowv[1][t]) + lz1 * (ly0 * rowv[2][t] + ly1 * rowv[3][t]);
+        *reinterpret_cast<float4*>(y + ((nc * Do + zo) * Ho + yo) * (size_t)(2 * W) + 4 * m) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {
+    if ((W & 1) == 0) {
+        const size_t total = (size_t)N * C * 2 * D * 2 * H * (W / 2);
+        hipLaunchKernelGGL(up2_fwd_vec_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, x, y, N * C, D, H, W);
+        RU_CHECK_LAUNCH("up2_fwd_vec_kernel");
+        return RU_OK;
+    }
     const size_t total = (size_t)N * C * 2 * D * 2 * H * W;
     hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, x, y, N * C, D, H, W);
     RU_CHECK_LAUNCH("up2_fwd_kernel");
@@ -569,7 +622,58 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ 
         dx[i] = acc;
     }
 }
+// W even: one thread per TWO coarse voxels (kx = 2m, 2m+1): per fine row one aligned float4 (ox 4m..4m+3) plus the two
+// neighbours 4m-1 and 4m+4 instead of eight scalar loads
+__global__ __launch_bounds__(256) void up2_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W, Wh = W / 2;
+    const size_t total = (size_t)NC * D * H * Wh;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i % Wh);
+        size_t r = i / Wh;
+        const int ky = (int)(r % H); r /= H;
+        const int kz = (int)(r % D);
+        const size_t nc = r / D;
+        const int k0 = 2 * m, k1 = 2 * m + 1;
+        float wz[4], wy[4], wa[4], wb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oz = 2 * kz - 1 + t, oy = 2 * ky - 1 + t, oa = 2 * k0 - 1 + t, ob = 2 * k1 - 1 + t;
+            wz[t] = (oz >= 0 && oz < Do) ? up2_coef(oz, D, kz) : 0.f;
+            wy[t] = (oy >= 0 && oy < Ho) ? up2_coef(oy, H, ky) : 0.f;
+            wa[t] = (oa >= 0 && oa < Wo) ? up2_coef(oa, W, k0) : 0.f;
+            wb[t] = (ob >= 0 && ob < Wo) ? up2_coef(ob, W, k1) : 0.f;
+        }
+        const int oxl = 4 * m - 1 >= 0 ? 4 * m - 1 : 0, oxr = 4 * m + 4 < Wo ? 4 * m + 4 : Wo - 1;   // clamped (their weights are 0 when outside)
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oz = 2 * kz - 1 + a;
+            const int ozc = oz < 0 ? 0 : (oz >= Do ? Do - 1 : oz);
+            float ay0 = 0.f, ay1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int oy = 2 * ky - 1 + b;
+                const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy);
+                const float* p = dy + ((nc * Do + ozc) * Ho + oyc) * (size_t)Wo;
+                const float4 f = *reinterpret_cast<const float4*>(p + 4 * m);     // fine 4m .. 4m+3
+                const float fl = p[oxl], fr = p[oxr];
+                // k0 = 2m uses fine 4m-1 .. 4m+2 ; k1 = 2m+1 uses fine 4m+1 .. 4m+4
+                ay0 += wy[b] * (wa[0] * fl + wa[1] * f.x + wa[2] * f.y + wa[3] * f.z);
+                ay1 += wy[b] * (wb[0] * f.y + wb[1] * f.z + wb[2] * f.w + wb[3] * fr);
+            }
+            acc0 += wz[a] * ay0;
+            acc1 += wz[a] * ay1;
+        }
+        *reinterpret_cast<float2*>(dx + ((nc * D + kz) * H + ky) * (size_t)W + 2 * m) = make_float2(acc0, acc1);
+    }
+}
 int up2_bwd_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s) {
+    if ((W & 1) == 0) {
+        const size_t tv = (size_t)N * C * D * H * (W / 2);
+        hipLaunchKernelGGL(up2_bwd_vec_kernel, dim3(grid1d(tv, 256)), dim3(256), 0, s, dy, dx, N * C, D, H, W);
+        RU_CHECK_LAUNCH("up2_bwd_vec_kernel");
+        return RU_OK;
+    }
     const size_t total = (size_t)N * C * D * H * W;
     hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, s, dy, dx, N * C, D, H, W);
     RU_CHECK_LAUNCH("up2_bwd_kernel");

@@ -460,18 +460,24 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
                     acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p], bf[q], acc[p][q], 0, 0, 0);
         }
     }
-    const int part = blockIdx.x * 4 + wave;
+    // fold the four waves' accumulators through LDS (fixed order) and write ONE partial per workgroup
+    __syncthreads();
+    float* red = smem;                                   // [4][OT*CT][256]
 #pragma unroll
     for (int p = 0; p < OT; ++p)
 #pragma unroll
-        for (int q = 0; q < CT; ++q) {
-            const int c = c0 + q * 16 + (lane & 15);
+        for (int q = 0; q < CT; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = o0 + p * 16 + (lane >> 4) * 4 + r;
-                if (o < CoP && c < CiP) partials[((size_t)part * CoP + o) * CiP + c] = acc[p][q][r];
-            }
-        }
+            for (int r = 0; r < 4; ++r) red[((wave * OT * CT + p * CT + q) * 4 + r) * 64 + lane] = acc[p][q][r];
+    __syncthreads();
+    for (int e = tid; e < OT * CT * 256; e += 256) {
+        const int pq = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        const float v = (red[((0 * OT * CT + pq) * 4 + r) * 64 + ln] + red[((1 * OT * CT + pq) * 4 + r) * 64 + ln]) +
+                        (red[((2 * OT * CT + pq) * 4 + r) * 64 + ln] + red[((3 * OT * CT + pq) * 4 + r) * 64 + ln]);
+        const int p = pq / CT, q = pq - p * CT;
+        const int c = c0 + q * 16 + (ln & 15), o = o0 + p * 16 + (ln >> 4) * 4 + r;
+        if (o < CoP && c < CiP) partials[((size_t)blockIdx.x * CoP + o) * CiP + c] = v;
+    }
 }
 
 struct W1Choice { int ot, ct, nbx, ngroups, ncg, nchunk; };
@@ -494,7 +500,7 @@ static W1Choice wgrad1_choose(int N, int Cin, int Cout, size_t V) {
 
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V) {
     const W1Choice c = wgrad1_choose(N, Cin, Cout, V);
-    return (size_t)c.nbx * 4 * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
+    return (size_t)c.nbx * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
 }
 
 template <int OT, int CT>
@@ -511,7 +517,7 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad1_f32_kernel<OT, CT>), dim3(c.nbx, c.ngroups), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad1_f32_kernel");
     const int total = a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx * 4, 1, CoP, CiP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 1, CoP, CiP,
                        a.Cout, a.Cin, a.dw, a.ldw, 1);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;

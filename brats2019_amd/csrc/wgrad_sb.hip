@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_sb_kernel(const Wgrad3Args a, f
     const int ntile = a.N * ntz * nty * ntx;
 
     // staging items (tile independent part)
-    constexpr int XITEMS = 16 * XROWS * 6, NXI = ((XITEMS + 255) / 256 + 2) / 3 * 3;   // float4 segments of the x halo tile (multiple of the batch)
+    constexpr int XITEMS = 16 * XROWS * 6, XBATCH = OT == 1 ? 5 : 3, NXI = ((XITEMS + 255) / 256 + XBATCH - 1) / XBATCH * XBATCH;   // float4 segments of the x halo tile
     constexpr int DITEMS = OT * 16 * DROWS * 4, NDI = (DITEMS + 255) / 256;  // float4 segments of the dy tile
 
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_sb_kernel(const Wgrad3Args a, f
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;
         __syncthreads();                                   // previous tile's reads are done
         // ---- x halo tile: 16 channels x XROWS rows x 6 aligned float4 -> fused transform -> hi/lo packets (8-byte halves)
-        constexpr int XB = 3;                                        // float4 loads in flight per thread and batch
+        constexpr int XB = XBATCH;                                   // float4 loads in flight per thread and batch (register budget)
 #pragma unroll 1
         for (int jb = 0; jb < NXI; jb += XB) {
             float4 v[XB];
@@ -260,8 +260,9 @@ static WSBChoice wsb_choose(int N, int Cin, int Cout, int D, int H, int W) {
     c.ot = CoP >= 32 ? 2 : 1;
     c.ncg = CiP / 16;
     c.ngroups = cdiv(CoP, 16 * c.ot) * c.ncg;
-    const long ntile = (long)N * cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 16);
-    long nbx = 768 / c.ngroups;
+    const int tz = c.ot == 1 ? 4 : 2;                 // one (o,c) pair: 4x4x16 tile (74 KB LDS, 2 workgroups / CU); two o-tiles: 2x4x16
+    const long ntile = (long)N * cdiv(D, tz) * cdiv(H, 4) * cdiv(W, 16);
+    long nbx = (c.ot == 1 ? 512 : 768) / c.ngroups;
     if (nbx < 1) nbx = 1;
     if (nbx > ntile) nbx = ntile;
     c.nbx = (int)nbx;
@@ -275,16 +276,17 @@ size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) 
 
 template <int OT>
 static int wsb_cfg(const Wgrad3Args& a, const WSBChoice& c, hipStream_t s) {
-    using P = WSB<2, 4, OT>;
+    constexpr int TZ = OT == 1 ? 4 : 2;
+    using P = WSB<TZ, 4, OT>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_sb_kernel<2, 4, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_sb_kernel<TZ, 4, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_sb)");
         attr_done = true;
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
-    hipLaunchKernelGGL((wgrad3_sb_kernel<2, 4, OT>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
-                       cdiv(a.D, 2), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, CoP, CiP);
+    hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
+                       cdiv(a.D, TZ), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_sb_kernel");
     const int total = 27 * a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
