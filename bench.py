@@ -133,6 +133,32 @@ def roofline_probe(batch, size, precision, launches=20):
             "algorithmic_bytes_per_launch": int(abytes), "hbm_algorithmic_gbps": round(gbps, 1)}
 
 
+def sliding_window_probe(backend, flat, precision, batch_tiles=8):
+    """BASELINE configs[4]: full-volume inference of one BraTS-native 240x240x155x4 volume with overlapping 128^3 tiles
+    (centre 64, border 32 -> 4 x 4 x 3 = 48 tiles, train.py:158-174 geometry generalised as in SURVEY 3.4), tiles batched
+    per forward, volume resident in HBM."""
+    from brats2019_amd import tiling
+    dev = flat.device
+    shape = (240, 240, 155)
+    vol = torch.randn((1, 4) + shape, device=dev)
+    tile, centre, border = (128, 128, 128), (64, 64, 64), (32, 32, 32)
+    grid = tiling.grid_for(shape, centre)
+    positions = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
+    out = torch.zeros((1, 3) + shape, device=dev)
+
+    def run():
+        for s0 in range(0, len(positions), batch_tiles):
+            idx = [tiling.get_indices(p, centre, border) for p in positions[s0:s0 + batch_tiles]]
+            tiles = torch.cat([tiling.copy(vol, tile, lo, hi) for lo, hi in idx], dim=0)
+            probs = backend.forward(flat, tiles, training=False)
+            for t, (lo, hi) in enumerate(idx):
+                tiling.copy_back(out, probs[t:t + 1], centre, lo, hi, border)
+    run()
+    dt = time_region(run, 3, False) / 3
+    return {"value": round(1.0 / dt, 3), "unit": "240x240x155 volumes/s", "tiles": len(positions), "tile": 128, "centre": 64, "border": 32,
+            "batch_tiles": batch_tiles, "ms_per_volume": round(dt * 1e3, 2), "tiles_per_s": round(len(positions) / dt, 1), "precision": precision}
+
+
 def cpu_baseline(size, threads=0):
     """The CPU oracle = the reference's op sequence on torch CPU, fwd+loss+bwd, batch 1.
     `cores` = torch threads actually used: on a many-core host the oneDNN/OpenMP path of this op mix is fastest well
@@ -223,6 +249,8 @@ def main():
         out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3),
                       "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2)}
         out["roofline"] = roofline_probe(args.batch, args.size, args.precision)
+        if args.size == 128:
+            out["sliding_window"] = sliding_window_probe(backend, flat, args.precision)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if rank == 0:

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
     using P = SB<TZ, TY>;
-    constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NSV = P::NSV, NROW = P::NROW;
+    constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NROW = P::NROW;
     constexpr int BUF = 4 * HVOLP;                      // packets per LDS buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem);

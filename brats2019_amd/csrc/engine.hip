@@ -928,3 +928,15 @@ extern "C" int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v
     RU_REQUIRE(w && g && m && v && vmax, "ru_adam_amsgrad_step: null argument");
     return adam_launch(w, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------- inference post-processing
+extern "C" int ru_tta_merge(const float* probs, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts,
+                            int C, int D, int H, int W, ru_stream_t stream) {
+    RU_REQUIRE(probs && mask && counts, "ru_tta_merge: null argument");
+    return tta_merge_launch(probs, K, flips, mean_out, mask, counts, C, D, H, W, (hipStream_t)stream);
+}
+extern "C" int ru_compose_labels(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels,
+                                 size_t V, ru_stream_t stream) {
+    RU_REQUIRE(mask && counts && labels, "ru_compose_labels: null argument");
+    return compose_labels_launch(mask, counts, et_min, labels, V, (hipStream_t)stream);
+}

@@ -114,13 +114,70 @@ __global__ __launch_bounds__(256) void conv1_kernel(const Conv1Args a) {
     }
 }
 
+// Deep levels (few voxels, hundreds of channels): the 1x1x1 conv is a GEMM  y[o][v] = sum_c wT[c][o] * x[c][v]  with
+// M = 16 output channels, N = 64 voxels (4 tiles) per wave and K = Cin walked 4 at a time on v_mfma_f32_16x16x4_f32
+// (exact f32, k-ordered like the scalar kernel).  Operands come straight from global / L2: A lane (o = l&15, k = l>>4),
+// B lane (v = l&15, k = l>>4); D lane holds 4 consecutive output channels of one voxel.
+typedef float f32x4_pw __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(const Conv1Args a, int nvt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.z;
+    const int o0 = blockIdx.y * 16;
+    const int vt = blockIdx.x * 4 + wave;                 // 64-voxel tile of this wave
+    if (vt >= nvt) return;
+    const size_t V = a.V;
+    const size_t v0 = (size_t)vt * 64;
+    const int r = lane & 15, k = lane >> 4;
+    const int Ct = a.C0 + a.C1;
+    const int oa = o0 + r < a.Cout ? o0 + r : a.Cout - 1;
+    size_t vb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const size_t v = v0 + 16 * t + r; vb[t] = v < V ? v : V - 1; }
+    f32x4_pw acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_pw{0.f, 0.f, 0.f, 0.f};
+    const float* x0 = a.x0 + (size_t)n * a.C0 * V;
+    const float* x1 = a.x1 ? a.x1 + (size_t)n * a.C1 * V : a.x0;
+#pragma unroll 4
+    for (int c0 = 0; c0 < Ct; c0 += 4) {
+        const int c = c0 + k;
+        const bool cok = c < Ct;
+        const int cc = cok ? c : Ct - 1;
+        const float av = cok ? a.wT[(size_t)cc * a.ldw + oa] : 0.f;
+        const float* xp = cc < a.C0 ? x0 + (size_t)cc * V : x1 + (size_t)(cc - a.C0) * V;
+        float bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t] = xp[vb[t]];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const size_t v = v0 + 16 * t + r;
+        if (v >= V) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = o0 + k * 4 + q;
+            if (o >= a.Cout) continue;
+            const size_t idx = ((size_t)n * a.Cout + o) * V + v;
+            float y = lrelu(acc[t][q], a.out_slope);
+            if (a.add) y += a.add[idx];
+            a.y[idx] = y;
+        }
+    }
+}
+
 int conv1_launch(const Conv1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cout, "conv1: bad shape");
     const bool vec = (a.V % 4) == 0;
     // few voxels x many channels (deep levels): one voxel and 4 outputs per thread, otherwise the launch is a handful of
     // workgroups each walking hundreds of input channels serially (latency-bound)
     const long wg_big = (long)((a.V / 4 + 255) / 256) * cdiv(a.Cout, 16) * a.N;
-    if (!vec || wg_big < 256) {
+    if (wg_big < 256 && a.C0 + a.C1 >= 32) {
+        const int nvt = (int)((a.V + 63) / 64);
+        dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(a.Cout, 16), (unsigned)a.N);
+        hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), 0, s, a, nvt);
+    } else if (!vec || wg_big < 256) {
         dim3 grid((unsigned)((a.V + 255) / 256), (unsigned)cdiv(a.Cout, 4), (unsigned)a.N);
         hipLaunchKernelGGL((conv1_kernel<1, 4>), grid, dim3(256), 0, s, a);
     } else {
@@ -786,6 +843,66 @@ int crit_grad_launch(const float* p, const float* g, const double* sums, double 
                      float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s) {
     hipLaunchKernelGGL(crit_grad_kernel, rows_grid(V, 1, N * C), dim3(256), 0, s, p, g, sums, count, w_dice, w_bce, bgw, priority, dp, C, V);
     RU_CHECK_LAUNCH("crit_grad_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ inference post-processing (test.py:134-159)
+// TTA merge: K predictions p[k] of flipped inputs (flip mask bit0 = D, bit1 = H, bit2 = W reversed) are un-flipped and
+// averaged in the reference's order ((p0 + p1) + p2 + ...) / K (float32, bit-exact vs numpy), thresholded at 0.5 and counted.
+__global__ __launch_bounds__(256) void tta_merge_kernel(const float* __restrict__ p, int K, unsigned flips, float* __restrict__ mean_out,
+                                                        unsigned char* __restrict__ mask_out, unsigned long long* __restrict__ counts,
+                                                        int C, int D, int H, int W) {
+    __shared__ unsigned int cnt[4];
+    const size_t V = (size_t)D * H * W;
+    const int c = blockIdx.y;
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int local = 0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+        const int x = (int)(v % W);
+        const int y = (int)((v / W) % H);
+        const int z = (int)(v / ((size_t)W * H));
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const unsigned f = (flips >> (3 * k)) & 7u;
+            const int zz = (f & 1u) ? D - 1 - z : z, yy = (f & 2u) ? H - 1 - y : y, xx = (f & 4u) ? W - 1 - x : x;
+            const float t = p[(((size_t)k * C + c) * D + zz) * H * W + (size_t)yy * W + xx];
+            acc = k == 0 ? t : acc + t;
+        }
+        const float m = acc / (float)K;
+        if (mean_out) mean_out[(size_t)c * V + v] = m;
+        const bool on = m > 0.5f;
+        mask_out[(size_t)c * V + v] = on ? 1 : 0;
+        local += on ? 1u : 0u;
+    }
+    atomicAdd(&cnt[threadIdx.x >> 6], local);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&counts[c], (unsigned long long)cnt[0] + cnt[1] + cnt[2] + cnt[3]);   // integer: order independent
+}
+// labels: 2 where WT, then 1 where TC, then 4 where ET if the ET count exceeds `et_min` (test.py:153-159)
+__global__ __launch_bounds__(256) void compose_labels_kernel(const unsigned char* __restrict__ mask, const unsigned long long* __restrict__ counts,
+                                                             unsigned long long et_min, unsigned char* __restrict__ labels, size_t V) {
+    const bool et_on = counts[2] > et_min;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+        unsigned char l = 0;
+        if (mask[v]) l = 2;
+        if (mask[V + v]) l = 1;
+        if (et_on && mask[2 * V + v]) l = 4;
+        labels[v] = l;
+    }
+}
+int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s) {
+    RU_REQUIRE(K >= 1 && K <= 8 && C >= 1, "tta_merge: 1..8 predictions");
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * C, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counts)");
+    const size_t V = (size_t)D * H * W;
+    hipLaunchKernelGGL(tta_merge_kernel, dim3(grid1d(V, 256, 4096), C), dim3(256), 0, s, p, K, flips, mean_out, mask, counts, C, D, H, W);
+    RU_CHECK_LAUNCH("tta_merge_kernel");
+    return RU_OK;
+}
+int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s) {
+    hipLaunchKernelGGL(compose_labels_kernel, dim3(grid1d(V, 256, 4096)), dim3(256), 0, s, mask, counts, et_min, labels, V);
+    RU_CHECK_LAUNCH("compose_labels_kernel");
     return RU_OK;
 }
 

@@ -154,6 +154,8 @@ int crit_tiles(size_t total);
 int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C, size_t V, float bgw, void* ws, size_t ws_bytes, hipStream_t s);
 int crit_grad_launch(const float* p, const float* g, const double* sums, double count, float w_dice, float w_bce,
                      float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s);
+int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s);
+int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s);
 int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float b1, float b2,
                 float eps, float wd, int step, hipStream_t s);
 

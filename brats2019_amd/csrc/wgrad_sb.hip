@@ -121,7 +121,7 @@ template <int TZ, int TY, int OT>
 __global__ __launch_bounds__(256, 2) void wgrad3_sb_kernel(const Wgrad3Args a, float* __restrict__ partials,
                                                           int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WSB<TZ, TY, OT>;
-    constexpr int HY = P::HY, XRP = P::XRP, DRP = P::DRP, XPLANE = P::XPLANE, DPLANE = P::DPLANE_P, NKB = P::NKB;
+    constexpr int HY = P::HY, XRP = P::XRP, DRP = P::DRP, XPLANE = P::XPLANE, DPLANE = P::DPLANE_P;
     constexpr int XROWS = P::XROWS, DROWS = P::DROWS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* xL = reinterpret_cast<u32x4*>(smem);                  // [hl][cb][c][XRP]

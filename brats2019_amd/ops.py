@@ -180,3 +180,31 @@ def adam_amsgrad_step(w, g, m, v, vmax, step, lr, betas=(0.9, 0.999), eps=1e-8, 
     """torch.optim.Adam(amsgrad=True) update on flat float32 buffers (main.py:133-137)."""
     L.check(L.load().ru_adam_amsgrad_step(L.f32(w), L.f32(g), L.f32(m), L.f32(v), L.f32(vmax), w.numel(), lr, betas[0], betas[1],
                                           eps, weight_decay, int(step), L.stream()), "ru_adam_amsgrad_step")
+
+
+TTA_FLIP_BITS = {1: 1, 2: 2, 3: 4}      # axis of a [C,D,H,W] array -> flip bit (D, H, W)
+
+
+def tta_merge(probs, flip_axes, want_mean=False):
+    """Un-flip + average K predictions of flipped copies (test.py:134-138), threshold at 0.5 (test.py:144).
+    probs: [K,C,D,H,W]; flip_axes: per copy the tuple of [C,D,H,W] axes that copy was flipped along.
+    Returns (mask uint8 [C,D,H,W], counts uint64-as-int64 [C], mean or None)."""
+    probs = _prep(probs)
+    k, c, d, h, w = [int(v) for v in probs.shape]
+    flips = 0
+    for i, axes in enumerate(flip_axes):
+        for ax in axes:
+            flips |= TTA_FLIP_BITS[ax] << (3 * i)
+    mask = torch.empty((c, d, h, w), dtype=torch.uint8, device=probs.device)
+    counts = torch.empty(c, dtype=torch.int64, device=probs.device)
+    mean = torch.empty((c, d, h, w), dtype=torch.float32, device=probs.device) if want_mean else None
+    L.check(L.load().ru_tta_merge(L.f32(probs), k, flips, L.ptr(mean, True), L.ptr(mask), L.ptr(counts), c, d, h, w, L.stream()), "ru_tta_merge")
+    return mask, counts, mean
+
+
+def compose_labels(mask, counts, et_min=32):
+    """test.py:153-159: labels {0,1,2,4} from the WT/TC/ET masks; ET only if more than `et_min` ET voxels."""
+    v = mask.numel() // int(mask.shape[0])
+    labels = torch.empty(tuple(mask.shape[1:]), dtype=torch.uint8, device=mask.device)
+    L.check(L.load().ru_compose_labels(L.ptr(mask), L.ptr(counts), int(et_min), L.ptr(labels), v, L.stream()), "ru_compose_labels")
+    return labels

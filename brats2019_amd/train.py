@@ -172,9 +172,11 @@ class Trainer(object):
             assert isinstance(batch[0], list)
             return self.model(self._to_device(batch[0]))
 
-    def predict_tiled(self, batch, output_shape, tile_shape=None, center_shape=None, border=None):
+    def predict_tiled(self, batch, output_shape, tile_shape=None, center_shape=None, border=None, batch_tiles=8):
         """train.py:145-176: per centre block, run the model on the zero-padded tile and paste the centre back.
-        The input volume is moved to the device once and every tile is cut there."""
+        The volume goes to the device once, tiles are cut there and `batch_tiles` of them share one forward (every op of
+        the network is per-sample, so batching tiles does not change a single value); the pasted result stays on the
+        device until the end (the reference does .cuda()/.cpu() per tile)."""
         tile_shape = tuple(tile_shape or self.tile_shape)
         center_shape = tuple(center_shape or self.center_shape)
         border = tuple(border or self.border)
@@ -185,14 +187,16 @@ class Trainer(object):
         self.model.eval()
         output = torch.zeros(output_shape, dtype=torch.float32, device=inp.device)
         grid = tiling.grid_for(inp.shape[2:], center_shape)
+        positions = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
+        nvol = int(inp.shape[0])
         with torch.no_grad():
-            for i in range(grid[0]):
-                for j in range(grid[1]):
-                    for k in range(grid[2]):
-                        lo, hi = tiling.get_indices((i, j, k), center_shape, border)
-                        tile = tiling.copy(inp, tile_shape, lo, hi)
-                        out = self.model([tile])[0]
-                        tiling.copy_back(output, out, center_shape, lo, hi, border)
+            for s0 in range(0, len(positions), max(1, int(batch_tiles))):
+                chunk = positions[s0:s0 + max(1, int(batch_tiles))]
+                idx = [tiling.get_indices(pos, center_shape, border) for pos in chunk]
+                tiles = torch.cat([tiling.copy(inp, tile_shape, lo, hi) for lo, hi in idx], dim=0)
+                out = self.model([tiles])[0]
+                for t, (lo, hi) in enumerate(idx):
+                    tiling.copy_back(output, out[t * nvol:(t + 1) * nvol], center_shape, lo, hi, border)
         return [output.cpu()]
 
     def _evaluate_and_save(self, loader, split_into_tiles, val_metrics, track_metric, results, epoch, comparator):

@@ -160,6 +160,18 @@ int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, floa
  * idx-th executed GroupNorm (execution order) into DEVICE buffers.  Returns number of GN layers if idx<0. */
 int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream);
 
+/* ---------------------------------------------------------------- inference post-processing (test.py:115-159)
+ * ru_tta_merge: `probs` holds K predictions [K][C][D][H][W] of flipped copies of one volume; bits 3k..3k+2 of `flips` say
+ * which axes (bit0 D, bit1 H, bit2 W) copy k was reversed along (test.py:117-120 uses {none, D, H, D+H}).  Each prediction
+ * is un-flipped (test.py:134-136) and they are averaged as sum(outputs)/K in list order (test.py:138, float32).  Outputs:
+ * mean_out [C][D][H][W] (may be NULL), mask [C][V] uint8 = mean > 0.5 (test.py:144), counts[C] = voxels set per channel.
+ * ru_compose_labels: labels[v] = 2 where mask[0], then 1 where mask[1], then 4 where mask[2] if counts[2] > et_min
+ * (test.py:153-159, et_min = 32).  counts is read on the device: no host synchronisation.  */
+int ru_tta_merge(const float* probs, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts,
+                 int C, int D, int H, int W, ru_stream_t stream);
+int ru_compose_labels(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels,
+                      size_t V, ru_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

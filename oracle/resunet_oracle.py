@@ -408,3 +408,102 @@ def tile_copy_back(data, tile, center_shape, index_min, index_max, border):
         src.append(slice(border[a], border[a] + (hi - lo)))
     data[(slice(None), slice(None)) + tuple(dst)] = tile[(slice(None), slice(None)) + tuple(src)]
     return data
+
+
+# --------------------------------------------------------------------------------------
+# inference driver around the forward pass (test.py:47-164) -- restated for the section 8(f) rank-1 row
+# --------------------------------------------------------------------------------------
+def closest_to_k(n, k=16):
+    """loader_helper.py:99-103: round n up to a multiple of k."""
+    return n if n % k == 0 else (n // k + 1) * k
+
+
+def bbox3(img):
+    """loader_helper.py:105-129: [[min],[max]] indices of the non-zero voxels per axis ([[-1,-1,-1],[0,0,0]] when empty)."""
+    nz = np.nonzero(np.asarray(img))
+    if nz[0].size == 0:
+        return np.array([[-1, -1, -1], [0, 0, 0]])
+    return np.array([[a.min() for a in nz], [a.max() for a in nz]])
+
+
+def get_bbox(data):
+    """test.py:47-49: union of the per-modality bounding boxes (max index is used as an EXCLUSIVE slice end at :87)."""
+    boxes = np.stack([bbox3(d) for d in data], axis=0)
+    return np.stack([boxes[:, 0].min(axis=0), boxes[:, 1].max(axis=0)], axis=0)
+
+
+def pad_to_multiple(image, k=16):
+    """test.py:92-99: symmetric zero padding of [C,D,H,W] to multiples of k; returns (padded, pad_left, pad_right)."""
+    old = np.array(image.shape[1:])
+    new = np.array([closest_to_k(int(i), k) for i in old])
+    diff = new - old
+    left = diff // 2
+    right = diff - left
+    padded = np.pad(image, ((0, 0),) + tuple((int(left[i]), int(right[i])) for i in range(3)), mode="constant", constant_values=0)
+    return padded, left, right
+
+
+def zscore_nonzero(x):
+    """test.py:103-113: per-channel mean/std over the voxels > 0 (moments accumulated as sum(x / n)), applied to ALL voxels."""
+    x = np.asarray(x)
+    n = (x > 0).sum(axis=(1, 2, 3))
+    mean = np.sum(x / n[:, None, None, None], axis=(1, 2, 3))
+    mean2 = np.sum(np.square(x) / n[:, None, None, None], axis=(1, 2, 3))
+    std = np.sqrt(mean2 - mean * mean)
+    return (x - mean.reshape(-1, 1, 1, 1)) / std.reshape(-1, 1, 1, 1)
+
+
+TTA_FLIPS = ((), (1,), (2,), (1, 2))      # test.py:117-120: axes of the [C,D,H,W] array that are reversed
+
+
+def tta_inputs(x):
+    """test.py:115-120: the four flipped copies of a [C,D,H,W] volume."""
+    return [np.ascontiguousarray(np.flip(x, axis=ax)) if ax else x for ax in TTA_FLIPS]
+
+
+def tta_merge(outputs):
+    """test.py:134-138: un-flip each prediction and average: sum(outputs) / len(outputs) (left-to-right float32 sum)."""
+    un = [np.flip(o, axis=ax) if ax else o for o, ax in zip(outputs, TTA_FLIPS)]
+    acc = un[0]
+    for o in un[1:]:
+        acc = acc + o
+    return acc / len(un)
+
+
+def compose_labels(prob):
+    """test.py:144-159: threshold 0.5; label 2 = WT, overwritten by 1 = TC, overwritten by 4 = ET if more than 32 ET voxels."""
+    m = np.asarray(prob) > 0.5
+    wt, tc, et = m[0], m[1], m[2]
+    out = np.zeros(wt.shape, np.uint8)
+    out[wt] = 2
+    out[tc] = 1
+    if et.sum() > 32:
+        out[et] = 4
+    return out, (int(wt.sum()), int(tc.sum()), int(et.sum()))
+
+
+def reject_small_regions(connectivity, ratio=0.25):
+    """test.py:51-62: zero every connected region (label of `connectivity`, background included) whose voxel count is below
+    ratio * (all voxels - voxels of the most frequent label)."""
+    out = connectivity.copy()
+    unique, counts = np.unique(connectivity, return_counts=True)
+    nonzero = connectivity.size - counts.max()
+    for u, c in zip(unique, counts):
+        if c < ratio * nonzero:
+            out[out == u] = 0
+    return out
+
+
+def label_components(mask):
+    """skimage.morphology.label default (test.py:162): full connectivity (26-neighbourhood in 3-D); here scipy.ndimage."""
+    import scipy.ndimage as ndi
+    lab, _ = ndi.label(mask, structure=np.ones((3, 3, 3), dtype=bool))
+    return lab
+
+
+def postprocess(prob):
+    """test.py:144-164 on the un-padded probability volume [3,D,H,W] -> uint8 labels."""
+    labels, vols = compose_labels(prob)
+    clusters = reject_small_regions(label_components(labels > 0), 0.1)
+    labels[clusters == 0] = 0
+    return labels, vols

@@ -30,7 +30,7 @@ sys.path.insert(0, REF)
 
 from oracle import resunet_oracle as O  # noqa: E402  (inputs/weights only: data, not algorithm)
 
-for _name in ("nibabel", "SimpleITK", "tensorboardX"):
+for _name in ("nibabel", "SimpleITK", "tensorboardX", "skimage", "skimage.morphology", "skimage.filters", "skimage.measure"):
     if _name not in sys.modules:
         try:
             __import__(_name)
@@ -38,6 +38,10 @@ for _name in ("nibabel", "SimpleITK", "tensorboardX"):
             _m = types.ModuleType(_name)
             if _name == "tensorboardX":
                 _m.SummaryWriter = object
+            if _name == "skimage":
+                _m.__path__ = []                     # lets `from skimage.filters import ...` resolve the blank sub-modules
+            if _name == "skimage.filters":
+                _m.threshold_otsu = None
             sys.modules[_name] = _m
 
 with contextlib.redirect_stdout(io.StringIO()):
@@ -349,6 +353,39 @@ def gen_tiling():
     save("tiling.npz", **out)
 
 
+# ------------------------------------------------------------------ inference helpers of test.py / loader_helper.py
+def gen_inference():
+    import importlib.util
+    sys.modules["skimage"].morphology = sys.modules["skimage.morphology"]
+    spec = importlib.util.spec_from_file_location("ref_test_script", os.path.join(REF, "test.py"))   # __main__ guard: nothing runs
+    ref_test = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(ref_test)
+    out = {}
+    r = rng(29)
+    img = np.zeros((4, 20, 22, 18), np.float32)
+    img[:, 3:15, 5:19, 2:11] = r.random((4, 12, 14, 9)).astype(np.float32) + 0.1
+    img[1, 2, 5, 2] = 0.7                         # modality-specific extent
+    out["img"] = img
+    out["bbox"] = ref_test.get_bbox(img)
+    out["bbox3_0"] = ref_lh.bbox3(img[0])
+    out["bbox3_empty"] = ref_lh.bbox3(np.zeros((3, 3, 3)))
+    out["closest16"] = np.asarray([ref_lh.closest_to_k(i, 16) for i in range(1, 50)])
+    lab = np.zeros((12, 12, 12), np.int64)
+    lab[1:6, 1:6, 1:6] = 1
+    lab[8:10, 8:10, 8:10] = 2
+    lab[11, 11, 11] = 3
+    lab[0, 11, 0] = 4
+    out["cc_in"] = lab
+    out["cc_out_010"] = ref_test.reject_small_regions(lab, 0.1)
+    out["cc_out_025"] = ref_test.reject_small_regions(lab)
+    lab2 = lab.copy()
+    lab2[:] = 5                                   # no background at all: the most frequent label plays the background role
+    lab2[0, 0, :3] = 0
+    out["cc2_in"], out["cc2_out"] = lab2, ref_test.reject_small_regions(lab2, 0.1)
+    save("inference.npz", **out)
+
+
 # ------------------------------------------------------------------ (8) checkpoint in Trainer._save layout
 def gen_checkpoint():
     import tempfile
@@ -402,3 +439,5 @@ if __name__ == "__main__":
         gen_tiling()
     if want("ckpt"):
         gen_checkpoint()
+    if want("inference"):
+        gen_inference()

@@ -1,0 +1,126 @@
+"""Inference driver (test.py:47-164).  CPU: the oracle restatement vs outputs of the reference's own
+helper functions (tests/golden/inference.npz) and the host mirror vs the oracle.  GPU: the TTA-merge / label kernels and
+the whole per-case pipeline vs the oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import resunet_oracle as O
+
+T = torch.from_numpy
+SMALL = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[8, 16, 32], number_of_outputs=3)
+
+
+def test_oracle_helpers_match_reference(golden):
+    g = golden("inference")
+    assert np.array_equal(O.get_bbox(g["img"]), g["bbox"])
+    assert np.array_equal(O.bbox3(g["img"][0]), g["bbox3_0"]) and np.array_equal(O.bbox3(np.zeros((3, 3, 3))), g["bbox3_empty"])
+    assert [O.closest_to_k(i, 16) for i in range(1, 50)] == g["closest16"].tolist()
+    assert np.array_equal(O.reject_small_regions(g["cc_in"], 0.1), g["cc_out_010"])
+    assert np.array_equal(O.reject_small_regions(g["cc_in"]), g["cc_out_025"])
+    assert np.array_equal(O.reject_small_regions(g["cc2_in"], 0.1), g["cc2_out"])
+
+
+def test_host_mirror_matches_oracle(golden):
+    from brats2019_amd import inference as I
+    g = golden("inference")
+    img = g["img"]
+    assert np.array_equal(I.get_bbox(img), O.get_bbox(img))
+    x, bbox, left, right = I.prepare_case(img)
+    crop = img[:, bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]]
+    padded, l2, r2 = O.pad_to_multiple(crop, 16)
+    assert np.array_equal(left, l2) and np.array_equal(right, r2)
+    np.testing.assert_allclose(x, O.zscore_nonzero(padded).astype(np.float32), rtol=0, atol=0)
+    assert all(s % 16 == 0 for s in x.shape[1:])
+    assert np.array_equal(I.reject_small_regions(g["cc_in"], 0.1), g["cc_out_010"])
+    rng = np.random.default_rng(3)
+    lab = (rng.random((10, 12, 9)) > 0.6).astype(np.uint8) * 2
+    ref, _ = None, None
+    prob = np.stack([lab > 0, np.zeros_like(lab, bool), np.zeros_like(lab, bool)]).astype(np.float32)
+    want, _ = O.postprocess(prob)
+    assert np.array_equal(I.postprocess_labels(lab), want)
+
+
+@pytest.mark.gpu
+def test_tta_merge_and_labels_bit_exact_vs_oracle():
+    from brats2019_amd import ops
+    rng = np.random.default_rng(11)
+    for shape, et_scale in (((3, 8, 12, 16), 1.0), ((3, 5, 6, 7), 0.02)):       # second case: fewer than 33 ET voxels
+        outs = [rng.random(shape).astype(np.float32) for _ in range(4)]
+        outs = [o * np.array([1, 1, et_scale], np.float32).reshape(3, 1, 1, 1) + (0.45 if et_scale == 1.0 else 0.0) * (1 if i else 1) for i, o in enumerate(outs)]
+        outs = [np.clip(o, 0, 1).astype(np.float32) for o in outs]
+        mean_ref = O.tta_merge(outs)
+        labels_ref, vols = O.compose_labels(mean_ref)
+        probs = torch.stack([T(o) for o in outs]).cuda()
+        mask, counts, mean = ops.tta_merge(probs, O.TTA_FLIPS, want_mean=True)
+        assert np.array_equal(mean.cpu().numpy(), mean_ref.astype(np.float32))       # same float32 summation order
+        assert np.array_equal(mask.cpu().numpy().astype(bool), mean_ref > 0.5)
+        assert tuple(counts.cpu().tolist()) == vols
+        labels = ops.compose_labels(mask, counts, et_min=32)
+        assert np.array_equal(labels.cpu().numpy(), labels_ref)
+        if et_scale != 1.0:
+            assert vols[2] <= 32 and not (labels_ref == 4).any()
+
+
+@pytest.mark.gpu
+def test_predict_case_matches_oracle_pipeline():
+    """whole per-case pipeline: crop, pad, z-score, 4-flip TTA through the HIP network, merge, labels, component rejection."""
+    from brats2019_amd import model as M, inference as I
+    seed = 17
+    rng = np.random.default_rng(seed)
+    img = np.zeros((4, 40, 44, 36), np.float32)
+    img[:, 4:33, 6:39, 3:30] = rng.random((4, 29, 33, 27)).astype(np.float32) * 3 + 0.05
+    params = O.make_params(seed, **SMALL)
+    net = M.UNet(**SMALL)
+    net.load_state_dict({k: T(v) for k, v in params.items()})
+    net.cuda()
+    got, vols = I.predict_case(net, img)
+    # oracle pipeline
+    bbox = O.get_bbox(img)
+    crop = img[:, bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]]
+    padded, left, right = O.pad_to_multiple(crop, 16)
+    x = O.zscore_nonzero(padded).astype(np.float32)
+    p = O.to_torch(params)
+    outs = []
+    with torch.no_grad():
+        for xi in O.tta_inputs(x):
+            outs.append(O.unet_forward(p, T(np.ascontiguousarray(xi))[None], **SMALL)[0].numpy())
+    mean = O.tta_merge(outs)
+    d, h, w = mean.shape[1:]
+    mean = mean[:, left[0]:d - right[0], left[1]:h - right[1], left[2]:w - right[2]]
+    # compare the label volumes (a label may only flip where the oracle probability sits on the threshold)
+    want, want_vols = O.postprocess(mean)
+    assert max(abs(a - b) for a, b in zip(vols, want_vols)) <= 3
+    full = np.zeros(img.shape[1:], np.uint8)
+    full[bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]] = want
+    diff = got != full
+    assert diff.mean() < 1e-3, "labels differ on %d voxels" % diff.sum()
+    assert set(np.unique(got).tolist()) <= {0, 1, 2, 4}
+
+
+@pytest.mark.gpu
+def test_predict_tiled_batched_matches_oracle_tiling(tmp_path):
+    """BASELINE config 5 at test size: overlapping tiles (centre 8, border 4, tile 16) over a ragged 40x24x20 volume, several
+    tiles per forward; the oracle runs the same tiling one tile at a time (train.py:158-174 semantics)."""
+    from brats2019_amd import model as M, train as TR
+    seed = 31
+    params = O.make_params(seed, **SMALL)
+    net = M.UNet(**SMALL)
+    net.load_state_dict({k: T(v) for k, v in params.items()})
+    rng = np.random.default_rng(seed)
+    vol = rng.standard_normal((1, 4, 40, 24, 20)).astype(np.float32)
+    tile, centre, border = (16, 16, 16), (8, 8, 8), (4, 4, 4)
+    tr = TR.Trainer(name="t", models_root=str(tmp_path), model=net, rewrite=True, connect_tb=False)
+    got = tr.predict_tiled([[T(vol)]], (1, 3, 40, 24, 20), tile, centre, border, batch_tiles=5)[0].numpy()
+    p = O.to_torch(params)
+    want = np.zeros((1, 3, 40, 24, 20), np.float32)
+    grid = [int(np.ceil(s / c)) for s, c in zip(vol.shape[2:], centre)]
+    with torch.no_grad():
+        for i in range(grid[0]):
+            for j in range(grid[1]):
+                for k in range(grid[2]):
+                    lo, hi = O.tile_indices((i, j, k), centre, border)
+                    t_in = O.tile_copy(vol, tile, lo, hi)
+                    t_out = O.unet_forward(p, T(t_in), **SMALL).numpy()
+                    O.tile_copy_back(want, t_out, centre, lo, hi, border)
+    assert np.abs(got - want).max() <= 2e-5
