@@ -321,12 +321,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const bool ok = has_e && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                 ge = ok ? (gz * H + gy) * W + gx : -1;
             }
+            // ablation (dbg 16 / 32): every lane reads element 0 of the channel -> same instruction stream, one cache line
+            const int ge_eff = (dbg & 16) ? 0 : (ge > 0 ? ge : 0), gi_eff = (dbg & 32) ? 0 : (gi > 0 ? gi : 0);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int cc = chunk * 16 + c;
                 const float* xp = a.x + ((size_t)n_cur * a.Cin + (cc < a.Cin ? cc : a.Cin - 1)) * DHW;   // unconditional, clamped
-                vi[c] = *reinterpret_cast<const float4*>(xp + (gi > 0 ? gi : 0));
-                ve[c] = xp[ge > 0 ? ge : 0];
+                vi[c] = *reinterpret_cast<const float4*>(xp + gi_eff);
+                ve[c] = xp[ge_eff];
             }
         };
         auto store = [&](int item, u32x4* buf) {              // consume the in-flight loads: transform, split, transpose
