@@ -124,3 +124,45 @@ def test_predict_tiled_batched_matches_oracle_tiling(tmp_path):
                     t_out = O.unet_forward(p, T(t_in), **SMALL).numpy()
                     O.tile_copy_back(want, t_out, centre, lo, hi, border)
     assert np.abs(got - want).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_entry_point_loads_reference_checkpoint_and_segments(tmp_path):
+    """BASELINE config 1 plumbing: `test.py --name --models_path` contract on a checkpoint written by the REFERENCE's
+    Trainer._save (tests/golden/ckpt/tiny), one synthetic 4-modality case in, uint8 labels {0,1,2,4} out."""
+    import os, shutil, sys
+    from brats2019_amd import test as entry, inference as I, model as M
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "tests", "golden", "ckpt", "tiny"), tmp_path / "tiny")
+    rng = np.random.default_rng(5)
+    img = np.zeros((4, 30, 28, 26), np.float32)
+    img[:, 2:27, 3:25, 1:24] = rng.random((4, 25, 22, 23)).astype(np.float32) * 2 + 0.1
+    np.save(tmp_path / "case.npy", img)
+    saved = {k: sys.modules.get(k) for k in ("model", "train", "loss")}
+    try:
+        entry.main(["--name", "tiny", "--models_path", str(tmp_path), "--input", str(tmp_path / "case.npy"),
+                    "--output", str(tmp_path / "seg.npy"), "--precision", "f32"])
+    finally:
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+    seg = np.load(tmp_path / "seg.npy")
+    assert seg.shape == img.shape[1:] and seg.dtype == np.uint8 and set(np.unique(seg).tolist()) <= {0, 1, 2, 4}
+    # same weights through the oracle pipeline
+    cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
+    params = O.make_params(23, **cfg)
+    bbox = O.get_bbox(img)
+    crop = img[:, bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]]
+    padded, left, right = O.pad_to_multiple(crop, 16)
+    x = O.zscore_nonzero(padded).astype(np.float32)
+    p = O.to_torch(params)
+    with torch.no_grad():
+        outs = [O.unet_forward(p, T(np.ascontiguousarray(xi))[None], **cfg)[0].numpy() for xi in O.tta_inputs(x)]
+    mean = O.tta_merge(outs)
+    d, h, w = mean.shape[1:]
+    want, _ = O.postprocess(mean[:, left[0]:d - right[0], left[1]:h - right[1], left[2]:w - right[2]])
+    full = np.zeros(img.shape[1:], np.uint8)
+    full[bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]] = want
+    assert (seg != full).mean() < 1e-3
