@@ -196,13 +196,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl == RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--shared-gpu", action="store_true", help="plumbing test: let every rank use cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
     from brats2019_amd import parallel as P
-    rank, local, world = P.init_process_group_from_env("nccl")
+    if args.shared_gpu:
+        os.environ["LOCAL_RANK_ORIG"] = os.environ.get("LOCAL_RANK", "0")
+    rank, local, world = P.init_process_group_from_env(args.dist_backend)
     distributed = world > 1
     if world != max(args.gpus, 1):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if args.shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

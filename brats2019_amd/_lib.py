@@ -59,6 +59,7 @@ SIGNATURES = {
     "ru_unet_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
+    "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),
 }
 
 

@@ -8,7 +8,7 @@ import sys
 
 
 def install_aliases(force=False):
-    from . import loss, model, train
-    for name, mod in (("model", model), ("train", train), ("loss", loss)):
+    from . import loss, metrics, model, train
+    for name, mod in (("model", model), ("train", train), ("loss", loss), ("metrics", metrics)):
         if force or name not in sys.modules:
             sys.modules[name] = mod

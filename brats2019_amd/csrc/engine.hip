@@ -940,3 +940,8 @@ extern "C" int ru_compose_labels(const unsigned char* mask, const unsigned long 
     RU_REQUIRE(mask && counts && labels, "ru_compose_labels: null argument");
     return compose_labels_launch(mask, counts, et_min, labels, V, (hipStream_t)stream);
 }
+
+extern "C" int ru_dice_counts(const float* p, const float* g, unsigned long long* counts, int N, int C, size_t V, ru_stream_t stream) {
+    RU_REQUIRE(p && g && counts && N > 0 && C > 0, "ru_dice_counts: bad argument");
+    return dice_counts_launch(p, g, counts, N * C, V, (hipStream_t)stream);
+}

@@ -906,6 +906,32 @@ int compose_labels_launch(const unsigned char* mask, const unsigned long long* c
     return RU_OK;
 }
 
+// ------------------------------------------------------------------ evaluation metric (metrics.py:108-133)
+// per (sample, channel): counts[row] = { sum(p>0.5 & g>0.5), sum(p>0.5) + sum(g>0.5) } as integers (order independent)
+__global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                          unsigned long long* __restrict__ counts, size_t V) {
+    const size_t row = blockIdx.y;
+    unsigned int inter = 0, uni = 0;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+        const bool a = p[row * V + v] > 0.5f, b = g[row * V + v] > 0.5f;
+        inter += (a && b) ? 1u : 0u;
+        uni += (a ? 1u : 0u) + (b ? 1u : 0u);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { inter += __shfl_xor(inter, o); uni += __shfl_xor(uni, o); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[row * 2], (unsigned long long)inter);
+        atomicAdd(&counts[row * 2 + 1], (unsigned long long)uni);
+    }
+}
+int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * rows, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dice counts)");
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(grid1d(V, 256 * 8, 1024), rows), dim3(256), 0, s, p, g, counts, V);
+    RU_CHECK_LAUNCH("dice_counts_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ Adam(amsgrad=True, weight_decay) (main.py:133-137)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, size_t n, float step_size, float b1, float b2, float eps, float wd,

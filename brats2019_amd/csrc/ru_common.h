@@ -156,6 +156,7 @@ int crit_grad_launch(const float* p, const float* g, const double* sums, double 
                      float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s);
 int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s);
 int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s);
+int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s);
 int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float b1, float b2,
                 float eps, float wd, int step, hipStream_t s);
 

@@ -208,3 +208,14 @@ def compose_labels(mask, counts, et_min=32):
     labels = torch.empty(tuple(mask.shape[1:]), dtype=torch.uint8, device=mask.device)
     L.check(L.load().ru_compose_labels(L.ptr(mask), L.ptr(counts), int(et_min), L.ptr(labels), v, L.stream()), "ru_compose_labels")
     return labels
+
+
+def dice_counts(pred, target):
+    """metrics.Dice.update counting step (metrics.py:116-127): int64 device tensor [N,C,2] = (#(p>.5 & g>.5), #(p>.5) + #(g>.5))."""
+    pred, target = _prep(pred), _prep(target)
+    assert pred.shape == target.shape                                  # metrics.py:112
+    n, c = int(pred.shape[0]), int(pred.shape[1])
+    v = pred.numel() // (n * c)
+    counts = torch.empty((n, c, 2), dtype=torch.int64, device=pred.device)
+    L.check(L.load().ru_dice_counts(L.f32(pred), L.f32(target), L.ptr(counts), n, c, v, L.stream()), "ru_dice_counts")
+    return counts

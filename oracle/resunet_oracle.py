@@ -370,10 +370,10 @@ def dice_metric(pred, gt):
     p = (np.asarray(pred) > 0.5).astype(np.float64)
     g = (np.asarray(gt) > 0.5).astype(np.float64)
     red = tuple(range(2, p.ndim))
-    num = 2.0 * (p * g).sum(red)
-    den = (p + g).sum(red)
+    num = (p * g).sum(red).astype(np.float32)          # the reference's sums are float32 tensors (exact: counts < 2^24)
+    den = (p + g).sum(red).astype(np.float32)
     with np.errstate(invalid="ignore", divide="ignore"):
-        d = num / den
+        d = (2 * num / den).astype(np.float64)          # float32 division (metrics.py:126), stored into a float64 array
     d[np.isnan(d)] = 1.0
     return d.mean(axis=0)
 

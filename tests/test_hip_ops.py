@@ -266,3 +266,18 @@ def test_conv3_bf16x3_ragged_w_falls_back_to_f32(ops):
     x = rng.standard_normal((1, 16, 4, 6, 18)).astype(np.float32)        # W % 4 != 0
     wt = (rng.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(432)).astype(np.float32)
     close(ops.conv3d(dev(x), dev(wt), precision="bf16x3"), O.conv3x3x3(T(x), T(wt)), name="fallback")
+
+
+def test_dice_metric_matches_reference(golden):
+    """metrics.Dice (metrics.py:101-133) vs the value the reference's own class produced (tests/golden/loss.npz)."""
+    from brats2019_amd import metrics as MT
+    g = golden("loss")
+    m = MT.Dice(classes=4)
+    m.update([dev(g["g"])], [dev(g["p"])])
+    np.testing.assert_array_equal(m.get(), g["metric_dice"])
+    m.update([dev(g["g"])], [dev(g["g"])])                 # perfect prediction -> 1 in every class; mean of the two updates
+    np.testing.assert_allclose(m.get(), (g["metric_dice"] + 1.0) / 2, rtol=0, atol=1e-12)
+    empty = torch.zeros(1, 3, 4, 4, 4).cuda()
+    m.reset()
+    m.update([empty], [empty])                              # 0/0 -> NaN -> 1 (metrics.py:128)
+    assert np.array_equal(m.get(), np.ones(3))
