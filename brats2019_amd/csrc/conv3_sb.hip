@@ -19,6 +19,7 @@
 //   C/D: lane holds 4 consecutive x voxels of output channel l&15 -> shared epilogue (conv3_epilogue.hpp).
 #include "conv3_epilogue.hpp"
 #include <stdlib.h>
+#include <utility>
 
 namespace ru {
 
@@ -60,7 +61,103 @@ __device__ __forceinline__ void split8(const float (&t)[8], u32x4& hi, u32x4& lo
     }
 }
 
-template <int TZ, int TY>
+// Epilogue of ONE M-tile (output row yy of plane zz), issued as soon as the tile's last MFMA is queued so the stores
+// trickle out under the next tiles' matrix work instead of in one burst per item (a burst of 32 KB per CU from every CU
+// at once is HBM-write bound and used to block the wave at store issue).
+//   NCDHW output (OUT16 = false): lane = (cout co0 + (l&15), 4 consecutive x at x0 + 4*(l>>4)); NS = 1 statistics pair
+//   C16 output   (OUT16 = true) : the MFMA ran with swapped operands, D[m = cout][n = voxel]: lane = (voxel x0 + (l&15),
+//                                 4 consecutive couts co0 + 4*(l>>4)): one aligned float4 of the voxel-major tensor; NS = 4
+struct SbOut {
+    size_t plane;        // OUT16: ((n*CB + cog)*D + zz)*H ; NCDHW: ((n*Cout + co)*D + zz)*H*W
+    int xx;              // first x of this lane
+    int cq;              // OUT16: channel quad offset inside the voxel
+    bool ok;             // lane-level validity (z, x, cout)
+    float4 bias;
+};
+template <bool OUT16>
+__device__ __forceinline__ SbOut sb_out_prepare(const Conv3Args& a, int n, int zz, int x0, int cog, int lane) {
+    SbOut o;
+    const int D = a.D, H = a.H, W = a.W;
+    const int zc = zz < D ? zz : 0;
+    if constexpr (OUT16) {
+        o.xx = x0 + (lane & 15);
+        o.cq = 4 * (lane >> 4);
+        o.plane = ((size_t)(n * (a.Cout >> 4) + cog) * D + zc) * H;
+        o.ok = zz < D && o.xx < W;
+        o.bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + cog * 16 + o.cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const int co = cog * 16 + (lane & 15);
+        o.xx = x0 + (lane >> 4) * 4;
+        o.cq = 0;
+        const int cc = co < a.Cout ? co : 0;
+        o.plane = (((size_t)n * a.Cout + cc) * D + zc) * (size_t)H * W;
+        o.ok = zz < D && co < a.Cout && o.xx < W;            // W % 4 == 0: the 4 voxels are in or out together
+        const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        o.bias = make_float4(b, b, b, b);
+    }
+    return o;
+}
+template <bool OUT16>
+__device__ __forceinline__ size_t sb_out_index(const Conv3Args& a, const SbOut& o, int yy) {
+    if constexpr (OUT16) return ((o.plane + yy) * a.W + o.xx) * 16 + o.cq;
+    else return o.plane + (size_t)yy * a.W + o.xx;
+}
+template <bool OUT16, int NS>
+__device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, float (&s1)[NS], float (&s2)[NS]) {
+    if (!(o.ok && yy < a.H)) return;
+    v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w;
+    if (a.add) { v[0] += radd.x; v[1] += radd.y; v[2] += radd.z; v[3] += radd.w; }
+    if constexpr (OUT16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+    } else {
+        s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
+        s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    if (a.sigmoid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + expf(-v[r]));
+    }
+    *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// per-wave statistics partial of one tile: [N][Cout][nblk][2] at block tile_in_sample*4 + wave
+template <bool OUT16, int NS>
+__device__ __forceinline__ void sb_out_stats(const Conv3Args& a, float (&s1)[NS], float (&s2)[NS], int n, int cog, int blk, int nblk, int lane) {
+    if (!a.stat_partials) return;
+    if constexpr (OUT16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o); s2[r] += __shfl_xor(s2[r], o); }
+        }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* p = a.stat_partials + (((size_t)n * a.Cout + cog * 16 + 4 * (lane >> 4) + r) * nblk + blk) * 2;
+                p[0] = s1[r]; p[1] = s2[r];
+            }
+        }
+    } else {
+        const int co = cog * 16 + (lane & 15);
+        s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16);
+        s1[0] += __shfl_xor(s1[0], 32); s2[0] += __shfl_xor(s2[0], 32);
+        if (lane < 16 && co < a.Cout) {
+            float* p = a.stat_partials + (((size_t)n * a.Cout + co) * nblk + blk) * 2;
+            p[0] = s1[0]; p[1] = s2[0];
+        }
+    }
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {           // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int TZ, int TY, bool IN16, bool OUT16>
 __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk) {
     using P = SB<TZ, TY>;
     constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NSV = P::NSV, NROW = P::NROW;
@@ -69,28 +166,17 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tiles_per_sample = ntz * nty * ntx;
+    const int n = b / tiles_per_sample;
+    const int tis = b - n * tiles_per_sample;
+    b = tis;
     const int tx = b % ntx; b /= ntx;
-    const int ty = b % nty; b /= nty;
-    const int tz = b % ntz;
-    const int n = b / ntz;
+    const int ty = b % nty;
+    const int tz = b / nty;
     const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;
-    const int cog = blockIdx.y, co0 = cog * 16;
+    const int cog = blockIdx.y;
     const int D = a.D, H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
-
-    // staging slots (W % 4 == 0): halo row [x0-1, x0+17) = six aligned 16-byte segments [x0-4+4q, +4); slot = (row, q)
-    int gv[NSV], lp[NSV];
-#pragma unroll
-    for (int j = 0; j < NSV; ++j) {
-        const int item = tid + j * 256;
-        const int row = item / 6, q = item - row * 6;
-        const int hz = row / HY, hy = row - hz * HY;
-        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
-        const bool slot = item < NROW * 6;
-        const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
-        gv[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
-        lp[j] = row * HX + 4 * q - 3;           // packet index of element 0 (elements outside [0,18) of the row are skipped)
-    }
 
     // A-fragment packet offsets per K-step (hi plane; lo plane = + 2*HVOLP)
     const int mz = (wave * MT) / TY, my0 = (wave * MT) % TY;
@@ -104,11 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
         aoff[ks] = (kg & 1) * HVOLP + ((mz + dz) * HY + my0 + dy) * HX + dx + (lane & 15);
     }
 
-    f32x4 acc[MT][1];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool xform = a.in_scale != nullptr;
     const float slope = xform ? a.in_slope : 1.f;    // neutral constants make the fused transform branch-free
+    auto mm = [](const bf16x8& av, const bf16x8& wv, const f32x4& c) -> f32x4 {
+        if constexpr (OUT16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, c, 0, 0, 0);     // D[m = cout][n = voxel]
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
+    };
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk) __syncthreads();
@@ -122,49 +212,107 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                 wreg[ks][1] = wp[(ks * 2 + 1) * 64];
             }
         }
-        // ---- stage 16 channels: per slot and channel-half, 8 float4 loads (8 channels x 4 voxels) in flight, then
-        //      transform + split + transpose into 4 hi and 4 lo packets
+        if constexpr (IN16) {
+            // ---- C16 input: (halo position, channel half) per thread and round; two aligned float4 per voxel half
+            constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
+            const int hsel = (tid >> 3) & 1;
+            const int pslot = (tid >> 4) * 8 + (tid & 7);
+            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + hsel * 8;
+            float4 v16[NR][2];
+            unsigned vmask = 0;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int cb = chunk * 16 + half * 8;
-            float sc[8], sh[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                sc[c] = 1.f; sh[c] = 0.f;
-                if (xform && cb + c < a.Cin) { sc[c] = a.in_scale[n * a.Cin + cb + c]; sh[c] = a.in_shift[n * a.Cin + cb + c]; }
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 128 + pslot;
+                const int row = p / HX, xc = p - row * HX;
+                const int hz = row / HY, hy = row - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
+                const bool ok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+                vmask |= ok ? (1u << r) : 0u;
+                v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
+                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
             }
-            float4 v[NSV][8];
+            float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (xform) {
+                const int cofs = n * a.Cin + chunk * 16 + hsel * 8;
 #pragma unroll
-            for (int j = 0; j < NSV; ++j) {
+                for (int c = 0; c < 8; ++c) { sc[c] = a.in_scale[cofs + c]; sh[c] = a.in_shift[cofs + c]; }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 128 + pslot;
+                if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
+                const bool ok = (vmask >> r) & 1u;
+                const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
+                float t[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    // UNCONDITIONAL load from a clamped (always valid) address; zeroed by select below.  A conditional load
-                    // makes hipcc branch around it and wait vmcnt(0) per load: one load in flight per thread.
-                    const int cg = cb + c < a.Cin ? cb + c : a.Cin - 1;
-                    v[j][c] = *reinterpret_cast<const float4*>(a.x + ((size_t)n * a.Cin + cg) * DHW + (gv[j] > 0 ? gv[j] : 0));
+                    const float u = fmaf(f[c], sc[c], sh[c]);
+                    t[c] = ok ? fmaxf(u, u * slope) : 0.f;          // zero padding applies to the ACTIVATED tensor
                 }
+                u32x4 hi, lo;
+                split8(t, hi, lo);
+                lds[hsel * HVOLP + p] = hi;
+                lds[(2 + hsel) * HVOLP + p] = lo;
             }
+        } else {
+            // ---- NCDHW input (W % 4 == 0): halo row [x0-1, x0+17) = six aligned 16-byte segments [x0-4+4q, +4); slot = (row, q).
+            //      Per slot and channel-half, 8 float4 loads (8 channels x 4 voxels) in flight, then transform + split + transpose
+            //      into 4 hi and 4 lo packets
+            int gv[NSV], lp[NSV];
 #pragma unroll
             for (int j = 0; j < NSV; ++j) {
-                if (gv[j] == -2) continue;
-                const bool inb = gv[j] >= 0;
-                const int q = (tid + j * 256) % 6;
-                const int e0 = q == 0 ? 3 : 0, e1 = q == 5 ? 1 : 4;        // elements of this segment inside the halo row
+                const int item = tid + j * 256;
+                const int row = item / 6, q = item - row * 6;
+                const int hz = row / HY, hy = row - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q;
+                const bool slot = item < NROW * 6;
+                const bool ok = slot && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+                gv[j] = !slot ? -2 : (ok ? (gz * H + gy) * W + gx : -1);
+                lp[j] = row * HX + 4 * q - 3;           // packet index of element 0 (elements outside [0,18) of the row are skipped)
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (e < e0 || e >= e1) continue;
-                    float t[8];
+            for (int half = 0; half < 2; ++half) {
+                const int cb = chunk * 16 + half * 8;
+                float sc[8], sh[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    sc[c] = 1.f; sh[c] = 0.f;
+                    if (xform && cb + c < a.Cin) { sc[c] = a.in_scale[n * a.Cin + cb + c]; sh[c] = a.in_shift[n * a.Cin + cb + c]; }
+                }
+                float4 v[NSV][8];
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        float u = e == 0 ? v[j][c].x : (e == 1 ? v[j][c].y : (e == 2 ? v[j][c].z : v[j][c].w));
-                        u = fmaf(u, sc[c], sh[c]);                          // branch-free: (1, 0, slope 1) when no transform
-                        u = fmaxf(u, u * slope);                            // LeakyReLU for 0 < slope <= 1
-                        t[c] = (inb && cb + c < a.Cin) ? u : 0.f;          // zero padding applies to the ACTIVATED tensor
+                        // UNCONDITIONAL load from a clamped (always valid) address; zeroed by select below.  A conditional load
+                        // makes hipcc branch around it and wait vmcnt(0) per load: one load in flight per thread.
+                        const int cg = cb + c < a.Cin ? cb + c : a.Cin - 1;
+                        v[j][c] = *reinterpret_cast<const float4*>(a.x + ((size_t)n * a.Cin + cg) * DHW + (gv[j] > 0 ? gv[j] : 0));
                     }
-                    u32x4 hi, lo;
-                    split8(t, hi, lo);
-                    lds[half * HVOLP + lp[j] + e] = hi;
-                    lds[(2 + half) * HVOLP + lp[j] + e] = lo;
+                }
+#pragma unroll
+                for (int j = 0; j < NSV; ++j) {
+                    if (gv[j] == -2) continue;
+                    const bool inb = gv[j] >= 0;
+                    const int q = (tid + j * 256) % 6;
+                    const int e0 = q == 0 ? 3 : 0, e1 = q == 5 ? 1 : 4;        // elements of this segment inside the halo row
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < e0 || e >= e1) continue;
+                        float t[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            float u = e == 0 ? v[j][c].x : (e == 1 ? v[j][c].y : (e == 2 ? v[j][c].z : v[j][c].w));
+                            u = fmaf(u, sc[c], sh[c]);                          // branch-free: (1, 0, slope 1) when no transform
+                            u = fmaxf(u, u * slope);                            // LeakyReLU for 0 < slope <= 1
+                            t[c] = (inb && cb + c < a.Cin) ? u : 0.f;          // zero padding applies to the ACTIVATED tensor
+                        }
+                        u32x4 hi, lo;
+                        split8(t, hi, lo);
+                        lds[half * HVOLP + lp[j] + e] = hi;
+                        lds[(2 + half) * HVOLP + lp[j] + e] = lo;
+                    }
                 }
             }
         }
@@ -181,14 +329,32 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                 al[i] = __builtin_bit_cast(bf16x8, lds[aoff[ks] + 2 * HVOLP + i * HX]);
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][0], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) acc[i] = mm(al[i], bh, acc[i]);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][0], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) acc[i] = mm(ah[i], bl, acc[i]);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][0], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) acc[i] = mm(ah[i], bh, acc[i]);
         }
     }
-    conv3_epilogue<MT, 1>(a, acc, smem, n, z0, y0, x0, mz, my0, co0, tz, ty, tx, ntz, nty, ntx);
+    // ---- epilogue: per-wave statistics partial (block tis*4 + wave), like the persistent kernel
+    constexpr int NS = OUT16 ? 4 : 1;
+    float s1[NS], s2[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+    float4 radd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) radd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.add) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int yy = y0 + my0 + i;
+            radd[i] = *reinterpret_cast<const float4*>(a.add + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
+    sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, tis * 4 + wave, tiles_per_sample * 4, lane);
 }
 
 // ------------------------------------------------------------------ v2: persistent producer / consumer workgroups
@@ -199,54 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 // loads of item w+2 in flight.  One __syncthreads per item.  Each SIMD hosts one consumer and one producer wave, so
 // the matrix pipe and the VALU/LDS-store work of the staging overlap instead of alternating.
 // Per-tile GroupNorm statistics are written per consumer WAVE (no cross-wave reduction -> no extra barrier).
-template <int MT>
-__device__ __forceinline__ void sb2_epilogue(const Conv3Args& a, f32x4 (&acc)[MT], int n, int z0, int y0, int x0, int mz, int my0,
-                                             int co0, int tile_in_sample, int nblk, int wave, int lane) {
-    const int D = a.D, H = a.H, W = a.W;
-    const size_t HW = (size_t)H * W;
-    const int zz = z0 + mz;
-    const int xq = x0 + (lane >> 4) * 4;
-    const int co = co0 + (lane & 15);
-    float s1 = 0.f, s2 = 0.f;
-    const float bv = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    float4 radd[MT];
-    if (a.add) {       // residual: all loads first (unconditional, clamped), then use
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int yy = y0 + my0 + i;
-            const bool ok = zz < D && yy < H && co < a.Cout && xq < W;
-            const size_t idx = ok ? (((size_t)n * a.Cout + co) * D + zz) * HW + (size_t)yy * W + xq : 0;
-            radd[i] = *reinterpret_cast<const float4*>(a.add + idx);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int yy = y0 + my0 + i;
-        const bool ok = zz < D && yy < H && co < a.Cout && xq < W;       // W % 4 == 0: the 4 voxels are in or out together
-        if (!ok) continue;
-        const size_t idx = (((size_t)n * a.Cout + co) * D + zz) * HW + (size_t)yy * W + xq;
-        f32x4 v = acc[i];
-        v += bv;
-        if (a.add) { v[0] += radd[i].x; v[1] += radd[i].y; v[2] += radd[i].z; v[3] += radd[i].w; }
-        s1 += (v[0] + v[1]) + (v[2] + v[3]);
-        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        if (a.sigmoid) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = 1.f / (1.f + expf(-v[r]));
-        }
-        *reinterpret_cast<float4*>(a.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (a.stat_partials) {
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if (lane < 16 && co < a.Cout) {
-            float* p = a.stat_partials + (((size_t)n * a.Cout + co) * nblk + tile_in_sample * 4 + wave) * 2;
-            p[0] = s1; p[1] = s2;
-        }
-    }
-}
-
-template <int TZ, int TY>
+template <int TZ, int TY, bool IN16, bool OUT16>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
@@ -261,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     const bool producer = wave >= 4;
     const int rw = wave & 3;                             // wave index inside its role group
     const int ptid = tid & 255;
-    const int cog = blockIdx.y, co0 = cog * 16;
+    const int cog = blockIdx.y;
     const int D = a.D, H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, DHW = (size_t)D * HW;
     const int tiles_per_sample = ntz * nty * ntx;
@@ -294,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         //   interior: halo row x 4 aligned float4 segments [x0+4q, +4)  -> NROW*4 items, every lane has 4 valid voxels
         //   edge    : halo row x {x0-1, x0+16}                           -> NROW*2 items, one scalar per channel
         // (the six-segment cover of the 18-wide row wasted 6 of 24 loaded floats and half of the lanes' VALU work)
+        if constexpr (!IN16) {
         constexpr int NI = NROW * 4, NE = NROW * 2;
         static_assert(NI <= 256 && NE <= 128, "one interior and one edge item per producer thread");
         const bool has_i = ptid < NI;
@@ -400,6 +520,89 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             }
             __syncthreads();
         }
+        } else {
+        // ---- C16 input: position p of the halo image (row-major, HX voxels per row) x channel half; the 8 lanes of a
+        // ds_write_b128 group hold 8 consecutive positions of one half (conflict free), and every voxel is two aligned
+        // float4 loads: a halo row is ONE contiguous run of 18 x 64 bytes
+        constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
+        const int hsel = (ptid >> 3) & 1;
+        const int pslot = (ptid >> 4) * 8 + (ptid & 7);
+        float4 v16[NR][2];
+        float4 sc4[2], sh4[2];
+        unsigned vmask = 0;
+        auto issue = [&](int item) {
+            if (dbg & 2) return;
+            const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
+            int n, z0, y0, x0, tis;
+            tile_origin(tile, n, z0, y0, x0, tis);
+            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + hsel * 8;
+            vmask = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 128 + pslot;
+                const int row = p / HX, xc = p - row * HX;
+                const int hz = row / HY, hy = row - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
+                const bool ok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+                vmask |= ok ? (1u << r) : 0u;
+                v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
+                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
+            }
+            if (xform) {
+                const int cofs = n * a.Cin + chunk * 16 + hsel * 8;
+                sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
+                sh4[0] = *reinterpret_cast<const float4*>(a.in_shift + cofs); sh4[1] = *reinterpret_cast<const float4*>(a.in_shift + cofs + 4);
+            }
+        };
+        auto store = [&](int item, u32x4* buf) {
+            (void)item;
+            if (dbg & 1) {
+                if (!(dbg & 2)) {
+                    float acc0 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) acc0 += v16[r][0].x + v16[r][1].x;
+                    if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u};
+                }
+                return;
+            }
+            float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (xform) {
+                sc[0] = sc4[0].x; sc[1] = sc4[0].y; sc[2] = sc4[0].z; sc[3] = sc4[0].w; sc[4] = sc4[1].x; sc[5] = sc4[1].y; sc[6] = sc4[1].z; sc[7] = sc4[1].w;
+                sh[0] = sh4[0].x; sh[1] = sh4[0].y; sh[2] = sh4[0].z; sh[3] = sh4[0].w; sh[4] = sh4[1].x; sh[5] = sh4[1].y; sh[6] = sh4[1].z; sh[7] = sh4[1].w;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 128 + pslot;
+                if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
+                const bool ok = (vmask >> r) & 1u;
+                const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
+                float t[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float u = fmaf(f[c], sc[c], sh[c]);
+                    t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                }
+                u32x4 hi, lo;
+                split8(t, hi, lo);
+                buf[hsel * HVOLP + p] = hi;
+                buf[(2 + hsel) * HVOLP + p] = lo;
+            }
+        };
+        if (nitems > 0) {
+            issue(0);
+            store(0, lds);
+            if (nitems > 1) issue(1);
+        }
+        __syncthreads();
+        for (int w = 0; w < nitems; ++w) {
+            if (w + 1 < nitems) {
+                store(w + 1, lds + ((w + 1) & 1) * BUF);
+                if (w + 2 < nitems) issue(w + 2);
+            }
+            __syncthreads();
+        }
+        }
     } else {
         // ---------------------------------------------------------------- consumers
         const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
@@ -423,18 +626,36 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         };
         if (nchunk == 1) load_w(0);                     // one chunk: the weights stay in registers for the whole run of tiles
         f32x4 acc[MT];
+        // OUT16: operands swapped -> D[m = cout][n = voxel] (lane owns 4 couts of one voxel, see sb_out_tile)
+        auto mm = [](const bf16x8& av, const bf16x8& wv, const f32x4& c) -> f32x4 {
+            if constexpr (OUT16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
+        };
+        constexpr int NS = OUT16 ? 4 : 1;
+        float s1[NS], s2[NS];
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const int chunk = w % nchunk;
+            const bool last = chunk == nchunk - 1 && !(dbg & 8);
             if (chunk == 0) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (nchunk > 1) load_w(chunk);
             const u32x4* buf = lds + (w & 1) * BUF;
+            int n = 0, z0 = 0, y0 = 0, x0 = 0, tis = 0;
+            SbOut out{};
+            if (last) {
+                tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
+                out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+#pragma unroll
+                for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+            }
             if (!(dbg & 4)) {
                 // software pipeline over two register sets (M-tiles 0..MT/2-1 and MT/2..MT-1): the A fragments of the next
-                // K-step are read while the other set's MFMAs run (one wave per SIMD cannot hide LDS latency by itself)
+                // K-step are read while the other set's MFMAs run (one wave per SIMD cannot hide LDS latency by itself).
+                // Measured alternatives (profiles/r01_sb2_ablation.txt): finishing the M-tiles in groups of 2 or 4 so their
+                // stores trickle out under the next group's MFMAs was slower (2: dependent MFMAs too close; 4: 535 vs 457 us).
                 constexpr int HM = MT / 2;
                 bf16x8 ah0[HM], al0[HM], ah1[HM], al1[HM];
 #pragma unroll
@@ -452,11 +673,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0[i], bh, acc[i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[i] = mm(al0[i], bh, acc[i]);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0[i], bl, acc[i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[i] = mm(ah0[i], bl, acc[i]);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0[i], bh, acc[i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[i] = mm(ah0[i], bh, acc[i]);
                     if (ks + 1 < SB_KSTEPS) {
 #pragma unroll
                         for (int i = 0; i < HM; ++i) {
@@ -466,11 +687,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1[i], bh, acc[HM + i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(al1[i], bh, acc[HM + i]);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1[i], bl, acc[HM + i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(ah1[i], bl, acc[HM + i]);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1[i], bh, acc[HM + i], 0, 0, 0);
+                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(ah1[i], bh, acc[HM + i]);
                     if (ks + 1 < SB_KSTEPS) {
 #pragma unroll
                         for (int i = 0; i < HM; ++i) {
@@ -481,11 +702,21 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (chunk == nchunk - 1 && !(dbg & 8)) {
-                int n, z0, y0, x0, tis;
-                tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
-                sb2_epilogue<MT>(a, acc, n, z0, y0, x0, mz, my0, co0, tis, tiles_per_sample * 4, rw, lane);
+            if (last) {
+                float4 radd[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) radd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.add) {                            // residual: all loads first (unconditional, clamped), then use
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int yy = y0 + my0 + i;
+                        radd[i] = *reinterpret_cast<const float4*>(a.add + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
             }
+            if (last) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, tis * 4 + rw, tiles_per_sample * 4, lane);
             __syncthreads();
         }
     }
@@ -544,23 +775,23 @@ static SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
     return {2, 4};
 }
 
-// v2 (persistent producer/consumer) handles the large-tile case; it writes one statistics partial per consumer wave
+// v2 (persistent producer/consumer) handles the large-tile case
 static bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
 
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     (void)Cin;
     const SBChoice c = sb_choose(N, Cout, D, H, W);
-    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * (sb_use_v2(c) ? 4 : 1);
+    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;       // one partial per wave
 }
 
-template <int TZ, int TY>
+template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static bool attr_done = false;
     static int ncu = 256;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         int dev = 0;
         hipDeviceProp_t prop;
@@ -576,33 +807,42 @@ static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)gx, (unsigned)ncog);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
 }
 
-template <int TZ, int TY>
+template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb_kernel<TZ, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb)");
         attr_done = true;
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.Cout, 16));
-    hipLaunchKernelGGL((conv3_sb_kernel<TZ, TY>), grid, dim3(256), P::LDS_BYTES, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16));
+    hipLaunchKernelGGL((conv3_sb_kernel<TZ, TY, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16));
     RU_CHECK_LAUNCH("conv3_sb_kernel");
     return RU_OK;
 }
 
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
-    RU_REQUIRE((a.W & 3) == 0, "conv3_sb: W must be a multiple of 4");
+    RU_REQUIRE((a.W & 3) == 0 || (a.in_c16 && a.out_c16), "conv3_sb: W must be a multiple of 4 for NCDHW tensors");
+    RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_sb: C16 input needs Cin %% 16 == 0");
+    RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
     const SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
-    if (sb_use_v2(c)) return sb2_cfg<4, 8>(a, s);
-    if (c.ty == 8) return sb_cfg<2, 8>(a, s);
-    return sb_cfg<2, 4>(a, s);
+    if (sb_use_v2(c)) {
+        if (a.in_c16) return a.out_c16 ? sb2_cfg<4, 8, true, true>(a, s) : sb2_cfg<4, 8, true, false>(a, s);
+        return a.out_c16 ? sb2_cfg<4, 8, false, true>(a, s) : sb2_cfg<4, 8, false, false>(a, s);
+    }
+    if (c.ty == 8) {
+        if (a.in_c16) return a.out_c16 ? sb_cfg<2, 8, true, true>(a, s) : sb_cfg<2, 8, true, false>(a, s);
+        return a.out_c16 ? sb_cfg<2, 8, false, true>(a, s) : sb_cfg<2, 8, false, false>(a, s);
+    }
+    if (a.in_c16) return a.out_c16 ? sb_cfg<2, 4, true, true>(a, s) : sb_cfg<2, 4, true, false>(a, s);
+    return a.out_c16 ? sb_cfg<2, 4, false, true>(a, s) : sb_cfg<2, 4, false, false>(a, s);
 }
 
 }  // namespace ru

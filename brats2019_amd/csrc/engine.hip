@@ -945,3 +945,25 @@ extern "C" int ru_dice_counts(const float* p, const float* g, unsigned long long
     RU_REQUIRE(p && g && counts && N > 0 && C > 0, "ru_dice_counts: bad argument");
     return dice_counts_launch(p, g, counts, N * C, V, (hipStream_t)stream);
 }
+
+// ====================================================================== C16 layout hooks (tests / probes)
+extern "C" int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int to_c16, ru_stream_t stream) {
+    RU_REQUIRE(src && dst && N > 0, "ru_layout_convert: bad argument");
+    return layout_convert_launch(src, dst, N, C, V, to_c16, (hipStream_t)stream);
+}
+
+extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int D, int H, int W,
+                               int flags, void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && w && y, "ru_conv3d_fwd_l: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    WsCarver C(ws, ws_bytes);
+    Conv3Args a{};
+    void* wf = C.take(conv3_sb_frag_bytes(Cin, Cout) / 4 + 64);
+    RU_WS_OK(C);
+    int rc = conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s);
+    if (rc) return rc;
+    a.mode = RU_PREC_BF16X3; a.wfrag = wf;
+    a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
+    a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    return conv3_sb_launch(a, s);
+}

@@ -906,6 +906,48 @@ int compose_labels_launch(const unsigned char* mask, const unsigned long long* c
     return RU_OK;
 }
 
+// ------------------------------------------------------------------ layout change NCDHW <-> C16
+// one workgroup = 64 voxels x 16 channels through LDS; both global sides coalesced
+__global__ __launch_bounds__(256) void layout_convert_kernel(const float* __restrict__ src, float* __restrict__ dst, int CB, size_t V, int to_c16) {
+    __shared__ float tile[16][65];
+    const size_t v0 = (size_t)blockIdx.x * 64;
+    const size_t nb = blockIdx.y;                          // n * CB + cb
+    const int t = threadIdx.x;
+    const float* s_nc = src + nb * 16 * V;                 // both layouts: 16 * V floats per (n, cb)
+    float* d_nc = dst + nb * 16 * V;
+    if (to_c16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (t >> 6) + 4 * j, v = t & 63;
+            tile[c][v] = v0 + v < V ? s_nc[(size_t)c * V + v0 + v] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = t + 256 * j, v = e >> 4, c = e & 15;
+            if (v0 + v < V) d_nc[(v0 + v) * 16 + c] = tile[c][v];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = t + 256 * j, v = e >> 4, c = e & 15;
+            tile[c][v] = v0 + v < V ? s_nc[(v0 + v) * 16 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (t >> 6) + 4 * j, v = t & 63;
+            if (v0 + v < V) d_nc[(size_t)c * V + v0 + v] = tile[c][v];
+        }
+    }
+}
+int layout_convert_launch(const float* src, float* dst, int N, int C, size_t V, int to_c16, hipStream_t s) {
+    RU_REQUIRE(C > 0 && C % 16 == 0, "layout_convert: C must be a multiple of 16");
+    hipLaunchKernelGGL(layout_convert_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)(N * (C / 16))), dim3(256), 0, s, src, dst, C / 16, V, to_c16);
+    RU_CHECK_LAUNCH("layout_convert_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ evaluation metric (metrics.py:108-133)
 // per (sample, channel): counts[row] = { sum(p>0.5 & g>0.5), sum(p>0.5) + sum(g>0.5) } as integers (order independent)
 __global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ p, const float* __restrict__ g,

@@ -49,6 +49,9 @@ struct Conv3Args {
     int CinP, CoutP;
     int mode;                // RU_PREC_F32: exact-f32 MFMA (wp); RU_PREC_BF16X3: split-bf16, 3 MFMA products (wfrag)
     const void* wfrag;       // packed bf16 hi/lo weight fragments (conv3_sb.hip) when mode == RU_PREC_BF16X3
+    // Engine-internal voxel-major layout "C16" (split-bf16 kernels only): [N][C/16][D][H][W][16], C % 16 == 0.
+    // in_c16: x (and in_scale/in_shift semantics unchanged); out_c16: y, add.  0 = NCDHW.
+    int in_c16, out_c16;
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
@@ -115,6 +118,8 @@ struct Conv1Args {
 };
 int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
+// NCDHW [N][C][V] <-> C16 [N][C/16][V][16] (C % 16 == 0); to_c16 = 1: src NCDHW -> dst C16, 0: the inverse
+int layout_convert_launch(const float* src, float* dst, int N, int C, size_t V, int to_c16, hipStream_t s);
 
 // space-to-depth for the 2x2x2 stride-2 conv: y[n][c*8 + (i*4+j*2+k)][z][y][x] = x[n][c][2z+i][2y+j][2x+k]
 int s2d_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);   // D,H,W = input (even)

@@ -219,3 +219,38 @@ def dice_counts(pred, target):
     counts = torch.empty((n, c, 2), dtype=torch.int64, device=pred.device)
     L.check(L.load().ru_dice_counts(L.f32(pred), L.f32(target), L.ptr(counts), n, c, v, L.stream()), "ru_dice_counts")
     return counts
+
+
+# ---------------------------------------------------------------------- engine-internal voxel-major layout (tests / probes)
+def to_c16(x):
+    """NCDHW [N,C,D,H,W] -> C16 storage [N,C/16,D,H,W,16] (device kernel ru_layout_convert)."""
+    x = _prep(x)
+    n, c, d, h, w = _dims5(x)
+    y = torch.empty((n, c // 16, d, h, w, 16), dtype=torch.float32, device=x.device)
+    L.check(L.load().ru_layout_convert(L.f32(x), L.f32(y), n, c, d * h * w, 1, L.stream()), "ru_layout_convert")
+    return y
+
+
+def from_c16(x):
+    x = _prep(x)
+    n, cb, d, h, w, _ = (int(v) for v in x.shape)
+    y = torch.empty((n, cb * 16, d, h, w), dtype=torch.float32, device=x.device)
+    L.check(L.load().ru_layout_convert(L.f32(x), L.f32(y), n, cb * 16, d * h * w, 0, L.stream()), "ru_layout_convert")
+    return y
+
+
+def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False):
+    """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16)."""
+    x, w, bias = _prep(x), _prep(w), _prep(bias)
+    if in_c16:
+        n, cb, d, h, wd, _ = (int(v) for v in x.shape)
+        cin = cb * 16
+    else:
+        n, cin, d, h, wd = _dims5(x)
+    cout = int(w.shape[0])
+    y = torch.empty((n, cout // 16, d, h, wd, 16) if out_c16 else (n, cout, d, h, wd), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3), x.device)
+    L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, int(in_c16) | (int(out_c16) << 1),
+                                L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd_l")
+    return y

@@ -172,6 +172,17 @@ int ru_tta_merge(const float* probs, int K, unsigned flips, float* mean_out, uns
 int ru_compose_labels(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels,
                       size_t V, ru_stream_t stream);
 
+/* ---------------------------------------------------------------- voxel-major working layout ("C16")
+ * Between the first and the last convolution the split-bf16 engine keeps activations as [N][C/16][D][H][W][16]
+ * (16 channels of a voxel contiguous; C % 16 == 0): a halo tile of a 3x3x3 convolution is then a few long contiguous
+ * runs instead of 16 channel planes x short rows.  Nothing in that layout crosses the boundary of ru_unet_*; the
+ * entry points below exist so the tests and probes can drive the layout-aware kernels one at a time.
+ * flags: bit 0 = x (input) is C16, bit 1 = y (output) is C16.  k = 3, RU_PREC_BF16X3 only. */
+int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int to_c16, ru_stream_t stream);
+int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y,
+                    int N, int Cin, int Cout, int D, int H, int W, int flags,
+                    void* ws, size_t ws_bytes, ru_stream_t stream);
+
 /* ---------------------------------------------------------------- evaluation metric (metrics.py:108-133, `Dice.update`)
  * counts[(n*C + c)*2 + {0,1}] = { #(p > 0.5 and g > 0.5), #(p > 0.5) + #(g > 0.5) } over the V voxels of sample n, channel c.
  * The metric is 2*counts[0]/counts[1] per (n, c) (NaN -> 1), averaged over the batch (host side: brats2019_amd/metrics.py). */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch one convolution entry point a few times (for rocprofv3 --pmc / --kernel-trace passes).
-usage: conv_probe.py [fwd|wgrad] [f32|bf16x3] [N] [C] [size] [launches]"""
+usage: conv_probe.py [fwd|wgrad] [f32|bf16x3] [N] [C] [size] [launches] [layout flags]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +12,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 c = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 size = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 launches = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+flags = int(sys.argv[7]) if len(sys.argv) > 7 else 0          # fwd only: bit 0 input C16, bit 1 output C16
 lib = L.load()
 dev = torch.device("cuda")
 x = torch.randn(n, c, size, size, size, device=dev)
@@ -20,7 +21,9 @@ y = torch.empty_like(x)
 dw = torch.empty_like(w)
 ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, c, c, size, size, size, 3), dev)
 for _ in range(launches):
-    if kind == "fwd":
+    if kind == "fwd" and flags:
+        L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, flags, L.ptr(ws), ws.numel(), L.stream()), "fwd_l")
+    elif kind == "fwd":
         L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, 3, L.PRECISIONS[prec], L.ptr(ws), ws.numel(), L.stream()), "fwd")
     else:
         L.check(lib.ru_conv3d_bwd_weight(L.f32(x), L.f32(y), L.f32(dw), None, n, c, c, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "wgrad")
