@@ -62,6 +62,7 @@ SIGNATURES = {
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),
     "ru_layout_convert": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
     "ru_conv3d_fwd_l": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
+    "ru_conv3d_bwd_weight_l": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
 }
 
 

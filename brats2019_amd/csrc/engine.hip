@@ -87,7 +87,7 @@ struct BlockP {           // parameter indices of one Residual (model.py:81-97)
     int down = -1, conv1 = -1, conv2 = -1, n1w = -1, n1b = -1, n2w = -1, n2b = -1;
     int cin_down = 0, c = 0;
     // packed-weight slots (offsets in floats into the pack region)
-    size_t pk_f1 = 0, pk_f2 = 0, pk_d1 = 0, pk_d2 = 0, pk_downT = 0;
+    size_t pk_f1 = 0, pk_f2 = 0, pk_d1 = 0, pk_d2 = 0, pk_downT = 0, pk_down16 = 0;   // pk_down16: [C][8*cin] then [8*cin][C]
     size_t fk_f1 = 0, fk_f2 = 0, fk_d1 = 0, fk_d2 = 0;     // byte offsets of the split-bf16 weight fragments
 };
 
@@ -125,6 +125,7 @@ struct ru_unet {
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
+    bool c16 = false;           // this forward/backward pair keeps its activations voxel-major (split-bf16, channels % 16 == 0)
     char* fpack = nullptr;
 
     // state of the last forward
@@ -186,7 +187,10 @@ static void assign_block_packs(ru_unet* h, BlockP& b) {
     b.pk_f2 = h->pk_total; h->pk_total += n;
     b.pk_d1 = h->pk_total; h->pk_total += n;
     b.pk_d2 = h->pk_total; h->pk_total += n;
-    if (b.down >= 0) { b.pk_downT = h->pk_total; h->pk_total += (size_t)8 * b.cin_down * b.c; }
+    if (b.down >= 0) {
+        b.pk_downT = h->pk_total; h->pk_total += (size_t)8 * b.cin_down * b.c;
+        b.pk_down16 = h->pk_total; h->pk_total += (size_t)2 * 8 * b.cin_down * b.c;
+    }
     const size_t f = conv3_sb_frag_bytes(b.c, b.c);
     b.fk_f1 = h->fk_total; h->fk_total += f;
     b.fk_f2 = h->fk_total; h->fk_total += f;
@@ -287,7 +291,10 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
             rc = pack3(b.conv1, b.pk_d1, b.fk_d1, b.c, b.c, 1); if (rc) return rc;
             rc = pack3(b.conv2, b.pk_d2, b.fk_d2, b.c, b.c, 1); if (rc) return rc;
         }
-        if (b.down >= 0) RU_RUN(transpose_launch(P(h, params, b.down), pk + b.pk_downT, b.c, 8 * b.cin_down, s));
+        if (b.down >= 0) {
+            if (h->c16) RU_RUN(pack_down16_launch(P(h, params, b.down), pk + b.pk_down16, pk + b.pk_down16 + (size_t)8 * b.cin_down * b.c, b.c, b.cin_down, s));
+            else RU_RUN(transpose_launch(P(h, params, b.down), pk + b.pk_downT, b.c, 8 * b.cin_down, s));
+        }
         return RU_OK;
     };
     { int rc = pack3(h->conv_in, h->pk_in, h->fk_in, kInCh, h->ch[0], 0); if (rc) return rc; }
@@ -305,8 +312,8 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
 
 // y = conv3(x) with optional fused input transform, tile statistics -> GNSave (mean/rstd/scale/shift)
 static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, const char* wf, float* y, const GNSave* in_gn,
-                    const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W) {
-    const int nblk = conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
+                    const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W, bool x_c16 = true) {
+    const int nblk = h->c16 ? conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
     out_gn.mean = A.alloc((size_t)N * kGroups);
     out_gn.rstd = A.alloc((size_t)N * kGroups);
@@ -319,6 +326,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.in_slope = kSlope;
     a.stat_partials = partials;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16;
     RU_RUN(conv3_launch(a, s));
     RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
                               (size_t)D * H * W, kGroups, kEps, s));
@@ -338,11 +346,18 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
         const size_t Vo = (size_t)Do * Ho * Wo;
         sv.xs2d = A.alloc((size_t)N * 8 * bp.cin_down * Vo);
         float* xd = A.alloc((size_t)N * C * Vo);
-        RU_RUN(s2d_launch(xprev, sv.xs2d, N, bp.cin_down, D, H, W, s));
         Conv1Args c1{};
-        c1.x0 = sv.xs2d; c1.C0 = 8 * bp.cin_down; c1.wT = h->pack + bp.pk_downT; c1.ldw = C; c1.y = xd; c1.out_slope = 1.f;
+        c1.x0 = sv.xs2d; c1.C0 = 8 * bp.cin_down; c1.y = xd; c1.out_slope = 1.f;
         c1.N = N; c1.Cout = C; c1.V = Vo;
-        RU_RUN(conv1_launch(c1, s));
+        if (h->c16) {
+            RU_RUN(s2d16_launch(xprev, sv.xs2d, N, bp.cin_down, D, H, W, s));
+            c1.wT = h->pack + bp.pk_down16; c1.ldw = 8 * bp.cin_down;         // [C][tap*cin + c]
+            RU_RUN(conv1_16_launch(c1, s));
+        } else {
+            RU_RUN(s2d_launch(xprev, sv.xs2d, N, bp.cin_down, D, H, W, s));
+            c1.wT = h->pack + bp.pk_downT; c1.ldw = C;
+            RU_RUN(conv1_launch(c1, s));
+        }
         x = xd; D = Do; H = Ho; W = Wo;
     }
     const size_t V = (size_t)D * H * W;
@@ -354,7 +369,8 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, h->fpack + bp.fk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
     if (rc) return rc;
     sv.out = A.alloc((size_t)N * C * V);
-    RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
+    if (h->c16) RU_RUN(gn_apply16_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
+    else RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
     *out = sv.out;
     return RU_OK;
 }
@@ -365,6 +381,8 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
     auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
     h->gn_order.clear();
+    h->c16 = h->precision == RU_PREC_BF16X3 && (h->W & 3) == 0;
+    for (int c : h->ch) h->c16 = h->c16 && (c % 16 == 0);
     h->pack = A.alloc(h->pk_total);
     h->fpack = reinterpret_cast<char*>(A.alloc(h->fk_total / sizeof(float) + 64));
     int rc = pack_all(h, params, A, s);
@@ -374,10 +392,11 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     const int C0 = h->ch[0];
     h->x_in = x;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0], false);
     if (rc) return rc;
     h->t0 = A.alloc((size_t)N * C0 * Vl(0));
-    RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
+    if (h->c16) RU_RUN(gn_apply16_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
+    else RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
     const float* cur = h->t0;
     h->first_s.assign(h->first_blocks.size(), BlockSave());
     for (size_t j = 0; j < h->first_blocks.size(); ++j) {
@@ -406,17 +425,27 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         ds.skip = h->skips[i];
         const int Ci = h->ch[i], Cc = h->ch[i + 1];
         ds.u = A.alloc((size_t)N * Cc * Vl(i));
-        RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        if (h->c16) RU_RUN(up2_fwd16_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        else RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
         ds.v = A.alloc((size_t)N * Ci * Vl(i));
         Conv1Args c1{};
-        c1.x0 = ds.u; c1.C0 = Cc; c1.wT = h->pack + h->pk_upT[i]; c1.ldw = Ci; c1.y = ds.v; c1.out_slope = kSlope;   // + LeakyReLU (model.py:422)
+        c1.x0 = ds.u; c1.C0 = Cc; c1.y = ds.v; c1.out_slope = kSlope;                                                 // + LeakyReLU (model.py:422)
         c1.N = N; c1.Cout = Ci; c1.V = Vl(i);
-        RU_RUN(conv1_launch(c1, s));
         ds.c = A.alloc((size_t)N * Ci * Vl(i));
         Conv1Args c2{};
         c2.x0 = ds.skip; c2.C0 = Ci; c2.x1 = ds.v; c2.C1 = Ci;                                                        // cat([skip, up]) (model.py:424)
-        c2.wT = h->pack + h->pk_decT[i]; c2.ldw = Ci; c2.y = ds.c; c2.out_slope = 1.f; c2.N = N; c2.Cout = Ci; c2.V = Vl(i);
-        RU_RUN(conv1_launch(c2, s));
+        c2.y = ds.c; c2.out_slope = 1.f; c2.N = N; c2.Cout = Ci; c2.V = Vl(i);
+        if (h->c16) {                                            // C16 kernel reads the reference layout [out][in] directly
+            c1.wT = P(h, params, h->up_w[i]); c1.ldw = Cc;
+            RU_RUN(conv1_16_launch(c1, s));
+            c2.wT = P(h, params, h->dec1_w[i]); c2.ldw = 2 * Ci;
+            RU_RUN(conv1_16_launch(c2, s));
+        } else {
+            c1.wT = h->pack + h->pk_upT[i]; c1.ldw = Ci;
+            RU_RUN(conv1_launch(c1, s));
+            c2.wT = h->pack + h->pk_decT[i]; c2.ldw = Ci;
+            RU_RUN(conv1_launch(c2, s));
+        }
         cur = ds.c;
         h->dec_s[i].assign(h->dec_blocks[i].size(), BlockSave());
         for (size_t j = 0; j < h->dec_blocks[i].size(); ++j) {
@@ -430,7 +459,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     if (h->training) { h->probs = A.alloc((size_t)N * h->nout * Vl(0)); pdst = h->probs; }
     Conv3Args a{};
     a.x = cur; a.wp = h->pack + h->pk_out; a.bias = P(h, params, h->conv_out_b); a.y = pdst; a.sigmoid = 1;
-    a.mode = h->precision; a.wfrag = h->fpack + h->fk_out;
+    a.mode = h->precision; a.wfrag = h->fpack + h->fk_out; a.in_c16 = h->c16;
     a.N = N; a.Cin = C0; a.Cout = h->nout; a.D = Dl[0]; a.H = Hl[0]; a.W = Wl[0];
     RU_RUN(conv3_launch(a, s));
     if (h->training && !A.dry) {
@@ -442,20 +471,23 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
 
 // ---------------------------------------------------------------------- backward pieces
 // GroupNorm(+LeakyReLU) backward: d_act -> dy (gradient w.r.t. the raw conv output), dgamma/dbeta written
-static int gn_bwd(Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
+static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
                   float* dy, float* dgamma, float* dbeta, int N, int C, size_t V) {
-    const int nblk = gn_bwd_tiles(V);
+    const int nblk = c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V);
     float* part = A.alloc((size_t)N * C * nblk * 2);
     float* coef = A.alloc((size_t)N * C * 3);
-    RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+    if (c16) RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+    else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
     RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s));
-    RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
+    if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
+    else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
     return RU_OK;
 }
 
-static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W) {
+static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
+                      bool x_c16 = false, bool dy_c16 = false) {
     Wgrad3Args w{};
-    w.x = x; w.dy = dy; w.dw = dw; w.mode = mode;
+    w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16;
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -464,9 +496,10 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     return RU_OK;
 }
 
-static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, float* dw, int ldw, int N, int Cin, int Cout, size_t V) {
+static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, float* dw, int ldw, int N, int Cin, int Cout, size_t V,
+                      bool c16 = false, int tap_split = 0) {
     Wgrad1Args w{};
-    w.x = x; w.dy = dy; w.dw = dw; w.ldw = ldw;
+    w.x = x; w.dy = dy; w.dw = dw; w.ldw = ldw; w.c16 = c16; w.tap_split = tap_split;
     w.ws_bytes = wgrad1_workspace_bytes(N, Cin, Cout, V);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
     w.N = N; w.Cin = Cin; w.Cout = Cout; w.V = V;
@@ -481,35 +514,44 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
     const size_t V = (size_t)D * H * W;
     float* dy2 = A.alloc((size_t)N * C * V);
-    int rc = gn_bwd(A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
+    const bool c16 = h->c16;
+    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W);
+    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
-    rc = gn_bwd(A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
+    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W);
+    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
+    d1.in_c16 = c16; d1.out_c16 = c16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
     // down-sampling conv backward (Appendix A2): 1x1 over the space-to-depth view
     const int Cp = bp.cin_down;
-    rc = wgrad1_run(A, s, sv.xs2d, dx, G(h, grads, bp.down), 8 * Cp, N, 8 * Cp, C, V);
+    rc = wgrad1_run(A, s, sv.xs2d, dx, G(h, grads, bp.down), 8 * Cp, N, 8 * Cp, C, V, c16, c16 ? Cp : 0);
     if (rc) return rc;
     float* t = A.alloc((size_t)N * 8 * Cp * V);
     Conv1Args c1{};
-    c1.x0 = dx; c1.C0 = C; c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp; c1.y = t; c1.out_slope = 1.f; c1.N = N; c1.Cout = 8 * Cp; c1.V = V;
-    RU_RUN(conv1_launch(c1, s));
+    c1.x0 = dx; c1.C0 = C; c1.y = t; c1.out_slope = 1.f; c1.N = N; c1.Cout = 8 * Cp; c1.V = V;
     float* dxp = A.alloc((size_t)N * Cp * V * 8);
-    RU_RUN(d2s_launch(t, dxp, N, Cp, 2 * D, 2 * H, 2 * W, s));
+    if (c16) {
+        c1.wT = h->pack + bp.pk_down16 + (size_t)8 * Cp * C; c1.ldw = C;          // [tap*Cp + c][C]
+        RU_RUN(conv1_16_launch(c1, s));
+        RU_RUN(d2s16_launch(t, dxp, N, Cp, 2 * D, 2 * H, 2 * W, s));
+    } else {
+        c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp;
+        RU_RUN(conv1_launch(c1, s));
+        RU_RUN(d2s_launch(t, dxp, N, Cp, 2 * D, 2 * H, 2 * W, s));
+    }
     *dxprev_out = dxp;
     return RU_OK;
 }
@@ -524,7 +566,8 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // head
     float* dlog = A.alloc((size_t)N * h->nout * Vl(0));
     RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
-    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0]);
+    const bool c16 = h->c16;
+    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false);
     if (rc) return rc;
     {
         const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
@@ -533,7 +576,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     }
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
-    dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
+    dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.out_c16 = c16; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
     std::vector<const float*> dskip(depth - 1, nullptr);
@@ -549,30 +592,46 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         // decoder_convs1x1[i] over cat([skip, v]) (model.py:424-425)
         const float* wdec = P(h, params, h->dec1_w[i]);          // [Ci][2Ci]
         float* gdec = G(h, grads, h->dec1_w[i]);
-        rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V);
+        rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V, c16);
         if (rc) return rc;
-        rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V);
+        rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V, c16);
         if (rc) return rc;
         float* dsk = A.alloc((size_t)N * Ci * V);
         float* dv = A.alloc((size_t)N * Ci * V);
         Conv1Args a1{};
-        a1.x0 = dcur; a1.C0 = Ci; a1.wT = wdec; a1.ldw = 2 * Ci; a1.y = dsk; a1.out_slope = 1.f; a1.N = N; a1.Cout = Ci; a1.V = V;
-        RU_RUN(conv1_launch(a1, s));
+        a1.x0 = dcur; a1.C0 = Ci; a1.y = dsk; a1.out_slope = 1.f; a1.N = N; a1.Cout = Ci; a1.V = V;
         Conv1Args a2 = a1;
-        a2.wT = A.dry ? nullptr : wdec + Ci; a2.y = dv;
-        RU_RUN(conv1_launch(a2, s));
+        a2.y = dv;
+        if (c16) {                                               // [out][in] = the transposed pack [2Ci][Ci]: rows 0..Ci-1 skip half, Ci.. up half
+            a1.wT = h->pack + h->pk_decT[i]; a1.ldw = Ci;
+            a2.wT = h->pack + h->pk_decT[i] + (size_t)Ci * Ci; a2.ldw = Ci;
+            RU_RUN(conv1_16_launch(a1, s));
+            RU_RUN(conv1_16_launch(a2, s));
+        } else {
+            a1.wT = wdec; a1.ldw = 2 * Ci;
+            a2.wT = A.dry ? nullptr : wdec + Ci; a2.ldw = 2 * Ci;
+            RU_RUN(conv1_launch(a1, s));
+            RU_RUN(conv1_launch(a2, s));
+        }
         dskip[i] = dsk;
         // LeakyReLU backward from the output v (model.py:422; Appendix A4), then upsampling[i][1] (1x1) and Trilinear
         float* dpre = A.alloc((size_t)N * Ci * V);
         RU_RUN(lrelu_bwd_launch(ds.v, dv, dpre, (size_t)N * Ci * V, kSlope, s));
-        rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V);
+        rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V, c16);
         if (rc) return rc;
         float* du = A.alloc((size_t)N * Cc * V);
         Conv1Args a3{};
-        a3.x0 = dpre; a3.C0 = Ci; a3.wT = P(h, params, h->up_w[i]); a3.ldw = Cc; a3.y = du; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
-        RU_RUN(conv1_launch(a3, s));
+        a3.x0 = dpre; a3.C0 = Ci; a3.y = du; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
         float* dz = A.alloc((size_t)N * Cc * Vl(i + 1));
-        RU_RUN(up2_bwd_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        if (c16) {
+            a3.wT = h->pack + h->pk_upT[i]; a3.ldw = Ci;          // [Cc][Ci] = [out][in]
+            RU_RUN(conv1_16_launch(a3, s));
+            RU_RUN(up2_bwd16_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        } else {
+            a3.wT = P(h, params, h->up_w[i]); a3.ldw = Cc;
+            RU_RUN(conv1_launch(a3, s));
+            RU_RUN(up2_bwd_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        }
         dcur = dz;
     }
     // encoder levels, deepest first; the skip gradient joins at each level's input
@@ -591,15 +650,21 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     }
     // norm_input (no activation: slope 1) and conv_input
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = gn_bwd(A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
+    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0]);
+    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks
         float* wpd = A.alloc(conv3_packed_floats(C0, kInCh));
-        RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), wpd, kInCh, C0, 1, s));
+        float* wfd = A.alloc(conv3_sb_frag_bytes(C0, kInCh) / sizeof(float) + 64);
         Conv3Args di{};
+        if (c16) {                                               // dy0 is voxel-major: the split-bf16 kernel reads it
+            RU_RUN(conv3_sb_pack_weights(P(h, params, h->conv_in), wfd, kInCh, C0, 1, s));
+            di.mode = RU_PREC_BF16X3; di.wfrag = wfd; di.in_c16 = 1;
+        } else {
+            RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), wpd, kInCh, C0, 1, s));
+        }
         di.x = dy0; di.wp = wpd; di.y = dx_in; di.N = N; di.Cin = C0; di.Cout = kInCh; di.D = Dl[0]; di.H = Hl[0]; di.W = Wl[0];
         RU_RUN(conv3_launch(di, s));
     }
@@ -966,4 +1031,17 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     return conv3_sb_launch(a, s);
+}
+
+extern "C" int ru_conv3d_bwd_weight_l(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
+                                      int flags, void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(x && dy && dw, "ru_conv3d_bwd_weight_l: null argument");
+    WsCarver C(ws, ws_bytes);
+    Wgrad3Args a{};
+    a.x = x; a.dy = dy; a.dw = dw; a.mode = RU_PREC_BF16X3; a.x_c16 = flags & 1; a.dy_c16 = (flags >> 1) & 1;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    a.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
+    a.ws = C.take(a.ws_bytes / 4);
+    RU_WS_OK(C);
+    return wgrad3_launch(a, (hipStream_t)stream);
 }

@@ -2,43 +2,9 @@
 // 2x2x2 stride-2 convolution, GroupNorm statistics / apply / backward, LeakyReLU, sigmoid, trilinear x2 up-sampling
 // and its transpose, the Dice+BCE criterion, and Adam(amsgrad).  All are streaming kernels: 16-byte coalesced
 // accesses along W (NCDHW), one pass per tensor, two-stage deterministic reductions (no float atomics).
-#include "ru_common.h"
+#include "pw_helpers.hpp"
 
 namespace ru {
-
-// ------------------------------------------------------------------ helpers
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-// sum over a 256-thread block; result valid in thread 0 (and broadcast through `buf[0]`)
-__device__ __forceinline__ float block_sum(float v, float* buf) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return buf[0] + buf[1] + buf[2] + buf[3];
-}
-__device__ __forceinline__ double block_sum_d(double v, double* buf) {
-    v = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return buf[0] + buf[1] + buf[2] + buf[3];
-}
-__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
-
-static inline unsigned grid1d(size_t n, int per_block, unsigned cap = 1u << 20) {
-    size_t b = (n + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    return (unsigned)(b > cap ? cap : b);
-}
 
 // ------------------------------------------------------------------ 1x1x1 convolution (model.py:393,401), VALU with scalar weights
 // Each thread owns VEC consecutive voxels and 16 output channels; the weight of (c, o) is wave-uniform, so it is
@@ -544,16 +510,6 @@ int add_launch(const float* a, const float* b, float* y, size_t n, hipStream_t s
 int fill_launch(float* p, float v, size_t n, hipStream_t s) { return ew_launch<EW_FILL>(nullptr, nullptr, p, n, v, s, "fill"); }
 
 // ------------------------------------------------------------------ trilinear x2, align_corners=False (model.py:12-14)
-// source index of output o: src = max(o/2 - 0.25, 0); i0 = floor(src); l1 = src - i0; i1 = i0 + (i0 < n-1)
-__device__ __forceinline__ void up2_src(int o, int n, int& i0, int& i1, float& l0, float& l1) {
-    float src = 0.5f * (float)o - 0.25f;
-    if (src < 0.f) src = 0.f;
-    i0 = (int)src;
-    l1 = src - (float)i0;
-    l0 = 1.f - l1;
-    i1 = i0 + (i0 < n - 1 ? 1 : 0);
-}
-
 __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int D, int H, int W) {
     const int Do = 2 * D, Ho = 2 * H;
     const size_t total = (size_t)NC * Do * Ho * W;     // one thread per output x-PAIR (2k, 2k+1)
@@ -632,12 +588,6 @@ int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, 
     return RU_OK;
 }
 
-// transpose of the above in gather form: dx[k] collects from outputs 2k-1 .. 2k+2 on each axis
-__device__ __forceinline__ float up2_coef(int o, int n, int k) {
-    int i0, i1; float l0, l1;
-    up2_src(o, n, i0, i1, l0, l1);
-    return (i0 == k ? l0 : 0.f) + (i1 == k ? l1 : 0.f);
-}
 __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int NC, int D, int H, int W) {
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t total = (size_t)NC * D * H * W;

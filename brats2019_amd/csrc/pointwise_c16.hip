@@ -1,0 +1,366 @@
+// pointwise_c16.hip -- the streaming kernels of the ResUNet path on the voxel-major working layout "C16":
+// activations [N][C/16][D][H][W][16] (16 channels of a voxel contiguous, C % 16 == 0).  The split-bf16 engine keeps every
+// tensor between the first and the last convolution in this layout (include/resunet_hip.h); these kernels are the C16
+// forms of pointwise.hip: GroupNorm apply / backward, trilinear x2 and its transpose, space-to-depth, the 1x1x1
+// convolution (exact-f32 MFMA) -- same arithmetic per element, different addressing.
+//
+// Addressing: one (sample, channel block) = V voxels x 16 floats = 4V float4.  float4 index f -> voxel f>>2, channels
+// cb*16 + 4*(f&3) .. +3.  Grid strides are multiples of 4, so a thread keeps its channel quad and loads the per-channel
+// parameters once.
+#include "pw_helpers.hpp"
+
+namespace ru {
+
+typedef float f32x4_c16 __attribute__((ext_vector_type(4)));
+
+static inline dim3 c16_grid(size_t V, int blocks_nc, unsigned cap = 2048) {
+    size_t bx = (V * 4 + 255) / 256;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)blocks_nc);
+}
+
+// ------------------------------------------------------------------ GroupNorm apply: y = (res) + lrelu(x*scale[n,c] + shift[n,c])
+__global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ res, float* __restrict__ y, int C, size_t V, float slope) {
+    const int nb = blockIdx.y, CB = C >> 4;
+    const int n = nb / CB, cb = nb - n * CB;
+    const int q = threadIdx.x & 3;
+    const float4 a = *reinterpret_cast<const float4*>(scale + (size_t)n * C + cb * 16 + 4 * q);
+    const float4 b = *reinterpret_cast<const float4*>(shift + (size_t)n * C + cb * 16 + 4 * q);
+    const size_t base = (size_t)nb * V * 4, F = V * 4;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    const float4* rp = res ? reinterpret_cast<const float4*>(res) + base : nullptr;
+    float4* yp = reinterpret_cast<float4*>(y) + base;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (size_t)gridDim.x * 256) {
+        const float4 t = xp[f];
+        float4 o;
+        o.x = lrelu(t.x * a.x + b.x, slope); o.y = lrelu(t.y * a.y + b.y, slope);
+        o.z = lrelu(t.z * a.z + b.z, slope); o.w = lrelu(t.w * a.w + b.w, slope);
+        if (rp) { const float4 r = rp[f]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        yp[f] = o;
+    }
+}
+int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s) {
+    RU_REQUIRE(C % 16 == 0, "gn_apply16: C must be a multiple of 16");
+    hipLaunchKernelGGL(gn_apply16_kernel, c16_grid(V, N * (C / 16)), dim3(256), 0, s, x, scale, shift, res, y, C, V, slope);
+    RU_CHECK_LAUNCH("gn_apply16_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm backward
+// reduce: per (n, c) and voxel chunk S1 = sum dyh, S2 = sum dyh * xhat (dyh = dy * lrelu'(x*scale+shift)); partials
+// [N][C][nblk][2] exactly like the NCDHW kernel, so gn_bwd_finalize is shared.  Fixed reduction order: deterministic.
+constexpr int GN16_CHUNK = 2048;   // voxels of one (n, channel block) reduced by one workgroup
+int gn_bwd_tiles16(size_t V) { return (int)((V + GN16_CHUNK - 1) / GN16_CHUNK); }
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk) {
+    __shared__ float red[4][16][2];
+    const int nb = blockIdx.y, CB = C >> 4;
+    const int n = nb / CB, cb = nb - n * CB;
+    const int q = threadIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = cb * 16 + 4 * q, cpg = C / G;
+    const float4 a4 = *reinterpret_cast<const float4*>(scale + (size_t)n * C + c4);
+    const float4 b4 = *reinterpret_cast<const float4*>(shift + (size_t)n * C + c4);
+    const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+    float mu[4], rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int g = (c4 + k) / cpg; mu[k] = mean[n * G + g]; rs[k] = rstd[n * G + g]; }
+    const size_t base = (size_t)nb * V * 4;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    const size_t v0 = (size_t)blockIdx.x * GN16_CHUNK;
+    const size_t v1 = v0 + GN16_CHUNK < V ? v0 + GN16_CHUNK : V;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t f = v0 * 4 + threadIdx.x; f < v1 * 4; f += 256) {
+        const float4 t = xp[f], d = dp[f];
+        const float tx[4] = {t.x, t.y, t.z, t.w}, dx[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dh = (tx[k] * a[k] + b[k]) > 0.f ? dx[k] : dx[k] * slope;
+            s1[k] += dh;
+            s2[k] += dh * ((tx[k] - mu[k]) * rs[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[wave][lane * 4 + k][0] = s1[k]; red[wave][lane * 4 + k][1] = s2[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int c = threadIdx.x;
+        float* p = partials + (((size_t)n * C + cb * 16 + c) * nblk + blockIdx.x) * 2;
+        p[0] = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
+        p[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+    }
+}
+int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s) {
+    RU_REQUIRE(C % 16 == 0 && C % G == 0, "gn_bwd_reduce16: bad channel count");
+    const int nblk = gn_bwd_tiles16(V);
+    hipLaunchKernelGGL(gn_bwd_reduce16_kernel, dim3(nblk, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk);
+    RU_CHECK_LAUNCH("gn_bwd_reduce16_kernel");
+    return RU_OK;
+}
+
+// apply: dx = cA*dyh + cB*x + cC with coef[N][C][3]
+__global__ __launch_bounds__(256) void gn_bwd_apply16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ coef, float slope,
+                                                             float* __restrict__ dx, int C, size_t V) {
+    const int nb = blockIdx.y, CB = C >> 4;
+    const int n = nb / CB, cb = nb - n * CB;
+    const int q = threadIdx.x & 3;
+    const size_t row = (size_t)n * C + cb * 16 + 4 * q;
+    float a[4], b[4], cA[4], cB[4], cC[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = scale[row + k]; b[k] = shift[row + k];
+        cA[k] = coef[(row + k) * 3]; cB[k] = coef[(row + k) * 3 + 1]; cC[k] = coef[(row + k) * 3 + 2];
+    }
+    const size_t base = (size_t)nb * V * 4, F = V * 4;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    float4* op = reinterpret_cast<float4*>(dx) + base;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (size_t)gridDim.x * 256) {
+        const float4 t = xp[f], d = dp[f];
+        float4 o;
+        o.x = cA[0] * ((t.x * a[0] + b[0]) > 0.f ? d.x : d.x * slope) + (cB[0] * t.x + cC[0]);
+        o.y = cA[1] * ((t.y * a[1] + b[1]) > 0.f ? d.y : d.y * slope) + (cB[1] * t.y + cC[1]);
+        o.z = cA[2] * ((t.z * a[2] + b[2]) > 0.f ? d.z : d.z * slope) + (cB[2] * t.z + cC[2]);
+        o.w = cA[3] * ((t.w * a[3] + b[3]) > 0.f ? d.w : d.w * slope) + (cB[3] * t.w + cC[3]);
+        op[f] = o;
+    }
+}
+int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef, float slope, float* dx,
+                          int N, int C, size_t V, hipStream_t s) {
+    RU_REQUIRE(C % 16 == 0, "gn_bwd_apply16: C must be a multiple of 16");
+    hipLaunchKernelGGL(gn_bwd_apply16_kernel, c16_grid(V, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, C, V);
+    RU_CHECK_LAUNCH("gn_bwd_apply16_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ trilinear x2 (model.py:12-14), same nesting z(y(x)) as the NCDHW kernel
+__global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const size_t nb = blockIdx.y;
+    const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
+    const float4* xp = reinterpret_cast<const float4*>(x) + nb * Vi * 4;
+    float4* yp = reinterpret_cast<float4*>(y) + nb * Vo * 4;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vo * 4; f += (size_t)gridDim.x * 256) {
+        const int q = (int)(f & 3);
+        size_t r = f >> 2;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int zo = (int)(r / Ho);
+        int z0, z1, y0, y1, x0, x1; float lz0, lz1, ly0, ly1, lx0, lx1;
+        up2_src(zo, D, z0, z1, lz0, lz1);
+        up2_src(yo, H, y0, y1, ly0, ly1);
+        up2_src(xo, W, x0, x1, lx0, lx1);
+        const size_t r00 = ((size_t)z0 * H + y0) * W, r01 = ((size_t)z0 * H + y1) * W, r10 = ((size_t)z1 * H + y0) * W, r11 = ((size_t)z1 * H + y1) * W;
+        const float4 a00 = xp[(r00 + x0) * 4 + q], b00 = xp[(r00 + x1) * 4 + q];
+        const float4 a01 = xp[(r01 + x0) * 4 + q], b01 = xp[(r01 + x1) * 4 + q];
+        const float4 a10 = xp[(r10 + x0) * 4 + q], b10 = xp[(r10 + x1) * 4 + q];
+        const float4 a11 = xp[(r11 + x0) * 4 + q], b11 = xp[(r11 + x1) * 4 + q];
+        float4 o;
+#define RU_UP2(c) o.c = lz0 * (ly0 * (lx0 * a00.c + lx1 * b00.c) + ly1 * (lx0 * a01.c + lx1 * b01.c)) + \
+                        lz1 * (ly0 * (lx0 * a10.c + lx1 * b10.c) + ly1 * (lx0 * a11.c + lx1 * b11.c))
+        RU_UP2(x); RU_UP2(y); RU_UP2(z); RU_UP2(w);
+#undef RU_UP2
+        yp[f] = o;
+    }
+}
+int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {
+    RU_REQUIRE(C % 16 == 0, "up2_fwd16: C must be a multiple of 16");
+    hipLaunchKernelGGL(up2_fwd16_kernel, c16_grid((size_t)D * H * W * 8, N * (C / 16), 8192), dim3(256), 0, s, x, y, D, H, W);
+    RU_CHECK_LAUNCH("up2_fwd16_kernel");
+    return RU_OK;
+}
+
+// transpose in gather form: coarse voxel k collects from fine 2k-1 .. 2k+2 on each axis
+__global__ __launch_bounds__(256) void up2_bwd16_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D, int H, int W) {
+    const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+    const size_t nb = blockIdx.y;
+    const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + nb * Vo * 4;
+    float4* op = reinterpret_cast<float4*>(dx) + nb * Vi * 4;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vi * 4; f += (size_t)gridDim.x * 256) {
+        const int q = (int)(f & 3);
+        size_t r = f >> 2;
+        const int kx = (int)(r % W); r /= W;
+        const int ky = (int)(r % H);
+        const int kz = (int)(r / H);
+        float wz[4], wy[4], wx[4];
+        int oz[4], oy[4], ox[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int z = 2 * kz - 1 + t, y = 2 * ky - 1 + t, xx = 2 * kx - 1 + t;
+            wz[t] = (z >= 0 && z < Do) ? up2_coef(z, D, kz) : 0.f;
+            wy[t] = (y >= 0 && y < Ho) ? up2_coef(y, H, ky) : 0.f;
+            wx[t] = (xx >= 0 && xx < Wo) ? up2_coef(xx, W, kx) : 0.f;
+            oz[t] = z < 0 ? 0 : (z >= Do ? Do - 1 : z);            // clamped: the weight is 0 outside
+            oy[t] = y < 0 ? 0 : (y >= Ho ? Ho - 1 : y);
+            ox[t] = xx < 0 ? 0 : (xx >= Wo ? Wo - 1 : xx);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float4 ay = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const size_t row = ((size_t)oz[a] * Ho + oy[b]) * Wo;
+                const float4 p0 = dp[(row + ox[0]) * 4 + q], p1 = dp[(row + ox[1]) * 4 + q], p2 = dp[(row + ox[2]) * 4 + q], p3 = dp[(row + ox[3]) * 4 + q];
+                ay.x += wy[b] * (wx[0] * p0.x + wx[1] * p1.x + wx[2] * p2.x + wx[3] * p3.x);
+                ay.y += wy[b] * (wx[0] * p0.y + wx[1] * p1.y + wx[2] * p2.y + wx[3] * p3.y);
+                ay.z += wy[b] * (wx[0] * p0.z + wx[1] * p1.z + wx[2] * p2.z + wx[3] * p3.z);
+                ay.w += wy[b] * (wx[0] * p0.w + wx[1] * p1.w + wx[2] * p2.w + wx[3] * p3.w);
+            }
+            acc.x += wz[a] * ay.x; acc.y += wz[a] * ay.y; acc.z += wz[a] * ay.z; acc.w += wz[a] * ay.w;
+        }
+        op[f] = acc;
+    }
+}
+int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s) {
+    RU_REQUIRE(C % 16 == 0, "up2_bwd16: C must be a multiple of 16");
+    hipLaunchKernelGGL(up2_bwd16_kernel, c16_grid((size_t)D * H * W, N * (C / 16), 8192), dim3(256), 0, s, dy, dx, D, H, W);
+    RU_CHECK_LAUNCH("up2_bwd16_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ space-to-depth for the 2x2x2 stride-2 conv (model.py:361-363)
+// y[n][tap*CB + cb][zo][yo][xo][16] = x[n][cb][2zo+i][2yo+j][2xo+k][16], tap = i*4 + j*2 + k: channel index of the
+// space-to-depth tensor = tap*Cin + c (the weights are packed to that order by pack_down16).
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void s2d16_kernel(const float* __restrict__ src, float* __restrict__ dst, int CB, int D, int H, int W) {
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+    const size_t Vi = (size_t)D * H * W, Vo = Vi / 8;
+    const int nk = blockIdx.y;                               // n * 8*CB + tap*CB + cb
+    const int n = nk / (8 * CB), kb = nk - n * 8 * CB;
+    const int tap = kb / CB, cb = kb - tap * CB;
+    const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
+    const size_t fine_base = ((size_t)n * CB + cb) * Vi * 4, coarse_base = (size_t)nk * Vo * 4;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vo * 4; f += (size_t)gridDim.x * 256) {
+        const int q = (int)(f & 3);
+        size_t r = f >> 2;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int zo = (int)(r / Ho);
+        const size_t fi = ((((size_t)(2 * zo + i) * H + 2 * yo + j) * W + 2 * xo + k) << 2) + q;
+        if (INVERSE) reinterpret_cast<float4*>(dst)[fine_base + fi] = reinterpret_cast<const float4*>(src)[coarse_base + f];
+        else reinterpret_cast<float4*>(dst)[coarse_base + f] = reinterpret_cast<const float4*>(src)[fine_base + fi];
+    }
+}
+int s2d16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {   // D,H,W = fine extents (even)
+    RU_REQUIRE(C % 16 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "s2d16: bad shape");
+    hipLaunchKernelGGL(s2d16_kernel<false>, c16_grid((size_t)D * H * W / 8, N * 8 * (C / 16), 1024), dim3(256), 0, s, x, y, C / 16, D, H, W);
+    RU_CHECK_LAUNCH("s2d16_kernel");
+    return RU_OK;
+}
+int d2s16_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s) {   // x (fine, C channels) overwritten
+    RU_REQUIRE(C % 16 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "d2s16: bad shape");
+    hipLaunchKernelGGL(s2d16_kernel<true>, c16_grid((size_t)D * H * W / 8, N * 8 * (C / 16), 1024), dim3(256), 0, s, y, x, C / 16, D, H, W);
+    RU_CHECK_LAUNCH("d2s16_kernel");
+    return RU_OK;
+}
+
+// weights of the 2x2x2 stride-2 conv [Cout][Cin][8] -> wd[Cout][tap*Cin + c] (forward) and wdT[tap*Cin + c][Cout] (data gradient)
+__global__ void pack_down16_kernel(const float* __restrict__ w, float* __restrict__ wd, float* __restrict__ wdT, int Cout, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin * 8) return;
+    const int tap = i & 7, c = (i >> 3) % Cin, o = i / (8 * Cin);
+    const float v = w[i];
+    wd[(size_t)o * 8 * Cin + tap * Cin + c] = v;
+    wdT[(size_t)(tap * Cin + c) * Cout + o] = v;
+}
+int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin, hipStream_t s) {
+    const int total = Cout * Cin * 8;
+    hipLaunchKernelGGL(pack_down16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, wd, wdT, Cout, Cin);
+    RU_CHECK_LAUNCH("pack_down16_kernel");
+    return RU_OK;
+}
+
+// ------------------------------------------------------------------ 1x1x1 convolution on C16 tensors (model.py:393,401; concat of model.py:424)
+// y[v][o] = act( sum_c wm[o][c] * xcat[v][c] ) (+ add) on v_mfma_f32_16x16x4_f32 (exact f32): M = 16 output channels,
+// N = 16 voxels, K = input channels.  Both operands are aligned float4 loads -- lane (r = l&15, g = l>>4) reads channels
+// 4g..4g+3 of a 16-channel block of voxel r (B) / of weight row o0 + r (A) -- and MFMA step e consumes element e, i.e. the
+// K index of lane group g in step e is channel 4g + e on both sides.  D: lane holds output channels 4g..4g+3 of voxel r:
+// one aligned float4 of the C16 output.  A wave owns 64 voxels x COB*16 output channels.
+template <int COB>
+__global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nvt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.z, cog = blockIdx.y;
+    const int vt = blockIdx.x * 4 + wave;
+    if (vt >= nvt) return;
+    const size_t V = a.V;
+    const size_t v0 = (size_t)vt * 64;
+    const int r = lane & 15, g = lane >> 4;
+    const int nkb0 = a.C0 >> 4, nkb1 = a.C1 >> 4, nkb = nkb0 + nkb1, CBo = a.Cout >> 4;
+    size_t vb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const size_t v = v0 + 16 * t + r; vb[t] = (v < V ? v : V - 1) * 16 + 4 * g; }
+    const float* wrow[COB];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb) {
+        const int cob = cog * COB + cb;
+        wrow[cb] = a.wT + (size_t)((cob < CBo ? cob : CBo - 1) * 16 + r) * a.ldw + 4 * g;
+    }
+    f32x4_c16 acc[4][COB];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) acc[t][cb] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kb = 0; kb < nkb; ++kb) {
+        const float* src = kb < nkb0 ? a.x0 + ((size_t)(n * nkb0 + kb) * V) * 16 : a.x1 + ((size_t)(n * nkb1 + kb - nkb0) * V) * 16;
+        float4 xb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xb[t] = *reinterpret_cast<const float4*>(src + vb[t]);
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {
+            const float4 wv = *reinterpret_cast<const float4*>(wrow[cb] + kb * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xb[t].x, acc[t][cb], 0, 0, 0);
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xb[t].y, acc[t][cb], 0, 0, 0);
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xb[t].z, acc[t][cb], 0, 0, 0);
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xb[t].w, acc[t][cb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const size_t v = v0 + 16 * t + r;
+        if (v >= V) continue;
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {
+            const int cob = cog * COB + cb;
+            if (cob >= CBo) continue;
+            const size_t idx = ((size_t)(n * CBo + cob) * V + v) * 16 + 4 * g;
+            float4 o = make_float4(lrelu(acc[t][cb][0], a.out_slope), lrelu(acc[t][cb][1], a.out_slope),
+                                   lrelu(acc[t][cb][2], a.out_slope), lrelu(acc[t][cb][3], a.out_slope));
+            if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+            *reinterpret_cast<float4*>(a.y + idx) = o;
+        }
+    }
+}
+// a.wT is read as wm[Cout][C0 + C1] with row pitch a.ldw (row-major OUT x IN: the reference layout of a 1x1x1 weight)
+int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
+    RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0, "conv1_16: bad shape");
+    RU_REQUIRE(a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Cout % 16 == 0 && a.ldw >= a.C0 + a.C1 && a.ldw % 4 == 0, "conv1_16: channels must be multiples of 16");
+    const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
+    const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
+    dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
+    if (cob == 4) hipLaunchKernelGGL(conv1_16_kernel<4>, grid, dim3(256), 0, s, a, nvt);
+    else if (cob == 2) hipLaunchKernelGGL(conv1_16_kernel<2>, grid, dim3(256), 0, s, a, nvt);
+    else hipLaunchKernelGGL(conv1_16_kernel<1>, grid, dim3(256), 0, s, a, nvt);
+    RU_CHECK_LAUNCH("conv1_16_kernel");
+    return RU_OK;
+}
+
+}  // namespace ru

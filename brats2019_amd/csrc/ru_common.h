@@ -83,6 +83,7 @@ struct Wgrad3Args {
     size_t ws_bytes;
     int N, Cin, Cout, D, H, W;
     int mode;                // RU_PREC_F32 / RU_PREC_BF16X3 (split-bf16 kernel, wgrad_sb.hip; needs W % 4 == 0)
+    int x_c16, dy_c16;       // voxel-major x / dy (split-bf16 kernel only); 0 = NCDHW
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
@@ -99,6 +100,8 @@ struct Wgrad1Args {
     size_t ws_bytes;
     int N, Cin, Cout;
     size_t V;
+    int c16;                 // x and dy are voxel-major (C16); Cin, Cout multiples of 16
+    int tap_split;           // > 0: the Cin index is tap*tap_split + c of a 2x2x2 conv: written to dw[o*ldw + c*8 + tap]
 };
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s);
@@ -154,6 +157,22 @@ int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, 
 int up2_bwd_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
 int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bias_grad_workspace_bytes(int N, int C, size_t V);
+
+// ------------------------------------------------------------------ the same on the voxel-major layout C16 (pointwise_c16.hip)
+int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s);
+int gn_bwd_tiles16(size_t V);
+int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
+int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef, float slope, float* dx,
+                          int N, int C, size_t V, hipStream_t s);
+int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);      // D,H,W = coarse extents
+int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
+// space-to-depth with channel order tap*C + c (tap = i*4 + j*2 + k); D,H,W = fine extents
+int s2d16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);
+int d2s16_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s);
+int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin, hipStream_t s);       // [Cout][Cin][8] -> [Cout][8*Cin], [8*Cin][Cout]
+// Conv1Args on C16 tensors; a.wT is read as wm[Cout][C0 + C1] (row-major out x in, pitch a.ldw)
+int conv1_16_launch(const Conv1Args& a, hipStream_t s);
 
 int crit_tiles(size_t total);
 int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C, size_t V, float bgw, void* ws, size_t ws_bytes, hipStream_t s);

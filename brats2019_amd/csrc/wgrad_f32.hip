@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 4) void wgrad3_f32_kernel(const Wgrad3Args a, 
 // dw[o*so + c*sc + tap] = sum_parts partials[part][tap][o][c].  256 threads = 64 outputs x 4 partial slices (the slices are
 // combined in a fixed order through LDS: deterministic), so a 512-partial reduction is 128 loads deep instead of 512.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
-                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc) {
+                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc, int split) {
     __shared__ float red[4][64];
     const int lane_o = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane_o;
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (; k < k1; ++k) s0 += p[(size_t)k * stride];
     red[slice][lane_o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (slice == 0 && ok) dw[(size_t)o * so + (size_t)c * sc + tap] = (red[0][lane_o] + red[1][lane_o]) + (red[2][lane_o] + red[3][lane_o]);
+    // split > 0: c = t*split + ci enumerates (tap t, channel ci) of a 2x2x2 conv whose gradient layout is [o][ci][8]
+    const size_t dst = split > 0 ? (size_t)o * so + (size_t)(c % split) * 8 + c / split : (size_t)o * so + (size_t)c * sc + tap;
+    if (slice == 0 && ok) dw[dst] = (red[0][lane_o] + red[1][lane_o]) + (red[2][lane_o] + red[3][lane_o]);
 }
 
 struct W3Choice { int tz, ty, ot, ct, nbx, ngroups, ncg; };
@@ -354,13 +356,17 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
     const int total = 27 * a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27);
+                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
 }
 
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.D > 0 && a.H > 0 && a.W > 0, "wgrad3: bad shape");
+    if (a.x_c16 || a.dy_c16) {
+        RU_REQUIRE(a.mode == RU_PREC_BF16X3, "wgrad3: voxel-major tensors need the split-bf16 kernel");
+        return wgrad3_sb_launch(a, s);
+    }
     if (a.mode == RU_PREC_BF16X3 && (a.W & 3) == 0) return wgrad3_sb_launch(a, s);
     const W3Choice c = wgrad3_choose(a.N, a.Cin, a.Cout, a.D, a.H, a.W);
     if (a.ws_bytes < wgrad3_f32_workspace_bytes(a.N, a.Cin, a.Cout, a.D, a.H, a.W) || !a.ws) {
@@ -398,7 +404,37 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
         const int n = (int)(t / nchunk);
         const size_t v0 = (size_t)(t % nchunk) * W1_VC;
         __syncthreads();
-        if ((V & 3) == 0) {
+        if (a.c16) {
+            // voxel-major tensors: one aligned float4 = 4 channels of one voxel; scattered into the [channel][voxel] LDS rows
+            constexpr int ND = OT * 16 * W1_VC / 4 / 256, NX = CT * 16 * W1_VC / 4 / 256;
+            float4 dv[ND], xv[NX];
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
+                const bool ok = v0 + r < V;
+                const float4 t4 = *reinterpret_cast<const float4*>(a.dy + (((size_t)n * (a.Cout >> 4) + (o0 >> 4) + p) * V + (ok ? v0 + r : 0)) * 16 + 4 * q);
+                dv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
+                const bool ok = v0 + r < V;
+                const float4 t4 = *reinterpret_cast<const float4*>(a.x + (((size_t)n * (a.Cin >> 4) + (c0 >> 4) + p) * V + (ok ? v0 + r : 0)) * 16 + 4 * q);
+                xv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
+                float* d = dys + (p * 16 + 4 * q) * W1_RS + r;
+                d[0] = dv[j].x; d[W1_RS] = dv[j].y; d[2 * W1_RS] = dv[j].z; d[3 * W1_RS] = dv[j].w;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
+                float* d = xs + (p * 16 + 4 * q) * W1_RS + r;
+                d[0] = xv[j].x; d[W1_RS] = xv[j].y; d[2 * W1_RS] = xv[j].z; d[3 * W1_RS] = xv[j].w;
+            }
+        } else if ((V & 3) == 0) {
             // aligned float4 loads, all issued before the first LDS store (row stride 258: 8-byte aligned float2 stores)
             constexpr int Q4 = W1_VC / 4;
             constexpr int ND = OT * 16 * Q4 / 256, NX = CT * 16 * Q4 / 256;
@@ -518,13 +554,14 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
     RU_CHECK_LAUNCH("wgrad1_f32_kernel");
     const int total = a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 1, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.ldw, 1);
+                       a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
 }
 
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cin, "wgrad1: bad shape");
+    RU_REQUIRE(!a.c16 || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "wgrad1: C16 tensors need channel counts that are multiples of 16");
     const W1Choice c = wgrad1_choose(a.N, a.Cin, a.Cout, a.V);
     if (!a.ws || a.ws_bytes < wgrad1_workspace_bytes(a.N, a.Cin, a.Cout, a.V)) {
         set_error("wgrad1: workspace too small");

@@ -27,7 +27,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // defined in wgrad_f32.hip
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin,
-                                    float* __restrict__ dw, int so, int sc);
+                                    float* __restrict__ dw, int so, int sc, int split);
 
 template <int TZ, int TY, int OT>
 struct WSB {
@@ -117,7 +117,28 @@ __device__ __forceinline__ void wsb_compute(const u32x4* __restrict__ xL, const 
     }
 }
 
-template <int TZ, int TY, int OT>
+// 8 floats -> 8 bf16 hi + 8 bf16 lo (one 16-byte packet each)
+__device__ __forceinline__ void wsplit8(const float (&t)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16x2 h;
+        h[0] = (__bf16)t[2 * i];
+        h[1] = (__bf16)t[2 * i + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hb << 16);
+        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+        bf16x2 l;
+        l[0] = (__bf16)(t[2 * i] - h0);
+        l[1] = (__bf16)(t[2 * i + 1] - h1);
+        hi[i] = hb;
+        lo[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+// X16 / DY16: the x / dy tensor is voxel-major (C16, [N][C/16][D][H][W][16]).  The packets need 8 consecutive x voxels of
+// ONE channel, so a thread loads the aligned float4 (4 channels) of 8 (x) or 4 (dy) consecutive voxels and transposes in
+// registers: 4 channels x 8 voxels -> 4 hi + 4 lo packets.  Every load instruction of a wave reads whole 64-byte voxels.
+template <int TZ, int TY, int OT, bool X16, bool DY16>
 __global__ __launch_bounds__(256, 2) void wgrad3_sb_kernel(const Wgrad3Args a, float* __restrict__ partials,
                                                           int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WSB<TZ, TY, OT>;
@@ -157,76 +178,163 @@ __global__ __launch_bounds__(256, 2) void wgrad3_sb_kernel(const Wgrad3Args a, f
         const int n = b / ntz;
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * 16;
         __syncthreads();                                   // previous tile's reads are done
-        // ---- x halo tile: 16 channels x XROWS rows x 6 aligned float4 -> fused transform -> hi/lo packets (8-byte halves)
-        constexpr int XB = XBATCH;                                   // float4 loads in flight per thread and batch (register budget)
+        if constexpr (X16) {
+            // ---- x halo tile, C16: item = (halo row, 8-column block, channel quad): 8 float4 loads -> 4 channels x 8 voxels
+            constexpr int XI16 = XROWS * 12, NX16 = (XI16 + 255) / 256;
+            const float* xb = a.x + ((size_t)(n * (a.Cin >> 4) + cgp) * DHW) * 16;
 #pragma unroll 1
-        for (int jb = 0; jb < NXI; jb += XB) {
-            float4 v[XB];
-            int live[XB];
-#pragma unroll
-            for (int u = 0; u < XB; ++u) {
-                const int it = tid + (jb + u) * 256;
-                const int ch = it / (XROWS * 6), rem = it - ch * (XROWS * 6);
-                const int row = rem / 6, q = rem - row * 6;
+            for (int rd = 0; rd < NX16; ++rd) {
+                const int it = tid + rd * 256;
+                const int cq = it & 3, rest = it >> 2;
+                const int row = rest / 3, cb = rest - row * 3;
                 const int hz = row / HY, hy = row - hz * HY;
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q, c = c0 + ch;
-                const bool ok = it < XITEMS && c < a.Cin && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
-                const size_t off = ok ? ((size_t)n * a.Cin + c) * DHW + (size_t)gz * HW + (size_t)gy * W + gx : 0;
-                v[u] = *reinterpret_cast<const float4*>(a.x + off);          // unconditional, clamped
-                live[u] = ok ? 1 : 0;
-            }
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx0 = x0 - 4 + 8 * cb;
+                const bool rok = it < XI16 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H;
+                const size_t rbase = rok ? ((size_t)gz * H + gy) * W : 0;
+                float4 v[8];
+                unsigned vm = 0;
 #pragma unroll
-            for (int u = 0; u < XB; ++u) {
-                const int it = tid + (jb + u) * 256;
-                if (it >= XITEMS) continue;
-                const int ch = it / (XROWS * 6), rem = it - ch * (XROWS * 6);
-                const int row = rem / 6, q = rem - row * 6;
-                const int c = c0 + ch < a.Cin ? c0 + ch : a.Cin - 1;
-                const float m = live[u] ? 1.f : 0.f;                         // dead lanes: (0, 0) -> exact zeros without a select
-                float sc = m, sh = 0.f;
-                if (xform) { sc = a.in_scale[n * a.Cin + c] * m; sh = a.in_shift[n * a.Cin + c] * m; }   // wave-uniform branch
-                float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    t[e] = fmaf(t[e], sc, sh);
-                    t[e] = fmaxf(t[e], t[e] * slope);                        // LeakyReLU for 0 < slope <= 1 (zero stays zero)
+                for (int j = 0; j < 8; ++j) {
+                    const int gx = gx0 + j;
+                    const bool ok = rok && (unsigned)gx < (unsigned)W;
+                    vm |= ok ? (1u << j) : 0u;
+                    v[j] = *reinterpret_cast<const float4*>(xb + (rbase + (ok ? gx : 0)) * 16 + 4 * cq);     // unconditional, clamped
                 }
-                u32x2 hi, lo;
-                split4(t, hi, lo);
-                const int pk = ((q >> 1) * 16 + ch) * XRP + row;             // [cb][c][row]
-                *(reinterpret_cast<u32x2*>(xL + pk) + (q & 1)) = hi;
-                *(reinterpret_cast<u32x2*>(xL + 3 * XPLANE + pk) + (q & 1)) = lo;
+                if (it >= XI16) continue;
+                float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (xform) {
+                    sc4 = *reinterpret_cast<const float4*>(a.in_scale + n * a.Cin + c0 + 4 * cq);
+                    sh4 = *reinterpret_cast<const float4*>(a.in_shift + n * a.Cin + c0 + 4 * cq);
+                }
+                const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = k == 0 ? v[j].x : (k == 1 ? v[j].y : (k == 2 ? v[j].z : v[j].w));
+                        const float u = fmaf(f, scv[k], shv[k]);
+                        t[j] = ((vm >> j) & 1u) ? fmaxf(u, u * slope) : 0.f;       // zero padding applies to the ACTIVATED tensor
+                    }
+                    u32x4 hi, lo;
+                    wsplit8(t, hi, lo);
+                    const int pk = (cb * 16 + 4 * cq + k) * XRP + row;             // [cb][c][row]
+                    xL[pk] = hi;
+                    xL[3 * XPLANE + pk] = lo;
+                }
+            }
+        } else {
+            // ---- x halo tile: 16 channels x XROWS rows x 6 aligned float4 -> fused transform -> hi/lo packets (8-byte halves)
+            constexpr int XB = XBATCH;                                   // float4 loads in flight per thread and batch (register budget)
+    #pragma unroll 1
+            for (int jb = 0; jb < NXI; jb += XB) {
+                float4 v[XB];
+                int live[XB];
+    #pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int it = tid + (jb + u) * 256;
+                    const int ch = it / (XROWS * 6), rem = it - ch * (XROWS * 6);
+                    const int row = rem / 6, q = rem - row * 6;
+                    const int hz = row / HY, hy = row - hz * HY;
+                    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 - 4 + 4 * q, c = c0 + ch;
+                    const bool ok = it < XITEMS && c < a.Cin && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && gx >= 0 && gx < W;
+                    const size_t off = ok ? ((size_t)n * a.Cin + c) * DHW + (size_t)gz * HW + (size_t)gy * W + gx : 0;
+                    v[u] = *reinterpret_cast<const float4*>(a.x + off);          // unconditional, clamped
+                    live[u] = ok ? 1 : 0;
+                }
+    #pragma unroll
+                for (int u = 0; u < XB; ++u) {
+                    const int it = tid + (jb + u) * 256;
+                    if (it >= XITEMS) continue;
+                    const int ch = it / (XROWS * 6), rem = it - ch * (XROWS * 6);
+                    const int row = rem / 6, q = rem - row * 6;
+                    const int c = c0 + ch < a.Cin ? c0 + ch : a.Cin - 1;
+                    const float m = live[u] ? 1.f : 0.f;                         // dead lanes: (0, 0) -> exact zeros without a select
+                    float sc = m, sh = 0.f;
+                    if (xform) { sc = a.in_scale[n * a.Cin + c] * m; sh = a.in_shift[n * a.Cin + c] * m; }   // wave-uniform branch
+                    float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        t[e] = fmaf(t[e], sc, sh);
+                        t[e] = fmaxf(t[e], t[e] * slope);                        // LeakyReLU for 0 < slope <= 1 (zero stays zero)
+                    }
+                    u32x2 hi, lo;
+                    split4(t, hi, lo);
+                    const int pk = ((q >> 1) * 16 + ch) * XRP + row;             // [cb][c][row]
+                    *(reinterpret_cast<u32x2*>(xL + pk) + (q & 1)) = hi;
+                    *(reinterpret_cast<u32x2*>(xL + 3 * XPLANE + pk) + (q & 1)) = lo;
+                }
             }
         }
-        // ---- dy tile: OT*16 channels x DROWS rows x 4 float4
-        {
-            float4 v[NDI];
-            int live[NDI];
+        if constexpr (DY16) {
+            // ---- dy tile, C16: item = (row, 4-voxel quarter, channel quad): 4 float4 loads -> 4 channels x 4 voxels (half packets)
+            constexpr int DI16 = DROWS * 4 * OT * 4, ND16 = (DI16 + 255) / 256;
 #pragma unroll
-            for (int j = 0; j < NDI; ++j) {
-                const int it = tid + j * 256;
-                const int ch = it / (DROWS * 4), rem = it - ch * (DROWS * 4);
-                const int row = rem / 4, q = rem - row * 4;
+            for (int rd = 0; rd < ND16; ++rd) {
+                const int it = tid + rd * 256;
+                const int oq = it & (OT * 4 - 1), rest = it / (OT * 4);
+                const int q = rest & 3, row = rest >> 2;
                 const int z = row / TY, y = row - z * TY;
-                const int gz = z0 + z, gy = y0 + y, gx = x0 + 4 * q, o = o0 + ch;
-                const bool ok = it < DITEMS && o < a.Cout && gz < D && gy < H && gx < W;
-                const size_t off = ok ? ((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx : 0;
-                v[j] = *reinterpret_cast<const float4*>(a.dy + off);
-                live[j] = ok ? 1 : 0;
-            }
+                const int gz = z0 + z, gy = y0 + y;
+                const bool rok = it < DI16 && gz < D && gy < H;
+                const float* db = a.dy + ((size_t)(n * (a.Cout >> 4) + og * OT + (oq >> 2)) * DHW) * 16 + 4 * (oq & 3);
+                const size_t rbase = rok ? ((size_t)gz * H + gy) * W : 0;
+                float4 v[4];
+                unsigned vm = 0;
 #pragma unroll
-            for (int j = 0; j < NDI; ++j) {
-                const int it = tid + j * 256;
-                if (it >= DITEMS) continue;
-                const int ch = it / (DROWS * 4), rem = it - ch * (DROWS * 4);
-                const int row = rem / 4, q = rem - row * 4;
-                const float m = live[j] ? 1.f : 0.f;
-                float t[4] = {v[j].x * m, v[j].y * m, v[j].z * m, v[j].w * m};
-                u32x2 hi, lo;
-                split4(t, hi, lo);
-                const int pk = (q >> 1) * DPLANE + ch * DRP + row;           // [xhalf][o][row]
-                *(reinterpret_cast<u32x2*>(dL + pk) + (q & 1)) = hi;
-                *(reinterpret_cast<u32x2*>(dL + 2 * DPLANE + pk) + (q & 1)) = lo;
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = x0 + 4 * q + j;
+                    const bool ok = rok && gx < W;
+                    vm |= ok ? (1u << j) : 0u;
+                    v[j] = *reinterpret_cast<const float4*>(db + (rbase + (ok ? gx : 0)) * 16);
+                }
+                if (it >= DI16) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float f = k == 0 ? v[j].x : (k == 1 ? v[j].y : (k == 2 ? v[j].z : v[j].w));
+                        t[j] = ((vm >> j) & 1u) ? f : 0.f;
+                    }
+                    u32x2 hi, lo;
+                    split4(t, hi, lo);
+                    const int pk = (q >> 1) * DPLANE + (4 * oq + k) * DRP + row;   // [xhalf][o][row]
+                    *(reinterpret_cast<u32x2*>(dL + pk) + (q & 1)) = hi;
+                    *(reinterpret_cast<u32x2*>(dL + 2 * DPLANE + pk) + (q & 1)) = lo;
+                }
+            }
+        } else {
+            // ---- dy tile: OT*16 channels x DROWS rows x 4 float4
+            {
+                float4 v[NDI];
+                int live[NDI];
+    #pragma unroll
+                for (int j = 0; j < NDI; ++j) {
+                    const int it = tid + j * 256;
+                    const int ch = it / (DROWS * 4), rem = it - ch * (DROWS * 4);
+                    const int row = rem / 4, q = rem - row * 4;
+                    const int z = row / TY, y = row - z * TY;
+                    const int gz = z0 + z, gy = y0 + y, gx = x0 + 4 * q, o = o0 + ch;
+                    const bool ok = it < DITEMS && o < a.Cout && gz < D && gy < H && gx < W;
+                    const size_t off = ok ? ((size_t)n * a.Cout + o) * DHW + (size_t)gz * HW + (size_t)gy * W + gx : 0;
+                    v[j] = *reinterpret_cast<const float4*>(a.dy + off);
+                    live[j] = ok ? 1 : 0;
+                }
+    #pragma unroll
+                for (int j = 0; j < NDI; ++j) {
+                    const int it = tid + j * 256;
+                    if (it >= DITEMS) continue;
+                    const int ch = it / (DROWS * 4), rem = it - ch * (DROWS * 4);
+                    const int row = rem / 4, q = rem - row * 4;
+                    const float m = live[j] ? 1.f : 0.f;
+                    float t[4] = {v[j].x * m, v[j].y * m, v[j].z * m, v[j].w * m};
+                    u32x2 hi, lo;
+                    split4(t, hi, lo);
+                    const int pk = (q >> 1) * DPLANE + ch * DRP + row;           // [xhalf][o][row]
+                    *(reinterpret_cast<u32x2*>(dL + pk) + (q & 1)) = hi;
+                    *(reinterpret_cast<u32x2*>(dL + 2 * DPLANE + pk) + (q & 1)) = lo;
+                }
             }
         }
         __syncthreads();
@@ -274,36 +382,42 @@ size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) 
     return (size_t)c.nbx * 27 * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
 }
 
-template <int OT>
+template <int OT, bool X16, bool DY16>
 static int wsb_cfg(const Wgrad3Args& a, const WSBChoice& c, hipStream_t s) {
     constexpr int TZ = OT == 1 ? 4 : 2;
     using P = WSB<TZ, 4, OT>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_sb_kernel<TZ, 4, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_sb)");
         attr_done = true;
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
-    hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
+    hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_sb_kernel");
     const int total = 27 * a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27);
+                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
 }
 
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s) {
-    RU_REQUIRE((a.W & 3) == 0, "wgrad3_sb: W must be a multiple of 4");
+    RU_REQUIRE((a.W & 3) == 0 || (a.x_c16 && a.dy_c16), "wgrad3_sb: W must be a multiple of 4 for NCDHW tensors");
+    RU_REQUIRE(!a.x_c16 || a.Cin % 16 == 0, "wgrad3_sb: C16 x needs Cin %% 16 == 0");
+    RU_REQUIRE(!a.dy_c16 || a.Cout % 16 == 0, "wgrad3_sb: C16 dy needs Cout %% 16 == 0");
     const WSBChoice c = wsb_choose(a.N, a.Cin, a.Cout, a.D, a.H, a.W);
     if (!a.ws || a.ws_bytes < wgrad3_sb_workspace_bytes(a.N, a.Cin, a.Cout, a.D, a.H, a.W)) {
         set_error("wgrad3_sb: workspace too small");
         return RU_ENOMEM;
     }
-    if (c.ot == 2) return wsb_cfg<2>(a, c, s);
-    return wsb_cfg<1>(a, c, s);
+    if (c.ot == 2) {
+        if (a.x_c16) return a.dy_c16 ? wsb_cfg<2, true, true>(a, c, s) : wsb_cfg<2, true, false>(a, c, s);
+        return a.dy_c16 ? wsb_cfg<2, false, true>(a, c, s) : wsb_cfg<2, false, false>(a, c, s);
+    }
+    if (a.x_c16) return a.dy_c16 ? wsb_cfg<1, true, true>(a, c, s) : wsb_cfg<1, true, false>(a, c, s);
+    return a.dy_c16 ? wsb_cfg<1, false, true>(a, c, s) : wsb_cfg<1, false, false>(a, c, s);
 }
 
 }  // namespace ru

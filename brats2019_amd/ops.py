@@ -254,3 +254,20 @@ def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False):
     L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, int(in_c16) | (int(out_c16) << 1),
                                 L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd_l")
     return y
+
+
+def conv3d_bwd_weight_layout(x, dy, x_c16=False, dy_c16=False):
+    """3x3x3 split-bf16 weight gradient on tensors in NCDHW or C16 storage."""
+    x, dy = _prep(x), _prep(dy)
+    if x_c16:
+        n, cb, d, h, wd, _ = (int(v) for v in x.shape)
+        cin = cb * 16
+    else:
+        n, cin, d, h, wd = _dims5(x)
+    cout = int(dy.shape[1]) * 16 if dy_c16 else int(dy.shape[1])
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3), x.device)
+    L.check(lib.ru_conv3d_bwd_weight_l(L.f32(x), L.f32(dy), L.f32(dw), n, cin, cout, d, h, wd, int(x_c16) | (int(dy_c16) << 1),
+                                       L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_bwd_weight_l")
+    return dw

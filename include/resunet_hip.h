@@ -182,6 +182,10 @@ int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int 
 int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y,
                     int N, int Cin, int Cout, int D, int H, int W, int flags,
                     void* ws, size_t ws_bytes, ru_stream_t stream);
+/* weight gradient; flags: bit 0 = x is C16, bit 1 = dy is C16 */
+int ru_conv3d_bwd_weight_l(const float* x, const float* dy, float* dw,
+                           int N, int Cin, int Cout, int D, int H, int W, int flags,
+                           void* ws, size_t ws_bytes, ru_stream_t stream);
 
 /* ---------------------------------------------------------------- evaluation metric (metrics.py:108-133, `Dice.update`)
  * counts[(n*C + c)*2 + {0,1}] = { #(p > 0.5 and g > 0.5), #(p > 0.5) + #(g > 0.5) } over the V voxels of sample n, channel c.

@@ -34,3 +34,16 @@ def test_conv3_layouts_equal_ncdhw(shape, in16, out16):
     if out16:
         y = ops.from_c16(y)
     assert torch.equal(y, ref), float((y - ref).abs().max())
+
+
+@pytest.mark.parametrize("x16,dy16", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 32, 32), (1, 32, 32, 16, 16, 32), (2, 16, 32, 8, 16, 16)])
+def test_wgrad3_layouts_equal_ncdhw(shape, x16, dy16):
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = shape
+    x = _rand(n, cin, d, h, w, seed=3)
+    dy = _rand(n, cout, d, h, w, seed=4)
+    ref = ops.conv3d_bwd_weight(x, dy, 3, precision="bf16x3")
+    ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+    dw = ops.conv3d_bwd_weight_layout(ops.to_c16(x) if x16 else x, ops.to_c16(dy) if dy16 else dy, x_c16=x16, dy_c16=dy16)
+    assert torch.equal(dw, ref), float((dw - ref).abs().max())

@@ -25,6 +25,10 @@ for _ in range(launches):
         L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, flags, L.ptr(ws), ws.numel(), L.stream()), "fwd_l")
     elif kind == "fwd":
         L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, 3, L.PRECISIONS[prec], L.ptr(ws), ws.numel(), L.stream()), "fwd")
+    elif flags:
+        L.check(lib.ru_conv3d_bwd_weight_l(L.f32(x), L.f32(y), L.f32(dw), n, c, c, size, size, size, flags, L.ptr(ws), ws.numel(), L.stream()), "wgrad_l")
+    elif prec == "bf16x3":
+        L.check(lib.ru_conv3d_bwd_weight_p(L.f32(x), L.f32(y), L.f32(dw), None, n, c, c, size, size, size, 3, L.PRECISIONS[prec], L.ptr(ws), ws.numel(), L.stream()), "wgrad")
     else:
         L.check(lib.ru_conv3d_bwd_weight(L.f32(x), L.f32(y), L.f32(dw), None, n, c, c, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "wgrad")
 torch.cuda.synchronize()
