@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libresunet_hip.so")
-SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "wgrad_sb.hip", "pointwise.hip", "pointwise_c16.hip", "engine.hip"]
+SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "wgrad_sb.hip", "wgrad_tr.hip", "pointwise.hip", "pointwise_c16.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(CSRC, "conv3_epilogue.hpp"), os.path.join(CSRC, "pw_helpers.hpp"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -52,7 +52,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with cf.ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
     for _, warn in results:

@@ -89,6 +89,9 @@ size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);   
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
 size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s);
+// both tensors voxel-major: transpose-read kernel (wgrad_tr.hip); workspace 0 if the channel counts do not fit
+size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
+int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s);
 
 // 1x1x1: dw[o][c] = sum_{n,v} dy[n][o][v] * x[n][c][v]; result written to dw[o*ldw + c] (ldw >= Cin)
 struct Wgrad1Args {

@@ -335,7 +335,9 @@ static size_t wgrad3_f32_workspace_bytes(int N, int Cin, int Cout, int D, int H,
 }
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
     const size_t a = wgrad3_f32_workspace_bytes(N, Cin, Cout, D, H, W), b = wgrad3_sb_workspace_bytes(N, Cin, Cout, D, H, W);
-    return a > b ? a : b;
+    const size_t c = wgrad3_tr_workspace_bytes(N, Cin, Cout, D, H, W);
+    const size_t m = a > b ? a : b;
+    return m > c ? m : c;
 }
 
 template <int TZ, int TY, int OT, int CT>
@@ -365,6 +367,7 @@ int wgrad3_launch(const Wgrad3Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.D > 0 && a.H > 0 && a.W > 0, "wgrad3: bad shape");
     if (a.x_c16 || a.dy_c16) {
         RU_REQUIRE(a.mode == RU_PREC_BF16X3, "wgrad3: voxel-major tensors need the split-bf16 kernel");
+        if (a.x_c16 && a.dy_c16) return wgrad3_tr_launch(a, s);
         return wgrad3_sb_launch(a, s);
     }
     if (a.mode == RU_PREC_BF16X3 && (a.W & 3) == 0) return wgrad3_sb_launch(a, s);

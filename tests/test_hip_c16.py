@@ -46,4 +46,10 @@ def test_wgrad3_layouts_equal_ncdhw(shape, x16, dy16):
     ref = ops.conv3d_bwd_weight(x, dy, 3, precision="bf16x3")
     ref = ref[0] if isinstance(ref, (tuple, list)) else ref
     dw = ops.conv3d_bwd_weight_layout(ops.to_c16(x) if x16 else x, ops.to_c16(dy) if dy16 else dy, x_c16=x16, dy_c16=dy16)
-    assert torch.equal(dw, ref), float((dw - ref).abs().max())
+    if x16 and dy16:
+        # both voxel-major: the transpose-read kernel (wgrad_tr.hip) sums the same split-bf16 products in another order
+        exact = torch.nn.grad.conv3d_weight(x.double(), (cout, cin, 3, 3, 3), dy.double(), padding=1).float()
+        tol = 2e-5 * float(exact.abs().max())
+        assert float((dw - exact).abs().max()) < tol and float((ref - exact).abs().max()) < tol
+    else:
+        assert torch.equal(dw, ref), float((dw - ref).abs().max())
