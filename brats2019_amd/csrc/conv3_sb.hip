@@ -652,55 +652,53 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
             }
             if (!(dbg & 4)) {
-                // software pipeline over two register sets (M-tiles 0..MT/2-1 and MT/2..MT-1): the A fragments of the next
-                // K-step are read while the other set's MFMAs run (one wave per SIMD cannot hide LDS latency by itself).
-                // Measured alternatives (profiles/r01_sb2_ablation.txt): finishing the M-tiles in groups of 2 or 4 so their
-                // stores trickle out under the next group's MFMAs was slower (2: dependent MFMAs too close; 4: 535 vs 457 us).
+                // Two register sets (M-tiles 0..HM-1 and HM..MT-1).  Per K-step and set: 3*HM MFMAs and the 2*HM A-fragment
+                // reads of the NEXT K-step into the same registers, each read placed right after the last MFMA that uses the
+                // register -- one LDS instruction between two MFMAs instead of a burst of eight (the burst left the matrix pipe
+                // idle while the reads issued: ~27 cycles per MFMA).  sched_barrier pins the written order.
                 constexpr int HM = MT / 2;
-                bf16x8 ah0[HM], al0[HM], ah1[HM], al1[HM];
+                bf16x8 ah[2][HM], al[2][HM];
 #pragma unroll
-                for (int i = 0; i < HM; ++i) {
-                    ah0[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + i * HX]);
-                    al0[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + i * HX]);
-                }
+                for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int i = 0; i < HM; ++i) {
-                    ah1[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (HM + i) * HX]);
-                    al1[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (HM + i) * HX]);
-                }
-#pragma unroll
-                for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+                    for (int i = 0; i < HM; ++i) {
+                        ah[h2][i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (h2 * HM + i) * HX]);
+                        al[h2][i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (h2 * HM + i) * HX]);
+                    }
+                static_for<SB_KSTEPS * 2>([&](auto S) {
+                    constexpr int ks = decltype(S)::value / 2, h2 = decltype(S)::value % 2;
+                    constexpr bool more = ks + 1 < SB_KSTEPS;
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                    const int nofs = more ? aoff[more ? ks + 1 : ks] : 0;
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = mm(al0[i], bh, acc[i]);
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = mm(ah0[i], bl, acc[i]);
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[i] = mm(ah0[i], bh, acc[i]);
-                    if (ks + 1 < SB_KSTEPS) {
-#pragma unroll
-                        for (int i = 0; i < HM; ++i) {
-                            ah0[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + i * HX]);
-                            al0[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + 2 * HVOLP + i * HX]);
+                    for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
+                        acc[h2 * HM + i] = mm(al[h2][i], bh, acc[h2 * HM + i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && i > 0) {
+                            al[h2][i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (h2 * HM + i - 1) * HX]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(al1[i], bh, acc[HM + i]);
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(ah1[i], bl, acc[HM + i]);
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) acc[HM + i] = mm(ah1[i], bh, acc[HM + i]);
-                    if (ks + 1 < SB_KSTEPS) {
-#pragma unroll
-                        for (int i = 0; i < HM; ++i) {
-                            ah1[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + (HM + i) * HX]);
-                            al1[i] = __builtin_bit_cast(bf16x8, buf[aoff[ks + 1] + 2 * HVOLP + (HM + i) * HX]);
+                    for (int i = 0; i < HM; ++i) {            // hi * lo
+                        acc[h2 * HM + i] = mm(ah[h2][i], bl, acc[h2 * HM + i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more && i == 0) {
+                            al[h2][HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (h2 * HM + HM - 1) * HX]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+#pragma unroll
+                    for (int i = 0; i < HM; ++i) {            // hi * hi ; ah[i] is free after its MFMA
+                        acc[h2 * HM + i] = mm(ah[h2][i], bh, acc[h2 * HM + i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            ah[h2][i] = __builtin_bit_cast(bf16x8, buf[nofs + (h2 * HM + i) * HX]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                });
             }
             if (last) {
                 float4 radd[MT];
