@@ -632,90 +632,129 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
         };
         constexpr int NS = OUT16 ? 4 : 1;
+        constexpr int HM = MT / 2;
         float s1[NS], s2[NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        // The M-tiles of a wave form two groups (0..HM-1, HM..MT-1).  A group runs all 14 K-steps on its own accumulators while
+        // the OTHER group's finished tile rows are stored, one store every third K-step: group 0 of a tile is stored under
+        // group 1's MFMAs, group 1 under group 0 of the NEXT item (after the barrier).  A store burst at the end of every item
+        // (32 KB per CU from all CUs at once) is HBM-write bound and used to stall the matrix pipe for ~25 % of the kernel.
+        // Inside a group, the A fragment of K-step ks+1 is read right after the last MFMA that uses the register: one LDS
+        // instruction between two MFMAs instead of a burst (sched_barrier pins the written order).
+        auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase) {
+            constexpr int gsel = decltype(GSEL)::value, cb = gsel * HM, sb = (1 - gsel) * HM;
+            float4 radd[HM];
+#pragma unroll
+            for (int j = 0; j < HM; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (do_store && a.add) {                    // residual: unconditional loads from clamped addresses
+#pragma unroll
+                for (int j = 0; j < HM; ++j) {
+                    const int yy = ybase + sb + j;
+                    radd[j] = *reinterpret_cast<const float4*>(a.add + ((so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
+                }
+            }
+            if (dbg & 4) {
+                if (do_store) {
+#pragma unroll
+                    for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, so, ybase + sb + j, acc[sb + j], radd[j], s1, s2);
+                }
+                return;
+            }
+            bf16x8 ah[HM], al[HM];
+#pragma unroll
+            for (int i = 0; i < HM; ++i) {
+                ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (cb + i) * HX]);
+                al[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (cb + i) * HX]);
+            }
+            static_for<SB_KSTEPS>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                constexpr bool more = ks + 1 < SB_KSTEPS;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                const int nofs = aoff[more ? ks + 1 : ks];
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
+                    acc[cb + i] = mm(al[i], bh, acc[cb + i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && i > 0) {
+                        al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (cb + i - 1) * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {            // hi * lo
+                    acc[cb + i] = mm(ah[i], bl, acc[cb + i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && i == 0) {
+                        al[HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (cb + HM - 1) * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < HM; ++i) {            // hi * hi ; ah[i] is free after its MFMA
+                    acc[cb + i] = mm(ah[i], bh, acc[cb + i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        ah[i] = __builtin_bit_cast(bf16x8, buf[nofs + (cb + i) * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (ks % 3 == 2 && ks / 3 < HM) {
+                    if (do_store) sb_out_tile<OUT16, NS>(a, so, ybase + sb + ks / 3, acc[sb + ks / 3], radd[ks / 3], s1, s2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            static_assert(HM <= SB_KSTEPS / 3, "one store slot per M-tile of the other group");
+        };
+        SbOut out_prev{}, out_cur{};
+        int yb_prev = 0, yb_cur = 0, n_prev = 0, tis_prev = 0;
+        bool pend = false;                              // group 1 of the previous tile still has to be stored
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const int chunk = w % nchunk;
             const bool last = chunk == nchunk - 1 && !(dbg & 8);
-            if (chunk == 0) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
             if (nchunk > 1) load_w(chunk);
             const u32x4* buf = lds + (w & 1) * BUF;
-            int n = 0, z0 = 0, y0 = 0, x0 = 0, tis = 0;
-            SbOut out{};
+            int n = 0, tis = 0;
             if (last) {
+                int z0, y0, x0;
                 tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
-                out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+                out_cur = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+                yb_cur = y0 + my0;
+            }
+            // ---- group 0 computes; group 1 of the previous tile is stored underneath, then that tile's statistics are flushed
+            if (chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev);
+            if (pend) {
+                sb_out_stats<OUT16, NS>(a, s1, s2, n_prev, cog, tis_prev * 4 + rw, tiles_per_sample * 4, lane);
 #pragma unroll
                 for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                pend = false;
             }
-            if (!(dbg & 4)) {
-                // Two register sets (M-tiles 0..HM-1 and HM..MT-1).  Per K-step and set: 3*HM MFMAs and the 2*HM A-fragment
-                // reads of the NEXT K-step into the same registers, each read placed right after the last MFMA that uses the
-                // register -- one LDS instruction between two MFMAs instead of a burst of eight (the burst left the matrix pipe
-                // idle while the reads issued: ~27 cycles per MFMA).  sched_barrier pins the written order.
-                constexpr int HM = MT / 2;
-                bf16x8 ah[2][HM], al[2][HM];
+            // ---- group 1 computes; group 0 of this tile is stored underneath
+            if (chunk == 0) {
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) {
-                        ah[h2][i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (h2 * HM + i) * HX]);
-                        al[h2][i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (h2 * HM + i) * HX]);
-                    }
-                static_for<SB_KSTEPS * 2>([&](auto S) {
-                    constexpr int ks = decltype(S)::value / 2, h2 = decltype(S)::value % 2;
-                    constexpr bool more = ks + 1 < SB_KSTEPS;
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                    const int nofs = more ? aoff[more ? ks + 1 : ks] : 0;
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
-                        acc[h2 * HM + i] = mm(al[h2][i], bh, acc[h2 * HM + i]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more && i > 0) {
-                            al[h2][i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (h2 * HM + i - 1) * HX]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) {            // hi * lo
-                        acc[h2 * HM + i] = mm(ah[h2][i], bl, acc[h2 * HM + i]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more && i == 0) {
-                            al[h2][HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (h2 * HM + HM - 1) * HX]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < HM; ++i) {            // hi * hi ; ah[i] is free after its MFMA
-                        acc[h2 * HM + i] = mm(ah[h2][i], bh, acc[h2 * HM + i]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) {
-                            ah[h2][i] = __builtin_bit_cast(bf16x8, buf[nofs + (h2 * HM + i) * HX]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                });
+                for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (last) {
-                float4 radd[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) radd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.add) {                            // residual: all loads first (unconditional, clamped), then use
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int yy = y0 + my0 + i;
-                        radd[i] = *reinterpret_cast<const float4*>(a.add + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0));
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
-            }
-            if (last) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, tis * 4 + rw, tiles_per_sample * 4, lane);
+            run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur);
+            if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; tis_prev = tis; }
             __syncthreads();
+        }
+        if (pend) {                                     // drain: group 1 of the last tile
+            float4 radd[HM];
+#pragma unroll
+            for (int j = 0; j < HM; ++j) {
+                const int yy = yb_prev + HM + j;
+                radd[j] = a.add ? *reinterpret_cast<const float4*>(a.add + ((out_prev.ok && yy < H) ? sb_out_index<OUT16>(a, out_prev, yy) : 0))
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
+            sb_out_stats<OUT16, NS>(a, s1, s2, n_prev, cog, tis_prev * 4 + rw, tiles_per_sample * 4, lane);
         }
     }
 }
