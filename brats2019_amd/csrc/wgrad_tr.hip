@@ -20,6 +20,7 @@
 // combined in a fixed order by wgrad_reduce_kernel (wgrad_f32.hip).
 #include "ru_common.h"
 
+#include <stdlib.h>
 #include <utility>
 
 namespace ru {
@@ -79,53 +80,65 @@ __device__ __forceinline__ bf16x8 wt_read_tr(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// consumer wave WAVE: taps WAVE, WAVE+4, ... (7 slots; slot 6 of wave 3 is tap 27 = a dummy that repeats tap 0 and is never written)
+// consumer wave WAVE: taps WAVE, WAVE+4, ... (7 slots; slot 6 of wave 3 is tap 27 = a dummy that repeats tap 0 and is never written).
+// Per K-block the 7 taps run as two half-steps (4 + 3 taps): inside a half-step the MFMAs go product-major over the taps, so two
+// MFMAs on the same accumulator are 3-4 instructions apart (back-to-back dependent MFMAs ran at ~24 cycles each), and the
+// transposed reads of the NEXT half-step's fragments are issued one or two at a time between the MFMAs.
 template <int TZ, int TY, int OT, int WAVE>
 __device__ __forceinline__ void wtr_consume(const char* __restrict__ buf, f32x4 (&acc)[7][OT], int lane_off) {
     using P = WTR<TZ, TY, OT>;
     constexpr int HY = P::HY, HX = P::HX, NKB = P::NKB;
-    constexpr int NSTEP = NKB * 7;
-    // operand fetch of step s = (kb, j): B = x at tap j; A (dy) is fetched once per kb
-    bf16x8 ah[OT], al[OT];
-    bf16x8 bh[3], bl[3];                                       // B fragments, prefetched two steps ahead
-    auto load_b = [&](auto S) {
-        constexpr int s = decltype(S)::value, kb = s / 7, j = s % 7, slot = s % 3;
-        constexpr int tap = (WAVE + 4 * j < 27) ? WAVE + 4 * j : 0;
-        constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        constexpr int r0 = 2 * kb, z = r0 / TY, y = r0 % TY;
-        constexpr int off0 = (((z + dz) * HY + y + dy) * HX + dx) * 32, off1 = off0 + HX * 32;
-        const char* p = buf + lane_off;
-        bh[slot] = wt_read_tr(p + P::X_OFF + off0, p + P::X_OFF + off1);
-        bl[slot] = wt_read_tr(p + P::XLO_OFF + off0, p + P::XLO_OFF + off1);
-    };
-    auto load_a = [&](auto KB) {
-        constexpr int kb = decltype(KB)::value;
-        constexpr int off0 = (2 * kb) * 16 * 32, off1 = off0 + 16 * 32;
-        const char* p = buf + lane_off;
-#pragma unroll
-        for (int q = 0; q < OT; ++q) {
-            ah[q] = wt_read_tr(p + P::D_OFF + q * 2 * P::DPLANE + off0, p + P::D_OFF + q * 2 * P::DPLANE + off1);
-            al[q] = wt_read_tr(p + P::D_OFF + q * 2 * P::DPLANE + P::DPLANE + off0, p + P::D_OFF + q * 2 * P::DPLANE + P::DPLANE + off1);
+    constexpr int NH = NKB * 2;                                 // half-steps: (kb, taps 0-3), (kb, taps 4-6)
+    bf16x8 ah[2][OT], al[2][OT];                                // dy fragments of K-block kb, double buffered by kb parity
+    bf16x8 bh[2][4], bl[2][4];                                  // x fragments of the taps of a half-step, double buffered
+    const char* p = buf + lane_off;
+    // one transposed read pair = one MFMA operand; READ index r of half-step h: r < 2*nt -> x fragment (tap slot r>>1, hi/lo r&1),
+    // then (only before a first half of a K-block) the dy fragments of that K-block
+    auto read_one = [&](auto H, auto R) {
+        constexpr int h = decltype(H)::value, r = decltype(R)::value;
+        constexpr int kb = h / 2, half = h % 2, nt = half == 0 ? 4 : 3, set = h % 2;
+        if constexpr (r < 2 * nt) {
+            constexpr int j = half * 4 + (r >> 1);
+            constexpr int tap = (WAVE + 4 * j < 27) ? WAVE + 4 * j : 0;
+            constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            constexpr int r0 = 2 * kb, z = r0 / TY, y = r0 % TY;
+            constexpr int off0 = (((z + dz) * HY + y + dy) * HX + dx) * 32, off1 = off0 + HX * 32;
+            if constexpr ((r & 1) == 0) bh[set][r >> 1] = wt_read_tr(p + P::X_OFF + off0, p + P::X_OFF + off1);
+            else bl[set][r >> 1] = wt_read_tr(p + P::XLO_OFF + off0, p + P::XLO_OFF + off1);
+        } else {
+            constexpr int ra = r - 2 * nt, q = ra >> 1;
+            constexpr int off0 = (2 * kb) * 16 * 32, off1 = off0 + 16 * 32;
+            constexpr int base = P::D_OFF + q * 2 * P::DPLANE;
+            if constexpr ((ra & 1) == 0) ah[kb & 1][q] = wt_read_tr(p + base + off0, p + base + off1);
+            else al[kb & 1][q] = wt_read_tr(p + base + P::DPLANE + off0, p + base + P::DPLANE + off1);
         }
     };
-    load_b(std::integral_constant<int, 0>{});
-    load_b(std::integral_constant<int, 1>{});
-    wt_static_for<NSTEP>([&](auto S) {
-        constexpr int s = decltype(S)::value, kb = s / 7, j = s % 7, slot = s % 3;
-        if constexpr (j == 0) load_a(std::integral_constant<int, kb>{});
-        if constexpr (s + 2 < NSTEP) load_b(std::integral_constant<int, s + 2>{});
-#pragma unroll
-        for (int q = 0; q < OT; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh[slot], acc[j][q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < OT; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl[slot], acc[j][q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < OT; ++q) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh[slot], acc[j][q], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    auto nreads = [](int h) constexpr { return (h % 2 == 0) ? 8 + 2 * OT : 6; };
+    wt_static_for<nreads(0)>([&](auto R) { read_one(std::integral_constant<int, 0>{}, R); });
+    wt_static_for<NH>([&](auto H) {
+        constexpr int h = decltype(H)::value, kb = h / 2, half = h % 2, nt = half == 0 ? 4 : 3, set = h % 2;
+        constexpr int nm = 3 * nt * OT;                          // MFMAs of this half-step
+        constexpr int nr = h + 1 < NH ? nreads(h + 1) : 0;       // reads of the next half-step, spread over the MFMAs
+        wt_static_for<nm>([&](auto M) {
+            constexpr int m = decltype(M)::value, prod = m / (nt * OT), t = (m / OT) % nt, q = m % OT, j = half * 4 + t;
+            if constexpr (prod == 0) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kb & 1][q], bh[set][t], acc[j][q], 0, 0, 0);
+            if constexpr (prod == 1) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kb & 1][q], bl[set][t], acc[j][q], 0, 0, 0);
+            if constexpr (prod == 2) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kb & 1][q], bh[set][t], acc[j][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // reads [m*nr/nm, (m+1)*nr/nm) of the next half-step go here
+            constexpr int ra = m * nr / nm, rb = (m + 1) * nr / nm;
+            wt_static_for<rb - ra>([&](auto K) {
+                read_one(std::integral_constant<int, h + 1>{}, std::integral_constant<int, ra + decltype(K)::value>{});
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
     });
 }
 
 template <int TZ, int TY, int OT>
-__global__ __launch_bounds__(512, 2) void wgrad3_tr_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
+__global__ __launch_bounds__(512, 2) void wgrad3_tr_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP, int dbg) {
+    // dbg (RU_WTR_DEBUG, ablation only; results are wrong when set): 1 = producers skip conversion + LDS store, 2 = producers skip the
+    // global loads, 4 = consumers skip the MFMAs
     using P = WTR<TZ, TY, OT>;
     constexpr int HY = P::HY, HX = P::HX, XPOS = P::XPOS, DPOS = P::DPOS;
     extern __shared__ __attribute__((aligned(256))) char lds[];
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tr_kernel(const Wgrad3Args a, f
         float4 sc4[2], sh4[2];
         unsigned mx = 0, md = 0;
         auto issue = [&](int item) {
+            if (dbg & 2) return;
             int n, z0, y0, x0;
             tile_origin(item, n, z0, y0, x0);
             const float* xb = a.x + ((size_t)(n * CBi + cgp) * DHW) * 16 + hsel * 8;
@@ -202,6 +216,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tr_kernel(const Wgrad3Args a, f
             }
         };
         auto store = [&](char* buf) {
+            if (dbg & 1) {
+                if (!(dbg & 2)) {
+                    float acc0 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < NRX; ++r) acc0 += vx[r][0].x + vx[r][1].x;
+#pragma unroll
+                    for (int r = 0; r < NRD; ++r) acc0 += vd[r][0].x + vd[r][1].x;
+                    if (acc0 == 12345.678f) buf[0] = 1;
+                }
+                return;
+            }
             float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (xform) {
                 sc[0] = sc4[0].x; sc[1] = sc4[0].y; sc[2] = sc4[0].z; sc[3] = sc4[0].w; sc[4] = sc4[1].x; sc[5] = sc4[1].y; sc[6] = sc4[1].z; sc[7] = sc4[1].w;
@@ -265,6 +290,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tr_kernel(const Wgrad3Args a, f
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const char* buf = lds + (w & 1) * P::BUF;
+            if (dbg & 4) { __syncthreads(); continue; }
             if (rw == 0) wtr_consume<TZ, TY, OT, 0>(buf, acc, lane_off);
             else if (rw == 1) wtr_consume<TZ, TY, OT, 1>(buf, acc, lane_off);
             else if (rw == 2) wtr_consume<TZ, TY, OT, 2>(buf, acc, lane_off);
@@ -320,8 +346,10 @@ static int wtr_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_tr)");
         attr_done = true;
     }
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("RU_WTR_DEBUG"); dbg = e ? atoi(e) : 0; }
     hipLaunchKernelGGL((wgrad3_tr_kernel<4, 4, OT>), dim3(c.nbx, c.ngroups), dim3(512), LDS, s, a, (float*)a.ws,
-                       cdiv(a.D, 4), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, a.Cout, a.Cin);
+                       cdiv(a.D, 4), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, a.Cout, a.Cin, dbg);
     RU_CHECK_LAUNCH("wgrad3_tr_kernel");
     const int total = 27 * a.Cout * a.Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, a.Cout, a.Cin,
