@@ -344,13 +344,13 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     if (bp.down >= 0) {
         const int Do = D / 2, Ho = H / 2, Wo = W / 2;
         const size_t Vo = (size_t)Do * Ho * Wo;
-        sv.xs2d = A.alloc((size_t)N * 8 * bp.cin_down * Vo);
+        if (!h->c16) sv.xs2d = A.alloc((size_t)N * 8 * bp.cin_down * Vo);
         float* xd = A.alloc((size_t)N * C * Vo);
         Conv1Args c1{};
         c1.x0 = sv.xs2d; c1.C0 = 8 * bp.cin_down; c1.y = xd; c1.out_slope = 1.f;
         c1.N = N; c1.Cout = C; c1.V = Vo;
-        if (h->c16) {
-            RU_RUN(s2d16_launch(xprev, sv.xs2d, N, bp.cin_down, D, H, W, s));
+        if (h->c16) {                                            // the 8 taps are gathered from xprev: no space-to-depth tensor
+            c1.x0 = xprev; c1.s2d = 1; c1.Dc = Do; c1.Hc = Ho; c1.Wc = Wo;
             c1.wT = h->pack + bp.pk_down16; c1.ldw = 8 * bp.cin_down;         // [C][tap*cin + c]
             RU_RUN(conv1_16_launch(c1, s));
         } else {
@@ -537,16 +537,23 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
     // down-sampling conv backward (Appendix A2): 1x1 over the space-to-depth view
     const int Cp = bp.cin_down;
-    rc = wgrad1_run(A, s, sv.xs2d, dx, G(h, grads, bp.down), 8 * Cp, N, 8 * Cp, C, V, c16, c16 ? Cp : 0);
-    if (rc) return rc;
-    float* t = A.alloc((size_t)N * 8 * Cp * V);
+    {
+        Wgrad1Args w{};
+        w.x = c16 ? sv.xprev : sv.xs2d; w.dy = dx; w.dw = G(h, grads, bp.down); w.ldw = 8 * Cp; w.c16 = c16; w.tap_split = c16 ? Cp : 0;
+        if (c16) { w.s2d = 1; w.Dc = D; w.Hc = H; w.Wc = W; }
+        w.ws_bytes = wgrad1_workspace_bytes(N, 8 * Cp, C, V);
+        w.ws = A.alloc(w.ws_bytes / sizeof(float));
+        w.N = N; w.Cin = 8 * Cp; w.Cout = C; w.V = V;
+        RU_RUN(wgrad1_launch(w, s));
+    }
+    float* t = c16 ? nullptr : A.alloc((size_t)N * 8 * Cp * V);
     Conv1Args c1{};
     c1.x0 = dx; c1.C0 = C; c1.y = t; c1.out_slope = 1.f; c1.N = N; c1.Cout = 8 * Cp; c1.V = V;
     float* dxp = A.alloc((size_t)N * Cp * V * 8);
-    if (c16) {
+    if (c16) {                                                   // transposed conv scattered straight into the fine tensor
         c1.wT = h->pack + bp.pk_down16 + (size_t)8 * Cp * C; c1.ldw = C;          // [tap*Cp + c][C]
+        c1.y = dxp; c1.s2d = 2; c1.Dc = D; c1.Hc = H; c1.Wc = W;
         RU_RUN(conv1_16_launch(c1, s));
-        RU_RUN(d2s16_launch(t, dxp, N, Cp, 2 * D, 2 * H, 2 * W, s));
     } else {
         c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp;
         RU_RUN(conv1_launch(c1, s));

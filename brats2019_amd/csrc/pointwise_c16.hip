@@ -301,9 +301,23 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
     const size_t v0 = (size_t)vt * 64;
     const int r = lane & 15, g = lane >> 4;
     const int nkb0 = a.C0 >> 4, nkb1 = a.C1 >> 4, nkb = nkb0 + nkb1, CBo = a.Cout >> 4;
-    size_t vb[4];
+    // fine-grid geometry of the 2x2x2 stride-2 modes
+    const int Hf = 2 * a.Hc, Wf = 2 * a.Wc;
+    const size_t Vf = V * 8;
+    size_t vb[4], fv[4];                                 // float offset of this lane's voxel (coarse) / its fine corner voxel index
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const size_t v = v0 + 16 * t + r; vb[t] = (v < V ? v : V - 1) * 16 + 4 * g; }
+    for (int t = 0; t < 4; ++t) {
+        size_t v = v0 + 16 * t + r;
+        if (v >= V) v = V - 1;
+        vb[t] = v * 16 + 4 * g;
+        fv[t] = 0;
+        if (a.s2d) {
+            const int xc = (int)(v % a.Wc);
+            const size_t rr = v / a.Wc;
+            const int yc = (int)(rr % a.Hc), zc = (int)(rr / a.Hc);
+            fv[t] = ((size_t)(2 * zc) * Hf + 2 * yc) * Wf + 2 * xc;
+        }
+    }
     const float* wrow[COB];
 #pragma unroll
     for (int cb = 0; cb < COB; ++cb) {
@@ -315,12 +329,21 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb) acc[t][cb] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+    const int CBf_in = nkb0 >> 3;                        // gather: channel blocks of the fine input tensor
 #pragma unroll 2
     for (int kb = 0; kb < nkb; ++kb) {
-        const float* src = kb < nkb0 ? a.x0 + ((size_t)(n * nkb0 + kb) * V) * 16 : a.x1 + ((size_t)(n * nkb1 + kb - nkb0) * V) * 16;
         float4 xb[4];
+        if (a.s2d == 1) {
+            const int tap = kb / CBf_in, cbf = kb - tap * CBf_in;
+            const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
+            const float* src = a.x0 + ((size_t)(n * CBf_in + cbf) * Vf) * 16 + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) xb[t] = *reinterpret_cast<const float4*>(src + vb[t]);
+            for (int t = 0; t < 4; ++t) xb[t] = *reinterpret_cast<const float4*>(src + (fv[t] + toff) * 16);
+        } else {
+            const float* src = kb < nkb0 ? a.x0 + ((size_t)(n * nkb0 + kb) * V) * 16 : a.x1 + ((size_t)(n * nkb1 + kb - nkb0) * V) * 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[t] = *reinterpret_cast<const float4*>(src + vb[t]);
+        }
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb) {
             const float4 wv = *reinterpret_cast<const float4*>(wrow[cb] + kb * 16);
@@ -333,6 +356,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             }
         }
     }
+    const int CBf_out = CBo >> 3;                        // scatter: channel blocks of the fine output tensor
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const size_t v = v0 + 16 * t + r;
@@ -341,7 +365,14 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
         for (int cb = 0; cb < COB; ++cb) {
             const int cob = cog * COB + cb;
             if (cob >= CBo) continue;
-            const size_t idx = ((size_t)(n * CBo + cob) * V + v) * 16 + 4 * g;
+            size_t idx;
+            if (a.s2d == 2) {
+                const int tap = cob / CBf_out, cbf = cob - tap * CBf_out;
+                const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
+                idx = ((size_t)(n * CBf_out + cbf) * Vf + fv[t] + toff) * 16 + 4 * g;
+            } else {
+                idx = ((size_t)(n * CBo + cob) * V + v) * 16 + 4 * g;
+            }
             float4 o = make_float4(lrelu(acc[t][cb][0], a.out_slope), lrelu(acc[t][cb][1], a.out_slope),
                                    lrelu(acc[t][cb][2], a.out_slope), lrelu(acc[t][cb][3], a.out_slope));
             if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
@@ -353,6 +384,10 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
 int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0, "conv1_16: bad shape");
     RU_REQUIRE(a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Cout % 16 == 0 && a.ldw >= a.C0 + a.C1 && a.ldw % 4 == 0, "conv1_16: channels must be multiples of 16");
+    if (a.s2d) {
+        RU_REQUIRE(a.Dc > 0 && a.Hc > 0 && a.Wc > 0 && (size_t)a.Dc * a.Hc * a.Wc == a.V && a.C1 == 0, "conv1_16: bad stride-2 geometry");
+        RU_REQUIRE(a.s2d == 1 ? a.C0 % 128 == 0 : a.Cout % 128 == 0, "conv1_16: stride-2 modes need 8 x (multiple of 16) channels");
+    }
     const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
     const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
     dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);

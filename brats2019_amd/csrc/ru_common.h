@@ -104,6 +104,8 @@ struct Wgrad1Args {
     int N, Cin, Cout;
     size_t V;
     int c16;                 // x and dy are voxel-major (C16); Cin, Cout multiples of 16
+    int s2d, Dc, Hc, Wc;     // c16 only, s2d = 1: x is the FINE tensor of a 2x2x2 stride-2 conv (Cin/8 channels, extents 2Dc x 2Hc x 2Wc);
+                             // input channel tap*(Cin/8) + c lives at fine voxel (2z+i, 2y+j, 2x+k); V = Dc*Hc*Wc
     int tap_split;           // > 0: the Cin index is tap*tap_split + c of a 2x2x2 conv: written to dw[o*ldw + c*8 + tap]
 };
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
@@ -121,6 +123,11 @@ struct Conv1Args {
     float out_slope;             // LeakyReLU slope on the output (1 = none)
     int N, Cout;
     size_t V;
+    // conv1_16_launch only: the 2x2x2 stride-2 conv and its transpose without a space-to-depth tensor.  V = COARSE voxels
+    // (Dc*Hc*Wc).  s2d = 1 (gather): x0 is the FINE tensor with C0/8 channels, input channel tap*(C0/8) + c is read from fine
+    // voxel (2z+i, 2y+j, 2x+k), tap = i*4 + j*2 + k.  s2d = 2 (scatter): y is the FINE tensor with Cout/8 channels, output
+    // channel tap*(Cout/8) + c is written to that fine voxel.
+    int s2d, Dc, Hc, Wc;
 };
 int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]

@@ -422,7 +422,19 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
             for (int j = 0; j < NX; ++j) {
                 const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
                 const bool ok = v0 + r < V;
-                const float4 t4 = *reinterpret_cast<const float4*>(a.x + (((size_t)n * (a.Cin >> 4) + (c0 >> 4) + p) * V + (ok ? v0 + r : 0)) * 16 + 4 * q);
+                const size_t vv = ok ? v0 + r : 0;
+                size_t off;
+                if (a.s2d) {                             // x = fine tensor of a 2x2x2 stride-2 conv: channel block (tap, cbf) at the fine voxel
+                    const int CBf = a.Cin >> 7, kb = (c0 >> 4) + p, tap = kb / CBf, cbf = kb - tap * CBf;
+                    const int xc = (int)(vv % a.Wc);
+                    const size_t rr = vv / a.Wc;
+                    const int yc = (int)(rr % a.Hc), zc = (int)(rr / a.Hc);
+                    const size_t fvx = ((size_t)(2 * zc + (tap >> 2)) * (2 * a.Hc) + 2 * yc + ((tap >> 1) & 1)) * (2 * a.Wc) + 2 * xc + (tap & 1);
+                    off = (((size_t)n * CBf + cbf) * (V * 8) + fvx) * 16 + 4 * q;
+                } else {
+                    off = (((size_t)n * (a.Cin >> 4) + (c0 >> 4) + p) * V + vv) * 16 + 4 * q;
+                }
+                const float4 t4 = *reinterpret_cast<const float4*>(a.x + off);
                 xv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -565,6 +577,7 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cin, "wgrad1: bad shape");
     RU_REQUIRE(!a.c16 || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "wgrad1: C16 tensors need channel counts that are multiples of 16");
+    RU_REQUIRE(!a.s2d || (a.c16 && a.Cin % 128 == 0 && (size_t)a.Dc * a.Hc * a.Wc == a.V), "wgrad1: bad stride-2 geometry");
     const W1Choice c = wgrad1_choose(a.N, a.Cin, a.Cout, a.V);
     if (!a.ws || a.ws_bytes < wgrad1_workspace_bytes(a.N, a.Cin, a.Cout, a.V)) {
         set_error("wgrad1: workspace too small");
