@@ -424,9 +424,13 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         ds.z = cur;
         ds.skip = h->skips[i];
         const int Ci = h->ch[i], Cc = h->ch[i + 1];
-        ds.u = A.alloc((size_t)N * Cc * Vl(i));
-        if (h->c16) RU_RUN(up2_fwd16_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
-        else RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        // C16 flow: the 1x1x1 conv and the trilinear interpolation are both linear and act on different axes, so
+        // conv(up(z)) = up(conv(z)): the conv runs on the COARSE grid (8x fewer voxels) and the up-sampling on Ci = Cc/2 channels,
+        // with the LeakyReLU fused into its store; the Cc-channel fine tensor `u` never exists.
+        if (!h->c16) {
+            ds.u = A.alloc((size_t)N * Cc * Vl(i));
+            RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+        }
         ds.v = A.alloc((size_t)N * Ci * Vl(i));
         Conv1Args c1{};
         c1.x0 = ds.u; c1.C0 = Cc; c1.y = ds.v; c1.out_slope = kSlope;                                                 // + LeakyReLU (model.py:422)
@@ -436,8 +440,11 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         c2.x0 = ds.skip; c2.C0 = Ci; c2.x1 = ds.v; c2.C1 = Ci;                                                        // cat([skip, up]) (model.py:424)
         c2.y = ds.c; c2.out_slope = 1.f; c2.N = N; c2.Cout = Ci; c2.V = Vl(i);
         if (h->c16) {                                            // C16 kernel reads the reference layout [out][in] directly
+            float* zc = A.alloc((size_t)N * Ci * Vl(i + 1));
+            c1.x0 = cur; c1.y = zc; c1.out_slope = 1.f; c1.V = Vl(i + 1);
             c1.wT = P(h, params, h->up_w[i]); c1.ldw = Cc;
             RU_RUN(conv1_16_launch(c1, s));
+            RU_RUN(up2_fwd16_launch(zc, ds.v, N, Ci, Dl[i + 1], Hl[i + 1], Wl[i + 1], kSlope, s));
             c2.wT = P(h, params, h->dec1_w[i]); c2.ldw = 2 * Ci;
             RU_RUN(conv1_16_launch(c2, s));
         } else {
@@ -624,17 +631,23 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         // LeakyReLU backward from the output v (model.py:422; Appendix A4), then upsampling[i][1] (1x1) and Trilinear
         float* dpre = A.alloc((size_t)N * Ci * V);
         RU_RUN(lrelu_bwd_launch(ds.v, dv, dpre, (size_t)N * Ci * V, kSlope, s));
-        rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V, c16);
-        if (rc) return rc;
-        float* du = A.alloc((size_t)N * Cc * V);
         Conv1Args a3{};
-        a3.x0 = dpre; a3.C0 = Ci; a3.y = du; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
+        a3.x0 = dpre; a3.C0 = Ci; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
         float* dz = A.alloc((size_t)N * Cc * Vl(i + 1));
-        if (c16) {
+        float* du = nullptr;
+        if (c16) {                                               // adjoint of up(conv(z)): everything after the transpose-interpolation is coarse
+            float* dzc = A.alloc((size_t)N * Ci * Vl(i + 1));
+            RU_RUN(up2_bwd16_launch(dpre, dzc, N, Ci, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
+            rc = wgrad1_run(A, s, ds.z, dzc, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, Vl(i + 1), true);
+            if (rc) return rc;
+            a3.x0 = dzc; a3.y = dz; a3.V = Vl(i + 1);
             a3.wT = h->pack + h->pk_upT[i]; a3.ldw = Ci;          // [Cc][Ci] = [out][in]
             RU_RUN(conv1_16_launch(a3, s));
-            RU_RUN(up2_bwd16_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
         } else {
+            rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V, false);
+            if (rc) return rc;
+            du = A.alloc((size_t)N * Cc * V);
+            a3.y = du;
             a3.wT = P(h, params, h->up_w[i]); a3.ldw = Cc;
             RU_RUN(conv1_launch(a3, s));
             RU_RUN(up2_bwd_launch(du, dz, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));

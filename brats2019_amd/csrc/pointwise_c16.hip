@@ -147,7 +147,7 @@ int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, c
 }
 
 // ------------------------------------------------------------------ trilinear x2 (model.py:12-14), same nesting z(y(x)) as the NCDHW kernel
-__global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W) {
+__global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W, float slope) {
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t nb = blockIdx.y;
     const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
@@ -173,12 +173,13 @@ __global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict_
                         lz1 * (ly0 * (lx0 * a10.c + lx1 * b10.c) + ly1 * (lx0 * a11.c + lx1 * b11.c))
         RU_UP2(x); RU_UP2(y); RU_UP2(z); RU_UP2(w);
 #undef RU_UP2
+        o.x = lrelu(o.x, slope); o.y = lrelu(o.y, slope); o.z = lrelu(o.z, slope); o.w = lrelu(o.w, slope);   // slope 1: none
         yp[f] = o;
     }
 }
-int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {
+int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, float slope, hipStream_t s) {
     RU_REQUIRE(C % 16 == 0, "up2_fwd16: C must be a multiple of 16");
-    hipLaunchKernelGGL(up2_fwd16_kernel, c16_grid((size_t)D * H * W * 8, N * (C / 16), 8192), dim3(256), 0, s, x, y, D, H, W);
+    hipLaunchKernelGGL(up2_fwd16_kernel, c16_grid((size_t)D * H * W * 8, N * (C / 16), 8192), dim3(256), 0, s, x, y, D, H, W, slope);
     RU_CHECK_LAUNCH("up2_fwd16_kernel");
     return RU_OK;
 }

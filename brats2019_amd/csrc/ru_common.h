@@ -175,7 +175,7 @@ int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, 
                            float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
 int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef, float slope, float* dx,
                           int N, int C, size_t V, hipStream_t s);
-int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);      // D,H,W = coarse extents
+int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, float slope, hipStream_t s);   // D,H,W = coarse extents; LeakyReLU(slope) on the output (1 = none)
 int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
 // space-to-depth with channel order tap*C + c (tap = i*4 + j*2 + k); D,H,W = fine extents
 int s2d16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);
