@@ -280,8 +280,8 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments)
     auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
         if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
-        // the f32 layout is always kept: ragged W falls back to the f32 kernel
-        RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
+        // outside the voxel-major flow the f32 layout is always kept: ragged W falls back to the f32 kernel
+        if (!h->c16) RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
         return RU_OK;
     };
     auto blk = [&](const BlockP& b) -> int {
@@ -515,8 +515,10 @@ static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, 
 }
 
 // Residual backward: dout -> d(xprev); parameter gradients into `grads`
+// `join`: a second gradient arriving at the block input (the skip connection of a down block); *joined tells whether it was added here
 static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hipStream_t s, const BlockSave& sv, const float* dout,
-                     const float** dxprev_out) {
+                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr) {
+    if (joined) *joined = false;
     const BlockP& bp = *sv.bp;
     const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
     const size_t V = (size_t)D * H * W;
@@ -560,6 +562,8 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (c16) {                                                   // transposed conv scattered straight into the fine tensor
         c1.wT = h->pack + bp.pk_down16 + (size_t)8 * Cp * C; c1.ldw = C;          // [tap*Cp + c][C]
         c1.y = dxp; c1.s2d = 2; c1.Dc = D; c1.Hc = H; c1.Wc = W;
+        c1.add = join;                                           // the skip gradient joins in the store
+        if (joined) *joined = true;                              // (decided by structure, not by the pointer: the dry walk has null pointers)
         RU_RUN(conv1_16_launch(c1, s));
     } else {
         c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp;
@@ -616,9 +620,11 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         a1.x0 = dcur; a1.C0 = Ci; a1.y = dsk; a1.out_slope = 1.f; a1.N = N; a1.Cout = Ci; a1.V = V;
         Conv1Args a2 = a1;
         a2.y = dv;
+        float* dpre = A.alloc((size_t)N * Ci * V);
         if (c16) {                                               // [out][in] = the transposed pack [2Ci][Ci]: rows 0..Ci-1 skip half, Ci.. up half
             a1.wT = h->pack + h->pk_decT[i]; a1.ldw = Ci;
             a2.wT = h->pack + h->pk_decT[i] + (size_t)Ci * Ci; a2.ldw = Ci;
+            a2.y = dpre; a2.mask = ds.v; a2.mask_slope = kSlope; // LeakyReLU backward (model.py:422) fused into the store
             RU_RUN(conv1_16_launch(a1, s));
             RU_RUN(conv1_16_launch(a2, s));
         } else {
@@ -629,8 +635,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         }
         dskip[i] = dsk;
         // LeakyReLU backward from the output v (model.py:422; Appendix A4), then upsampling[i][1] (1x1) and Trilinear
-        float* dpre = A.alloc((size_t)N * Ci * V);
-        RU_RUN(lrelu_bwd_launch(ds.v, dv, dpre, (size_t)N * Ci * V, kSlope, s));
+        if (!c16) RU_RUN(lrelu_bwd_launch(ds.v, dv, dpre, (size_t)N * Ci * V, kSlope, s));
         Conv1Args a3{};
         a3.x0 = dpre; a3.C0 = Ci; a3.out_slope = 1.f; a3.N = N; a3.Cout = Cc; a3.V = V;
         float* dz = A.alloc((size_t)N * Cc * Vl(i + 1));
@@ -656,13 +661,16 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     }
     // encoder levels, deepest first; the skip gradient joins at each level's input
     for (int i = depth - 2; i >= 0; --i) {
+        bool joined = false;
         for (int j = (int)h->enc_s[i].size() - 1; j >= 0; --j) {
-            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur);
+            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr);
             if (rc) return rc;
         }
-        float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
-        RU_RUN(add_launch(dcur, dskip[i], sum, (size_t)N * h->ch[i] * Vl(i), s));
-        dcur = sum;
+        if (!joined) {
+            float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
+            RU_RUN(add_launch(dcur, dskip[i], sum, (size_t)N * h->ch[i] * Vl(i), s));
+            dcur = sum;
+        }
     }
     for (int j = (int)h->first_s.size() - 1; j >= 0; --j) {
         rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur);

@@ -376,6 +376,11 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             }
             float4 o = make_float4(lrelu(acc[t][cb][0], a.out_slope), lrelu(acc[t][cb][1], a.out_slope),
                                    lrelu(acc[t][cb][2], a.out_slope), lrelu(acc[t][cb][3], a.out_slope));
+            if (a.mask) {
+                const float4 m = *reinterpret_cast<const float4*>(a.mask + idx);
+                o.x = m.x > 0.f ? o.x : o.x * a.mask_slope; o.y = m.y > 0.f ? o.y : o.y * a.mask_slope;
+                o.z = m.z > 0.f ? o.z : o.z * a.mask_slope; o.w = m.w > 0.f ? o.w : o.w * a.mask_slope;
+            }
             if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
             *reinterpret_cast<float4*>(a.y + idx) = o;
         }

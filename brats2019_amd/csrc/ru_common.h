@@ -128,6 +128,9 @@ struct Conv1Args {
     // voxel (2z+i, 2y+j, 2x+k), tap = i*4 + j*2 + k.  s2d = 2 (scatter): y is the FINE tensor with Cout/8 channels, output
     // channel tap*(Cout/8) + c is written to that fine voxel.
     int s2d, Dc, Hc, Wc;
+    // conv1_16_launch only: LeakyReLU backward fused into the store: y = acc * (mask[idx] > 0 ? 1 : mask_slope), mask laid out like y
+    const float* mask;
+    float mask_slope;
 };
 int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
