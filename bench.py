@@ -88,14 +88,18 @@ def roofline_probe(batch, size, precision, launches=20):
     from brats2019_amd import _lib as L
     lib = L.load()
     dev = torch.device("cuda")
-    x = torch.randn(batch, 16, size, size, size, device=dev)
+    x = torch.randn(batch, 16, size, size, size, device=dev)     # bf16x3: read as voxel-major [N][1][D][H][W][16] (same bytes)
     w = torch.randn(16, 16, 3, 3, 3, device=dev) * 0.05
     y = torch.empty_like(x)
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(batch, 16, 16, size, size, size, 3), dev)
 
     def launch():
-        L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.PRECISIONS[precision],
-                                    L.ptr(ws), ws.numel(), L.stream()), "conv")
+        if precision == "bf16x3":      # the kernel the engine runs: voxel-major (C16) input and output
+            L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3,
+                                        L.ptr(ws), ws.numel(), L.stream()), "conv")
+        else:
+            L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.PRECISIONS[precision],
+                                        L.ptr(ws), ws.numel(), L.stream()), "conv")
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -119,9 +123,9 @@ def roofline_probe(batch, size, precision, launches=20):
     gbps = abytes / (ms * 1e-3) / 1e9
     if precision == "bf16x3":
         # executed MFMA work = 3 products x (28/27 tap padding) x algorithmic; at the dense bf16 peak that is 144 us for
-        # batch 4, the fp32 NCDHW in+out traffic at 8 TB/s is 134 us: the kernel sits on the ridge.  Reported against the
+        # batch 4, the fp32 in+out traffic at 8 TB/s is 134 us: the kernel sits on the ridge.  Reported against the
         # bf16 MFMA peak with ALGORITHMIC flops (so frac <= 1/3.11 by construction) and against HBM with algorithmic bytes.
-        return {"bound": "mfma", "kernel": "conv3_sb2_kernel<4,8> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3)" % (batch, size),
+        return {"bound": "mfma", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
                 "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
                 "algorithmic_bytes_per_launch": int(abytes), "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
