@@ -60,6 +60,9 @@ SIGNATURES = {
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),
+    "ru_zscore_workspace_bytes": (_sz, [_i, _sz]),
+    "ru_zscore_stats": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
+    "ru_augment_patch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ru_layout_convert": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
     "ru_conv3d_fwd_l": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_weight_l": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),

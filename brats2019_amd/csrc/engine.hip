@@ -1073,3 +1073,26 @@ extern "C" int ru_conv3d_bwd_weight_l(const float* x, const float* dy, float* dw
     RU_WS_OK(C);
     return wgrad3_launch(a, (hipStream_t)stream);
 }
+
+// ====================================================================== training input pipeline (dataloader.py)
+extern "C" size_t ru_zscore_workspace_bytes(int C, size_t V) { return zscore_workspace_bytes(C, V) + 256; }
+extern "C" int ru_zscore_stats(const float* image, double* stats, int C, size_t V, void* ws, size_t ws_bytes, ru_stream_t stream) {
+    RU_REQUIRE(image && stats && C > 0 && V > 0, "ru_zscore_stats: bad argument");
+    return zscore_stats_launch(image, stats, C, V, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int ru_augment_patch(const float* image, const unsigned char* label, const float* mean, const float* inv_std, int C, int D, int H, int W,
+                                const int* crop_lo, const int* patch, const double* scale, int flags, const float* gain, const float* bias,
+                                float* data_out, float* target_out, ru_stream_t stream) {
+    RU_REQUIRE(image && label && mean && inv_std && crop_lo && patch && scale && gain && bias && data_out && target_out, "ru_augment_patch: null argument");
+    RU_REQUIRE(C > 0 && C <= RU_AUG_MAXC, "ru_augment_patch: 1..%d channels", RU_AUG_MAXC);
+    const int dims[3] = {D, H, W};
+    AugmentArgs a{};
+    a.image = image; a.label = label; a.data = data_out; a.target = target_out; a.C = C; a.D = D; a.H = H; a.W = W; a.flags = flags;
+    for (int i = 0; i < 3; ++i) {
+        RU_REQUIRE(patch[i] > 0 && crop_lo[i] >= 0 && crop_lo[i] + patch[i] <= dims[i], "ru_augment_patch: the crop must lie inside the volume");
+        RU_REQUIRE(scale[i] > 0.0, "ru_augment_patch: scale must be positive");
+        a.lo[i] = crop_lo[i]; a.P[i] = patch[i]; a.scale[i] = scale[i];
+    }
+    for (int c = 0; c < C; ++c) { a.mean[c] = mean[c]; a.istd[c] = inv_std[c]; a.gain[c] = gain[c]; a.bias[c] = bias[c]; }
+    return augment_patch_launch(a, (hipStream_t)stream);
+}

@@ -924,6 +924,110 @@ int dice_counts_launch(const float* p, const float* g, unsigned long long* count
     return RU_OK;
 }
 
+// ------------------------------------------------------------------ training input pipeline (dataloader.py:100-216)
+// z-score statistics: per channel count(x > 0), sum x, sum x^2 over ALL voxels (dataloader.py:124-130), float64, two stages
+constexpr int ZS_CHUNK = 16384;
+size_t zscore_workspace_bytes(int C, size_t V) { return (size_t)C * ((V + ZS_CHUNK - 1) / ZS_CHUNK) * 3 * sizeof(double); }
+__global__ __launch_bounds__(256) void zscore_partial_kernel(const float* __restrict__ x, double* __restrict__ part, size_t V, int nblk) {
+    __shared__ double buf[4];
+    const size_t c = blockIdx.y;
+    const size_t v0 = (size_t)blockIdx.x * ZS_CHUNK, v1 = v0 + ZS_CHUNK < V ? v0 + ZS_CHUNK : V;
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
+        const double t = (double)x[c * V + v];
+        n += t > 0.0 ? 1.0 : 0.0;
+        s1 += t;
+        s2 += t * t;
+    }
+    n = block_sum_d(n, buf);
+    s1 = block_sum_d(s1, buf);
+    s2 = block_sum_d(s2, buf);
+    if (threadIdx.x == 0) { double* p = part + (c * nblk + blockIdx.x) * 3; p[0] = n; p[1] = s1; p[2] = s2; }
+}
+__global__ void zscore_final_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    const int c = blockIdx.x, j = threadIdx.x;                    // 3 threads: count, sum, sumsq; fixed order
+    if (j >= 3) return;
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) a += part[((size_t)c * nblk + i) * 3 + j];
+    stats[c * 3 + j] = a;
+}
+int zscore_stats_launch(const float* x, double* stats, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s) {
+    RU_REQUIRE(ws && ws_bytes >= zscore_workspace_bytes(C, V), "zscore: workspace too small");
+    const int nblk = (int)((V + ZS_CHUNK - 1) / ZS_CHUNK);
+    hipLaunchKernelGGL(zscore_partial_kernel, dim3(nblk, C), dim3(256), 0, s, x, (double*)ws, V, nblk);
+    RU_CHECK_LAUNCH("zscore_partial_kernel");
+    hipLaunchKernelGGL(zscore_final_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, stats, nblk);
+    RU_CHECK_LAUNCH("zscore_final_kernel");
+    return RU_OK;
+}
+
+// One fused pass per patch (dataloader.py:147-205): crop -> affine zoom (scipy affine_transform, diagonal matrix, order 1, mode
+// 'reflect' = linear interpolation on the half-sample-symmetric extension of the CROP, source coordinate = scale * output index)
+// of the z-scored modalities and of the one-hot label -> flips of D, H, W -> optional D<->H transpose -> per-channel gain / bias
+// -> WT / TC / ET soft targets.  One thread per output voxel: the 8 corner offsets and weights are shared by all channels.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    int m = i % (2 * n);
+    if (m < 0) m += 2 * n;
+    return m < n ? m : 2 * n - 1 - m;
+}
+__global__ __launch_bounds__(256) void augment_patch_kernel(const AugmentArgs a) {
+    const int P0 = a.P[0], P1 = a.P[1], P2 = a.P[2];
+    const bool tr = (a.flags & 8) != 0;
+    const int Q0 = tr ? P1 : P0, Q1 = tr ? P0 : P1;                // output extents
+    const size_t total = (size_t)Q0 * Q1 * P2;
+    const size_t HW = (size_t)a.H * a.W, DHW = (size_t)a.D * HW;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int k = (int)(o % P2);
+        const size_t r = o / P2;
+        const int j = (int)(r % Q1), i = (int)(r / Q1);
+        const int pa = tr ? j : i, pb = tr ? i : j;                // indices before the transpose
+        const int p[3] = {(a.flags & 1) ? P0 - 1 - pa : pa, (a.flags & 2) ? P1 - 1 - pb : pb, (a.flags & 4) ? P2 - 1 - k : k};
+        size_t off[3][2];
+        float wgt[3][2];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double x = (double)p[ax] * a.scale[ax];
+            const double f = floor(x);
+            const int i0 = (int)f;
+            const float t = (float)(x - f);
+            const size_t stride = ax == 0 ? HW : (ax == 1 ? (size_t)a.W : 1);
+            off[ax][0] = (size_t)(reflect_idx(i0, a.P[ax]) + a.lo[ax]) * stride;
+            off[ax][1] = (size_t)(reflect_idx(i0 + 1, a.P[ax]) + a.lo[ax]) * stride;
+            wgt[ax][0] = 1.f - t;
+            wgt[ax][1] = t;
+        }
+        float acc[RU_AUG_MAXC];
+#pragma unroll
+        for (int c = 0; c < RU_AUG_MAXC; ++c) acc[c] = 0.f;
+        float cw1 = 0.f, cw2 = 0.f, cw3 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int qa = q >> 2, qb = (q >> 1) & 1, qc = q & 1;
+            const float w = wgt[0][qa] * wgt[1][qb] * wgt[2][qc];
+            const size_t v = off[0][qa] + off[1][qb] + off[2][qc];
+#pragma unroll
+            for (int c = 0; c < RU_AUG_MAXC; ++c)
+                if (c < a.C) acc[c] += w * a.image[(size_t)c * DHW + v];
+            const int l = a.label[v];
+            cw1 += l == 1 ? w : 0.f;
+            cw2 += l == 2 ? w : 0.f;
+            cw3 += l == 3 ? w : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < RU_AUG_MAXC; ++c)
+            if (c < a.C) a.data[(size_t)c * total + o] = ((acc[c] - a.mean[c]) * a.istd[c]) * a.gain[c] + a.bias[c];
+        a.target[o] = (cw1 + cw2) + cw3;                           // WT = 1 + 2 + 3
+        a.target[total + o] = cw1 + cw3;                           // TC = 1 + 3
+        a.target[2 * total + o] = cw3;                             // ET = 3
+    }
+}
+int augment_patch_launch(const AugmentArgs& a, hipStream_t s) {
+    const size_t total = (size_t)a.P[0] * a.P[1] * a.P[2];
+    hipLaunchKernelGGL(augment_patch_kernel, dim3(grid1d(total, 256, 4096)), dim3(256), 0, s, a);
+    RU_CHECK_LAUNCH("augment_patch_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ Adam(amsgrad=True, weight_decay) (main.py:133-137)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, size_t n, float step_size, float b1, float b2, float eps, float wd,

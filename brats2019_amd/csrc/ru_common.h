@@ -194,6 +194,22 @@ int crit_grad_launch(const float* p, const float* g, const double* sums, double 
 int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s);
 int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s);
 int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s);
+// training input pipeline (dataloader.py:100-216)
+constexpr int RU_AUG_MAXC = 8;
+struct AugmentArgs {
+    const float* image;          // [C][D][H][W] raw modalities
+    const unsigned char* label;  // [D][H][W] values 0..3
+    float* data;                 // [C][Q0][Q1][P2]
+    float* target;               // [3][Q0][Q1][P2]
+    int C, D, H, W;
+    int lo[3], P[3];
+    double scale[3];
+    int flags;                   // bit 0-2: flip D, H, W; bit 3: transpose D <-> H
+    float mean[RU_AUG_MAXC], istd[RU_AUG_MAXC], gain[RU_AUG_MAXC], bias[RU_AUG_MAXC];
+};
+size_t zscore_workspace_bytes(int C, size_t V);
+int zscore_stats_launch(const float* x, double* stats, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
+int augment_patch_launch(const AugmentArgs& a, hipStream_t s);
 int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float b1, float b2,
                 float eps, float wd, int step, hipStream_t s);
 

@@ -192,6 +192,20 @@ int ru_conv3d_bwd_weight_l(const float* x, const float* dy, float* dw,
  * The metric is 2*counts[0]/counts[1] per (n, c) (NaN -> 1), averaged over the batch (host side: brats2019_amd/metrics.py). */
 int ru_dice_counts(const float* p, const float* g, unsigned long long* counts, int N, int C, size_t V, ru_stream_t stream);
 
+/* ---------------------------------------------------------------- training input pipeline (dataloader.py:100-216, SimpleReader)
+ * ru_zscore_stats: per channel stats[c] = { #(x > 0), sum x, sum x^2 } over all V voxels in float64 -- the three numbers the
+ *   reference's normalisation is made of (dataloader.py:124-130: the count is over positive voxels, the sums over all).
+ * ru_augment_patch: ONE pass from the resident raw case to a training patch (dataloader.py:147-205): crop [lo, lo + patch),
+ *   z-score ((x - mean) * inv_std), zoom by `scale` per axis (scipy.ndimage.affine_transform with a diagonal matrix, order 1,
+ *   mode 'reflect', applied to the modalities and to the one-hot label), flips (flags bit 0/1/2 = axes D/H/W), transpose of D
+ *   and H (bit 3), per-channel gain and bias, WT/TC/ET soft targets.  data_out [C][Q0][Q1][P2], target_out [3][Q0][Q1][P2] with
+ *   (Q0, Q1) = (P1, P0) when transposed.  The small parameter arrays are HOST pointers, read at launch.  C <= 8. */
+size_t ru_zscore_workspace_bytes(int C, size_t V);
+int ru_zscore_stats(const float* image, double* stats, int C, size_t V, void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_augment_patch(const float* image, const unsigned char* label, const float* mean, const float* inv_std,
+                     int C, int D, int H, int W, const int* crop_lo, const int* patch, const double* scale, int flags,
+                     const float* gain, const float* bias, float* data_out, float* target_out, ru_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

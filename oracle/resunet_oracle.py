@@ -507,3 +507,131 @@ def postprocess(prob):
     clusters = reject_small_regions(label_components(labels > 0), 0.1)
     labels[clusters == 0] = 0
     return labels, vols
+
+
+# ====================================================================== training input pipeline (dataloader.py:100-216)
+# The reference's SimpleReader draws its parameters from the global `random` / `numpy.random` streams and transforms with
+# numpy + scipy.ndimage.affine_transform (third-party, scipy; image has 1.15.3).  Restated with EXPLICIT parameters; the closed
+# form of affine_transform(order=1, mode='reflect') with a diagonal matrix -- linear interpolation on the half-sample-symmetric
+# extension, input coordinate = scale * output index -- was checked against scipy here to 2e-16.
+import random as _pyrandom
+
+
+def zscore_positive(image):
+    """dataloader.py:124-134 (and :259-266): per channel, the voxel COUNT is over x > 0 but the sums run over ALL voxels;
+    every voxel is normalised.  float64 like the reference (num_voxels is int64).  Returns (normalised, mean, std)."""
+    image = np.asarray(image)
+    nv = (image > 0).sum(axis=(1, 2, 3))
+    mean = np.sum(image / nv[:, None, None, None], axis=(1, 2, 3))
+    mean2 = np.sum(np.square(image) / nv[:, None, None, None], axis=(1, 2, 3))
+    std = np.sqrt(mean2 - mean * mean)
+    return (image - mean.reshape(-1, 1, 1, 1)) / std.reshape(-1, 1, 1, 1), mean, std
+
+
+def label_bbox(label, patch_size):
+    """dataloader.py:104-116 (__cache): bounding box of label > 0, grown by 50 voxels, clipped so a patch fits."""
+    bbox = bbox3(np.asarray(label) > 0).astype(np.float64)
+    shape = np.array(np.asarray(label).shape)
+    low = np.array(patch_size) / 2.0 + 1
+    high = shape - np.array(patch_size) / 2.0 - 1
+    bbox[0] = np.maximum(bbox[0] - 50, low)
+    bbox[1] = np.minimum(bbox[1] + 50, high)
+    return bbox
+
+
+def draw_augment_params(bbox, patch_size, channels=4):
+    """dataloader.py:141-199: the draws of SimpleReader.__getitem__, in its order, from the same global generators
+    (`numpy.random`: crop centre, intensity gain / bias; `random`: the unused sigma and alpha, the three zoom factors,
+    three flips, the transpose)."""
+    center = np.random.rand(3)
+    center = center * (bbox[1] - bbox[0]) + bbox[0]
+    left_bottom = (center - np.array(patch_size) / 2.0).astype(np.int32)
+    _pyrandom.random()                                   # sigma (:157), only used by the commented-out elastic transform
+    _pyrandom.random()                                   # alpha (:158)
+    scale = [0.7 + _pyrandom.random() * 0.6 for _ in range(3)]
+    flips = [_pyrandom.random() > 0.5 for _ in range(3)]
+    transpose = _pyrandom.random() > 0.5
+    gain = np.random.uniform(0.9, 1.1, size=(channels, 1, 1, 1))
+    bias = np.random.uniform(-0.2, 0.2, size=(channels, 1, 1, 1))
+    return dict(crop_lo=left_bottom, scale=np.array(scale), flips=flips, transpose=transpose,
+                gain=gain.reshape(-1), bias=bias.reshape(-1))
+
+
+def reflect_index(i, n):
+    """half-sample symmetric extension (d c b a | a b c d | d c b a): index of the source sample"""
+    i = np.mod(i, 2 * n)
+    return np.where(i < n, i, 2 * n - 1 - i)
+
+
+def zoom_linear_reflect(vol, scale):
+    """scipy.ndimage.affine_transform(vol, (1, sx, sy, sz), order=1, mode='reflect') for vol [C, D, H, W]; float64."""
+    vol = np.asarray(vol, np.float64)
+    _, D, H, W = vol.shape
+    idx, wgt = [], []
+    for n, s in zip((D, H, W), scale):
+        x = np.arange(n, dtype=np.float64) * s
+        i0 = np.floor(x).astype(np.int64)
+        t = x - i0
+        idx.append((reflect_index(i0, n), reflect_index(i0 + 1, n)))
+        wgt.append((1.0 - t, t))
+    out = np.zeros_like(vol)
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                w = wgt[0][a][:, None, None] * wgt[1][b][None, :, None] * wgt[2][c][None, None, :]
+                out += w[None] * vol[:, idx[0][a]][:, :, idx[1][b]][:, :, :, idx[2][c]]
+    return out
+
+
+def augment_patch(image_norm, label, crop_lo, patch_size, scale, flips, transpose, gain, bias):
+    """dataloader.py:147-205 with explicit parameters: crop, zoom (data and one-hot label), flips, transpose, intensity,
+    WT/TC/ET targets.  Returns (data [C,...], target [3,...]) float32."""
+    lo, ps = [int(v) for v in crop_lo], [int(v) for v in patch_size]
+    sl = tuple(slice(l, l + p) for l, p in zip(lo, ps))
+    data = np.asarray(image_norm)[(slice(None),) + sl]
+    lab = np.asarray(label)[sl]
+    onehot = np.eye(4)[lab.astype(np.int32)].transpose((3, 0, 1, 2))
+    data = zoom_linear_reflect(data, scale)
+    onehot = zoom_linear_reflect(onehot, scale)
+    for ax, f in enumerate(flips):
+        if f:
+            data = np.flip(data, axis=ax + 1)
+            onehot = np.flip(onehot, axis=ax + 1)
+    if transpose:
+        data = data.transpose((0, 2, 1, 3))
+        onehot = onehot.transpose((0, 2, 1, 3))
+    data = data * np.asarray(gain).reshape(-1, 1, 1, 1) + np.asarray(bias).reshape(-1, 1, 1, 1)
+    wt = onehot[1:].sum(axis=0, keepdims=True)
+    tc = onehot[[1, 3]].sum(axis=0, keepdims=True)
+    et = onehot[3, None]
+    return np.ascontiguousarray(data, np.float32), np.concatenate([wt, tc, et], axis=0).astype(np.float32)
+
+
+def full_volume_item(image, label, k=16):
+    """dataloader.py:243-283 (FullReader.__getitem__): zero-pad to multiples of k, z-score, hard WT/TC/ET targets."""
+    image, label = np.asarray(image), np.asarray(label)
+    new_shape = tuple(closest_to_k(i, k) for i in image.shape[1:])
+    img = np.zeros((image.shape[0],) + new_shape, np.float32)
+    lab = np.zeros(new_shape, np.float32)
+    img[(slice(None),) + tuple(slice(0, s) for s in image.shape[1:])] = image
+    lab[tuple(slice(0, s) for s in label.shape)] = label
+    norm, _, _ = zscore_positive(img)
+    onehot = np.eye(4)[lab.astype(np.int32)].transpose((3, 0, 1, 2))
+    tgt = np.concatenate([onehot[1:].sum(axis=0, keepdims=True), onehot[[1, 3]].sum(axis=0, keepdims=True), onehot[3, None]], axis=0)
+    return norm.astype(np.float32), tgt.astype(np.float32)
+
+
+def make_dataloader_case(seed=77, shape=(48, 56, 40)):
+    """Synthetic multimodal case for the input-pipeline fixtures: 4 positive modalities inside an ellipsoid "brain" (zeros
+    outside, like skull-stripped BraTS data) and a nested 2 / 1 / 3 label blob.  Inputs only."""
+    r = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    c = [s / 2.0 for s in shape]
+    brain = ((zz - c[0]) / (0.42 * shape[0])) ** 2 + ((yy - c[1]) / (0.42 * shape[1])) ** 2 + ((xx - c[2]) / (0.42 * shape[2])) ** 2 < 1.0
+    image = (np.abs(r.standard_normal((4,) + tuple(shape))) * 120 + 40).astype(np.float32) * brain[None]
+    d2 = ((zz - c[0] - 2) / (0.15 * shape[0])) ** 2 + ((yy - c[1] + 3) / (0.16 * shape[1])) ** 2 + ((xx - c[2] - 1) / (0.14 * shape[2])) ** 2
+    label = np.zeros(shape, np.float32)
+    label[d2 < 1.0] = 2
+    label[d2 < 0.5] = 1
+    label[d2 < 0.2] = 3
+    return image, label

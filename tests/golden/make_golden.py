@@ -414,6 +414,51 @@ def gen_checkpoint():
     print("wrote ckpt/tiny/tinybest_model.pth %.1f KB" % (os.path.getsize(src) / 1024))
 
 
+# ------------------------------------------------------------------ (9) training input pipeline (dataloader.py)
+def gen_dataloader():
+    """Runs the reference's SimpleReader.__getitem__ / FullReader.__getitem__ on a synthetic in-memory case (its NIfTI reader is
+    replaced by a function returning that case; nibabel is absent) with seeded global generators, and stores inputs + outputs."""
+    import random
+    import warnings
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import dataloader as ref_dl
+    image, label = O.make_dataloader_case(77)          # regenerated by the tests: only the reference's OUTPUTS are stored
+    patch = (24, 24, 24)
+    ref_dl.loader_helper.read_multimodal = lambda *a, **k: (image.copy(), label.copy(), np.eye(4))
+    sr = object.__new__(ref_dl.SimpleReader)
+    sr.series = [("p", "case")]
+    sr.annotation_path = None
+    sr.patch_size = patch
+    sr.images_in_epoch = 8
+    sr.patches_from_single_image = 100
+    sr.real_length = 1
+    sr.labels_location = []
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sr._SimpleReader__cache()
+        sr.patches_from_current_image = sr.patches_from_single_image + 1      # forces the load (and z-score) on first use
+        sr.current_image_index = 0
+        out = dict(patch=np.asarray(patch), bbox=np.asarray(sr.labels_location[0], np.float64))
+        for k, seed in enumerate((5, 6, 7, 8)):
+            random.seed(seed)
+            np.random.seed(seed)
+            d, l = sr[0]
+            out["data%d" % k] = d[0].numpy()
+            out["target%d" % k] = l[0].numpy()
+            out["seed%d" % k] = np.int64(seed)
+        out["image_norm_sub"] = np.asarray(sr.image, np.float32)[:, ::3, ::3, ::3]
+        fr = object.__new__(ref_dl.FullReader)
+        fr.path = "p"
+        fr.series = ["case"]
+        ref_dl.loader_helper.read_multimodal = lambda *a, **k: (image[:, :38, :41, :36].copy(), label[:38, :41, :36].copy(), np.eye(4))
+        d, l = fr[0]
+        out["full_shape"] = np.asarray(d[0].shape)
+        out["full_data_sub"] = d[0].numpy()[:, ::2, ::2, ::2]
+        out["full_target_bits"] = np.packbits(l[0].numpy().astype(np.uint8))
+    save("dataloader.npz", **out)
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:])
     full = O.DEFAULT_CFG
@@ -441,3 +486,5 @@ if __name__ == "__main__":
         gen_checkpoint()
     if want("inference"):
         gen_inference()
+    if want("dataloader"):
+        gen_dataloader()
