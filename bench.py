@@ -122,15 +122,18 @@ def roofline_probe(batch, size, precision, launches=20):
     abytes = 2 * 16 * batch * size ** 3 * 4
     gbps = abytes / (ms * 1e-3) / 1e9
     if precision == "bf16x3":
-        # executed MFMA work = 3 products x (28/27 tap padding) x algorithmic; at the dense bf16 peak that is 144 us for
-        # batch 4, the fp32 in+out traffic at 8 TB/s is 134 us: the kernel sits on the ridge.  Reported against the
-        # bf16 MFMA peak with ALGORITHMIC flops (so frac <= 1/3.11 by construction) and against HBM with algorithmic bytes.
-        return {"bound": "mfma", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
-                "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
-                "algorithmic_bytes_per_launch": int(abytes), "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
-                "executed_mfma_frac": round(achieved * 3 * 28 / 27 / BF16_MFMA_PEAK_TFLOPS, 4),
-                "hbm_algorithmic_gbps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 4)}
+        # The kernel sits on the ridge: executed MFMA work (3 products x 28/27 tap padding x algorithmic) at the dense bf16
+        # peak is 144 us for batch 4, the fp32 in+out traffic at 8 TB/s is 134 us.  Measured (profiles/r01_sb2_ablation.txt): the
+        # memory side limits -- loads alone 178 us, stores alone 137 us, MFMA loop alone 233-261 us, and doubling the consumer
+        # waves changed nothing -- so the roofline line is the HBM one (algorithmic bytes = input + output, fp32); the MFMA
+        # view is kept beside it (algorithmic flops, so <= 1/3.11 of the peak by construction, and the executed fraction).
+        return {"bound": "hbm", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
+                "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(abytes),
+                "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_algorithmic_tflops": round(achieved, 2),
+                "mfma_algorithmic_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
+                "executed_mfma_frac": round(achieved * 3 * 28 / 27 / BF16_MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "mfma", "kernel": "conv3_f32_kernel<4,8,8,1> (3x3x3 conv 16->16, %d x %d^3)" % (batch, size),
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
