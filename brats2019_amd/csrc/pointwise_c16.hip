@@ -1,7 +1,7 @@
 // pointwise_c16.hip -- the streaming kernels of the ResUNet path on the voxel-major working layout "C16":
 // activations [N][C/16][D][H][W][16] (16 channels of a voxel contiguous, C % 16 == 0).  The split-bf16 engine keeps every
 // tensor between the first and the last convolution in this layout (include/resunet_hip.h); these kernels are the C16
-// forms of pointwise.hip: GroupNorm apply / backward, trilinear x2 and its transpose, space-to-depth, the 1x1x1
+// forms of pointwise.hip: GroupNorm apply / backward, trilinear x2 and its transpose, the 1x1x1 / 2x2x2-stride-2
 // convolution (exact-f32 MFMA) -- same arithmetic per element, different addressing.
 //
 // Addressing: one (sample, channel block) = V voxels x 16 floats = 4V float4.  float4 index f -> voxel f>>2, channels
@@ -234,42 +234,8 @@ int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int
     return RU_OK;
 }
 
-// ------------------------------------------------------------------ space-to-depth for the 2x2x2 stride-2 conv (model.py:361-363)
-// y[n][tap*CB + cb][zo][yo][xo][16] = x[n][cb][2zo+i][2yo+j][2xo+k][16], tap = i*4 + j*2 + k: channel index of the
-// space-to-depth tensor = tap*Cin + c (the weights are packed to that order by pack_down16).
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void s2d16_kernel(const float* __restrict__ src, float* __restrict__ dst, int CB, int D, int H, int W) {
-    const int Do = D / 2, Ho = H / 2, Wo = W / 2;
-    const size_t Vi = (size_t)D * H * W, Vo = Vi / 8;
-    const int nk = blockIdx.y;                               // n * 8*CB + tap*CB + cb
-    const int n = nk / (8 * CB), kb = nk - n * 8 * CB;
-    const int tap = kb / CB, cb = kb - tap * CB;
-    const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
-    const size_t fine_base = ((size_t)n * CB + cb) * Vi * 4, coarse_base = (size_t)nk * Vo * 4;
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vo * 4; f += (size_t)gridDim.x * 256) {
-        const int q = (int)(f & 3);
-        size_t r = f >> 2;
-        const int xo = (int)(r % Wo); r /= Wo;
-        const int yo = (int)(r % Ho);
-        const int zo = (int)(r / Ho);
-        const size_t fi = ((((size_t)(2 * zo + i) * H + 2 * yo + j) * W + 2 * xo + k) << 2) + q;
-        if (INVERSE) reinterpret_cast<float4*>(dst)[fine_base + fi] = reinterpret_cast<const float4*>(src)[coarse_base + f];
-        else reinterpret_cast<float4*>(dst)[coarse_base + f] = reinterpret_cast<const float4*>(src)[fine_base + fi];
-    }
-}
-int s2d16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s) {   // D,H,W = fine extents (even)
-    RU_REQUIRE(C % 16 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "s2d16: bad shape");
-    hipLaunchKernelGGL(s2d16_kernel<false>, c16_grid((size_t)D * H * W / 8, N * 8 * (C / 16), 1024), dim3(256), 0, s, x, y, C / 16, D, H, W);
-    RU_CHECK_LAUNCH("s2d16_kernel");
-    return RU_OK;
-}
-int d2s16_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s) {   // x (fine, C channels) overwritten
-    RU_REQUIRE(C % 16 == 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "d2s16: bad shape");
-    hipLaunchKernelGGL(s2d16_kernel<true>, c16_grid((size_t)D * H * W / 8, N * 8 * (C / 16), 1024), dim3(256), 0, s, y, x, C / 16, D, H, W);
-    RU_CHECK_LAUNCH("d2s16_kernel");
-    return RU_OK;
-}
-
+// ------------------------------------------------------------------ 2x2x2 stride-2 conv (model.py:361-363): weight packs
+// The conv itself is conv1_16_kernel in gather mode (channel index of the gathered operand = tap*Cin + c, tap = i*4 + j*2 + k).
 // weights of the 2x2x2 stride-2 conv [Cout][Cin][8] -> wd[Cout][tap*Cin + c] (forward) and wdT[tap*Cin + c][Cout] (data gradient)
 __global__ void pack_down16_kernel(const float* __restrict__ w, float* __restrict__ wd, float* __restrict__ wdT, int Cout, int Cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

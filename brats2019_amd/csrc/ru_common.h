@@ -180,9 +180,6 @@ int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, c
                           int N, int C, size_t V, hipStream_t s);
 int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, float slope, hipStream_t s);   // D,H,W = coarse extents; LeakyReLU(slope) on the output (1 = none)
 int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
-// space-to-depth with channel order tap*C + c (tap = i*4 + j*2 + k); D,H,W = fine extents
-int s2d16_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);
-int d2s16_launch(const float* y, float* x, int N, int C, int D, int H, int W, hipStream_t s);
 int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin, hipStream_t s);       // [Cout][Cin][8] -> [Cout][8*Cin], [8*Cin][Cout]
 // Conv1Args on C16 tensors; a.wT is read as wm[Cout][C0 + C1] (row-major out x in, pitch a.ldw)
 int conv1_16_launch(const Conv1Args& a, hipStream_t s);
