@@ -493,6 +493,22 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
 
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
                       bool x_c16 = false, bool dy_c16 = false) {
+    if (x_c16 != dy_c16 && mode == RU_PREC_BF16X3 && Cin <= 16 && Cout <= 16) {
+        // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side is copied into one zero-padded
+        // voxel-major block so the transpose-read kernel runs (0.42 + 0.11 ms instead of 0.74-0.88 ms at 4 x 128^3)
+        const size_t V = (size_t)D * H * W;
+        float* pad = A.alloc((size_t)N * 16 * V);
+        RU_RUN(pad_to_c16_launch(x_c16 ? dy : x, pad, N, x_c16 ? Cout : Cin, V, s));
+        Wgrad3Args w{};
+        w.x = x_c16 ? x : pad; w.dy = x_c16 ? pad : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
+        w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
+        w.dw_cin = Cin; w.dw_cout = Cout;
+        w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
+        w.ws_bytes = wgrad3_workspace_bytes(N, w.Cin, w.Cout, D, H, W);
+        w.ws = A.alloc(w.ws_bytes / sizeof(float));
+        RU_RUN(wgrad3_launch(w, s));
+        return RU_OK;
+    }
     Wgrad3Args w{};
     w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16;
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;

@@ -898,6 +898,30 @@ int layout_convert_launch(const float* src, float* dst, int N, int C, size_t V, 
     return RU_OK;
 }
 
+// few-channel NCDHW tensor (network input: 4 modalities; head gradient: 3 classes) -> one zero-padded voxel-major block, so the
+// transpose-read weight-gradient kernel can take it
+__global__ __launch_bounds__(256) void pad_to_c16_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, size_t V) {
+    const size_t n = blockIdx.y;
+    const float* sp = src + n * C * V;
+    float4* dp = reinterpret_cast<float4*>(dst + n * 16 * V);
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < V * 4; f += (size_t)gridDim.x * 256) {
+        const size_t v = f >> 2;
+        const int c0 = (int)(f & 3) * 4;
+        float4 o;
+        o.x = c0 + 0 < C ? sp[(size_t)(c0 + 0) * V + v] : 0.f;
+        o.y = c0 + 1 < C ? sp[(size_t)(c0 + 1) * V + v] : 0.f;
+        o.z = c0 + 2 < C ? sp[(size_t)(c0 + 2) * V + v] : 0.f;
+        o.w = c0 + 3 < C ? sp[(size_t)(c0 + 3) * V + v] : 0.f;
+        dp[f] = o;
+    }
+}
+int pad_to_c16_launch(const float* src, float* dst, int N, int C, size_t V, hipStream_t s) {
+    RU_REQUIRE(C > 0 && C <= 16, "pad_to_c16: 1..16 channels");
+    hipLaunchKernelGGL(pad_to_c16_kernel, dim3(grid1d(V * 4, 256, 4096), (unsigned)N), dim3(256), 0, s, src, dst, C, V);
+    RU_CHECK_LAUNCH("pad_to_c16_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ evaluation metric (metrics.py:108-133)
 // per (sample, channel): counts[row] = { sum(p>0.5 & g>0.5), sum(p>0.5) + sum(g>0.5) } as integers (order independent)
 __global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ p, const float* __restrict__ g,

@@ -84,6 +84,7 @@ struct Wgrad3Args {
     int N, Cin, Cout, D, H, W;
     int mode;                // RU_PREC_F32 / RU_PREC_BF16X3 (split-bf16 kernel, wgrad_sb.hip; needs W % 4 == 0)
     int x_c16, dy_c16;       // voxel-major x / dy (split-bf16 kernel only); 0 = NCDHW
+    int dw_cin, dw_cout;     // wgrad_tr only: real channel counts of dw when x / dy are zero-padded to 16 channels (0 = Cin / Cout)
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
@@ -136,6 +137,8 @@ int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
 // NCDHW [N][C][V] <-> C16 [N][C/16][V][16] (C % 16 == 0); to_c16 = 1: src NCDHW -> dst C16, 0: the inverse
 int layout_convert_launch(const float* src, float* dst, int N, int C, size_t V, int to_c16, hipStream_t s);
+// NCDHW [N][C][V] with C < 16 -> one zero-padded C16 block [N][1][V][16]
+int pad_to_c16_launch(const float* src, float* dst, int N, int C, size_t V, hipStream_t s);
 
 // space-to-depth for the 2x2x2 stride-2 conv: y[n][c*8 + (i*4+j*2+k)][z][y][x] = x[n][c][2z+i][2y+j][2x+k]
 int s2d_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);   // D,H,W = input (even)

@@ -351,9 +351,10 @@ static int wtr_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_tr_kernel<4, 4, OT>), dim3(c.nbx, c.ngroups), dim3(512), LDS, s, a, (float*)a.ws,
                        cdiv(a.D, 4), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, a.Cout, a.Cin, dbg);
     RU_CHECK_LAUNCH("wgrad3_tr_kernel");
-    const int total = 27 * a.Cout * a.Cin;
+    const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;      // real extents of dw (zero-padded operands)
+    const int total = 27 * co * ci;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, a.Cout, a.Cin,
-                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0);
+                       co, ci, a.dw, ci * 27, 27, 0);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
 }
