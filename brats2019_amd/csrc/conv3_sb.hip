@@ -708,8 +708,19 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             static_assert(HM <= SB_KSTEPS / 3, "one store slot per M-tile of the other group");
         };
         SbOut out_prev{}, out_cur{};
-        int yb_prev = 0, yb_cur = 0, n_prev = 0, tis_prev = 0;
+        int yb_prev = 0, yb_cur = 0, n_prev = 0;
         bool pend = false;                              // group 1 of the previous tile still has to be stored
+        // GroupNorm statistics: ONE partial per (workgroup, consumer wave, sample) -- the tiles of a workgroup come in increasing
+        // order, so a sample's tiles are consecutive; the partial is flushed when the sample changes and the samples this
+        // workgroup never sees get zeros (the finalize kernel then reads gridDim.x*4 partials per channel instead of 4 per tile)
+        const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
+        unsigned flushed = 0;                           // bit n: sample n has been written
+        auto flush_stats = [&](int n) {
+            sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+            flushed |= 1u << (n & 31);
+#pragma unroll
+            for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        };
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const int chunk = w % nchunk;
@@ -717,6 +728,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (nchunk > 1) load_w(chunk);
             const u32x4* buf = lds + (w & 1) * BUF;
             int n = 0, tis = 0;
+            const int n_item = (t_begin + (w / nchunk) * G) / tiles_per_sample;      // sample of this item's tile
             if (last) {
                 int z0, y0, x0;
                 tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
@@ -730,9 +742,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             }
             run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev);
             if (pend) {
-                sb_out_stats<OUT16, NS>(a, s1, s2, n_prev, cog, tis_prev * 4 + rw, tiles_per_sample * 4, lane);
-#pragma unroll
-                for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                if (n_item != n_prev) flush_stats(n_prev);   // the previous tile was the last one of its sample here
                 pend = false;
             }
             // ---- group 1 computes; group 0 of this tile is stored underneath
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur);
-            if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; tis_prev = tis; }
+            if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
             __syncthreads();
         }
         if (pend) {                                     // drain: group 1 of the last tile
@@ -754,7 +764,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             }
 #pragma unroll
             for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
-            sb_out_stats<OUT16, NS>(a, s1, s2, n_prev, cog, tis_prev * 4 + rw, tiles_per_sample * 4, lane);
+            flush_stats(n_prev);
+        }
+        if (a.stat_partials && !(dbg & 8)) {            // zeros for the samples this workgroup did not touch (s1 = s2 = 0 here)
+            for (int n = 0; n < a.N; ++n)
+                if (n >= 32 || !((flushed >> n) & 1u)) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
         }
     }
 }
@@ -807,7 +821,7 @@ struct SBChoice { int tz, ty; };
 static SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
     const int ncog = cdiv(Cout, 16);
     auto blocks = [&](int tz, int ty) { return (long)N * cdiv(D, tz) * cdiv(H, ty) * cdiv(W, 16) * ncog; };
-    if (blocks(4, 8) >= 1024) return {4, 8};
+    if (blocks(4, 8) >= 256) return {4, 8};        // one persistent producer/consumer workgroup per CU is enough (deep levels: 8 chunks per tile)
     if (blocks(2, 8) >= 1024) return {2, 8};
     return {2, 4};
 }
@@ -815,33 +829,46 @@ static SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
 // v2 (persistent producer/consumer) handles the large-tile case
 static bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
 
+static int sb_ncu() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
+}
+// workgroups along x of the persistent kernel: one resident workgroup per CU in total
+static long sb2_grid_x(int N, int Cout, int D, int H, int W) {
+    const int ncu = sb_ncu(), ncog = cdiv(Cout, 16);
+    const long ntile = (long)N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
+    long gx = ncu / (ncog < ncu ? ncog : ncu);
+    if (gx < 1) gx = 1;
+    return gx > ntile ? ntile : gx;
+}
+
+// number of statistics partials per (sample, channel) the kernel chosen for this shape writes
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     (void)Cin;
     const SBChoice c = sb_choose(N, Cout, D, H, W);
-    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;       // one partial per wave
+    if (sb_use_v2(c)) return (int)sb2_grid_x(N, Cout, D, H, W) * 4;    // persistent kernel: one per (workgroup, consumer wave)
+    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
 }
 
 template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static bool attr_done = false;
-    static int ncu = 256;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         attr_done = true;
     }
+    static_assert(TZ == 4 && TY == 8, "sb2_grid_x assumes the (4,8,16) tile");
+    RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2: at most 32 samples per call when statistics are requested");
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
-    const long ntile = (long)a.N * ntz * nty * ntx;
-    const int ncog = cdiv(a.Cout, 16);
-    long gx = ncu / (ncog < ncu ? ncog : ncu);          // one resident workgroup per CU in total
-    if (gx < 1) gx = 1;
-    if (gx > ntile) gx = ntile;
-    dim3 grid((unsigned)gx, (unsigned)ncog);
+    dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
     hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
