@@ -89,51 +89,50 @@ struct WTZ {
     static constexpr int NKB = 8;                        // K-blocks per step: 2 planes x 4 row pairs
 };
 
-// consumer wave WAVE: taps WAVE, WAVE+4, ... (7 slots; slot 6 of wave 3 is tap 27 = a dummy that repeats tap 0 and is never written).
-// Per K-block the 7 taps run as two half-steps (4 + 3 taps): inside a half-step the MFMAs go product-major over the taps, so two
-// MFMAs on the same accumulator are 3-4 instructions apart, and the transposed reads of the NEXT half-step's fragments are issued
-// one or two at a time between the MFMAs.
-template <int OT, int WAVE>
-__device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const int (&pb)[4], const char* __restrict__ dl, f32x4 (&acc)[7][OT]) {
+// Consumer wave: ALL 27 taps for its share of the step's voxels (OT = 1: one plane, 4 of the 8 rows; OT = 2: one of the two
+// o-tiles, one plane, all 8 rows) -- 27 accumulators, summed over the waves by wgrad_reduce_kernel (each wave writes its own
+// partial).  K-blocks pair rows (y, y+2): for a 4-row half the two K-blocks (0,2) and (1,3) and the three dy taps touch only the
+// four row pairs (p, p+2), p = 0..3 of the halo image, so per (dz, dx) 8 operands (hi and lo) feed 18 MFMAs; with the dy image
+// read once per half that is 0.94 transposed reads per MFMA instead of 1.5, and no wave re-reads another wave's dy fragments.
+// The reads of the next (dz, dx) group are issued between the MFMAs of the current one.
+template <int OT>
+__device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const int (&pw)[3], const char* __restrict__ dl, f32x4 (&acc)[27]) {
     using P = WTZ<OT>;
-    constexpr int HX = P::HX, NKB = P::NKB, NH = NKB * 2;
-    bf16x8 ah[2][OT], al[2][OT];
-    bf16x8 bh[2][4], bl[2][4];
-    auto read_one = [&](auto H, auto R) {
-        constexpr int h = decltype(H)::value, r = decltype(R)::value;
-        constexpr int kb = h / 2, half = h % 2, nt = half == 0 ? 4 : 3, set = h % 2;
-        constexpr int z = kb / 4, y = 2 * (kb % 4);
-        if constexpr (r < 2 * nt) {
-            constexpr int j = half * 4 + (r >> 1);
-            constexpr int tap = (WAVE + 4 * j < 27) ? WAVE + 4 * j : 0;
-            constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            constexpr int off0 = ((y + dy) * HX + dx) * 32, off1 = off0 + HX * 32;
-            const char* p = xl + pb[z + dz];
-            if constexpr ((r & 1) == 0) bh[set][r >> 1] = wt_read_tr(p + P::X_OFF + off0, p + P::X_OFF + off1);
-            else bl[set][r >> 1] = wt_read_tr(p + P::XLO_OFF + off0, p + P::XLO_OFF + off1);
+    constexpr int HX = P::HX, NHALF = OT, NU = NHALF * 9;       // units: (row half, (dz, dx))
+    bf16x8 bh[2][4], bl[2][4];                                  // x operands of a unit: row pairs p = 0..3, double buffered
+    bf16x8 ah[2][2], al[2][2];                                  // dy operands of a half: K-blocks (0,2), (1,3), double buffered by half
+    // read r of unit u: r < 8 -> x operand (pair r>>1, hi/lo r&1); then, for the first unit of a half, the 4 dy operands
+    auto read_one = [&](auto U, auto R) {
+        constexpr int u = decltype(U)::value, r = decltype(R)::value;
+        constexpr int h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
+        if constexpr (r < 8) {
+            constexpr int pr = r >> 1;
+            constexpr int off0 = ((4 * h + pr) * HX + dx) * 32, off1 = off0 + 2 * HX * 32;
+            const char* p = xl + pw[dz];
+            if constexpr ((r & 1) == 0) bh[set][pr] = wt_read_tr(p + P::X_OFF + off0, p + P::X_OFF + off1);
+            else bl[set][pr] = wt_read_tr(p + P::XLO_OFF + off0, p + P::XLO_OFF + off1);
         } else {
-            constexpr int ra = r - 2 * nt, q = ra >> 1;
-            constexpr int off0 = (z * P::TY + y) * 16 * 32, off1 = off0 + 16 * 32;
-            constexpr int base = q * 2 * P::DPLANE;
-            if constexpr ((ra & 1) == 0) ah[kb & 1][q] = wt_read_tr(dl + base + off0, dl + base + off1);
-            else al[kb & 1][q] = wt_read_tr(dl + base + P::DPLANE + off0, dl + base + P::DPLANE + off1);
+            constexpr int ra = r - 8, kbi = ra >> 1;
+            constexpr int off0 = (4 * h + kbi) * 16 * 32, off1 = off0 + 2 * 16 * 32;
+            if constexpr ((ra & 1) == 0) ah[h & 1][kbi] = wt_read_tr(dl + off0, dl + off1);
+            else al[h & 1][kbi] = wt_read_tr(dl + P::DPLANE + off0, dl + P::DPLANE + off1);
         }
     };
-    auto nreads = [](int h) constexpr { return (h % 2 == 0) ? 8 + 2 * OT : 6; };
+    auto nreads = [](int u) constexpr { return (u % 9 == 0) ? 12 : 8; };
     wt_static_for<nreads(0)>([&](auto R) { read_one(std::integral_constant<int, 0>{}, R); });
-    wt_static_for<NH>([&](auto H) {
-        constexpr int h = decltype(H)::value, kb = h / 2, half = h % 2, nt = half == 0 ? 4 : 3, set = h % 2;
-        constexpr int nm = 3 * nt * OT;
-        constexpr int nr = h + 1 < NH ? nreads(h + 1) : 0;
-        wt_static_for<nm>([&](auto M) {
-            constexpr int m = decltype(M)::value, prod = m / (nt * OT), t = (m / OT) % nt, q = m % OT, j = half * 4 + t;
-            if constexpr (prod == 0) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kb & 1][q], bh[set][t], acc[j][q], 0, 0, 0);
-            if constexpr (prod == 1) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kb & 1][q], bl[set][t], acc[j][q], 0, 0, 0);
-            if constexpr (prod == 2) acc[j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kb & 1][q], bh[set][t], acc[j][q], 0, 0, 0);
+    wt_static_for<NU>([&](auto U) {
+        constexpr int u = decltype(U)::value, h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
+        constexpr int nr = u + 1 < NU ? nreads(u + 1) : 0;
+        wt_static_for<18>([&](auto M) {
+            constexpr int m = decltype(M)::value, prod = m / 6, kbi = (m / 3) % 2, dy = m % 3;
+            constexpr int tap = dz * 9 + dy * 3 + dx, pr = kbi + dy;
+            if constexpr (prod == 0) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
+            if constexpr (prod == 1) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bl[set][pr], acc[tap], 0, 0, 0);
+            if constexpr (prod == 2) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int ra = m * nr / nm, rb = (m + 1) * nr / nm;
+            constexpr int ra = m * nr / 18, rb = (m + 1) * nr / 18;
             wt_static_for<rb - ra>([&](auto K) {
-                read_one(std::integral_constant<int, h + 1>{}, std::integral_constant<int, ra + decltype(K)::value>{});
+                read_one(std::integral_constant<int, u + 1>{}, std::integral_constant<int, ra + decltype(K)::value>{});
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -281,40 +280,38 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             __syncthreads();
         }
     } else {
-        f32x4 acc[7][OT];
+        f32x4 acc[27];
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
-#pragma unroll
-            for (int q = 0; q < OT; ++q) acc[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int i16 = lane & 15, g = lane >> 4;
         const int lane_off = (4 * g + (i16 >> 2)) * 32 + (i16 & 3) * 8;
+        // this wave's share of a step: plane zw; OT = 1: rows 4*(rw&1) .. +3 of it, OT = 2: all 8 rows and o-tile rw & 1
+        const int zw = rw >> 1;
+        const int yb = OT == 1 ? 4 * (rw & 1) : 0, qw = OT == 1 ? 0 : (rw & 1);
+        const int xrow_off = yb * HX * 32 + lane_off;
+        const int drow_off = (zw * TY + yb) * 16 * 32 + qw * 2 * P::DPLANE + lane_off;
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const int j = w / ntz, k = w - j * ntz;
-            const int s0 = j * colstride + 2 * k;        // ring number of halo plane z0 - 1
-            int pb[4];
+            const int s0 = j * colstride + 2 * k + zw;   // ring number of halo plane (z0 - 1) + zw: tap dz reads plane s0 + dz
+            int pw[3];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) pb[p] = ((s0 + p) & (P::NSLOT - 1)) * P::PLANE + lane_off;
-            const char* dl = lds + P::D_OFF + (w & 1) * P::DBUF + lane_off;
-            if (rw == 0) wtz_consume<OT, 0>(lds, pb, dl, acc);
-            else if (rw == 1) wtz_consume<OT, 1>(lds, pb, dl, acc);
-            else if (rw == 2) wtz_consume<OT, 2>(lds, pb, dl, acc);
-            else wtz_consume<OT, 3>(lds, pb, dl, acc);
+            for (int p = 0; p < 3; ++p) pw[p] = ((s0 + p) & (P::NSLOT - 1)) * P::PLANE + xrow_off;
+            const char* dl = lds + P::D_OFF + (w & 1) * P::DBUF + drow_off;
+            wtz_consume<OT>(lds, pw, dl, acc);
             __syncthreads();
         }
-        const int o0 = og * OT * 16, c0 = cgp * 16;
+        // ---- partials[part][tap][o][c], part = (workgroup, wave share): D lane = (rows o = 4*(l>>4) + r, column c = l&15)
+        constexpr int NW = OT == 1 ? 4 : 2;
+        const int part = blockIdx.x * NW + (OT == 1 ? rw : (rw >> 1));
+        const int o0 = og * OT * 16 + qw * 16, c0 = cgp * 16;
+        const int c = c0 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int tap = rw + 4 * j;
-            if (tap >= 27) continue;
+        for (int t = 0; t < 27; ++t) {
 #pragma unroll
-            for (int q = 0; q < OT; ++q) {
-                const int c = c0 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = o0 + q * 16 + (lane >> 4) * 4 + r;
-                    if (o < CoP && c < CiP) partials[(((size_t)blockIdx.x * 27 + tap) * CoP + o) * CiP + c] = acc[j][q][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + (lane >> 4) * 4 + r;
+                if (o < CoP && c < CiP) partials[(((size_t)part * 27 + t) * CoP + o) * CiP + c] = acc[t][r];
             }
         }
     }
@@ -337,7 +334,7 @@ static WTRChoice wtr_choose(int N, int Cin, int Cout, int D, int H, int W) {
 size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
     if (Cin % 16 || Cout % 16) return 0;
     const WTRChoice c = wtr_choose(N, Cin, Cout, D, H, W);
-    return (size_t)c.nbx * 27 * Cout * Cin * sizeof(float);
+    return (size_t)c.nbx * (c.ot == 1 ? 4 : 2) * 27 * Cout * Cin * sizeof(float);       // one partial per (workgroup, wave share)
 }
 
 template <int OT>
@@ -357,7 +354,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
     const int total = 27 * co * ci;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, nbx, 27, a.Cout, a.Cin,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, nbx * (OT == 1 ? 4 : 2), 27, a.Cout, a.Cin,
                        co, ci, a.dw, ci * 27, 27, 0);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
