@@ -76,7 +76,7 @@ class UNetEngine:
         self.precision = precision
 
     def _workspace(self, n, d, h, w, training, device):
-        key = (n, d, h, w, bool(training), str(device))
+        key = (n, d, h, w, bool(training), str(device), self.precision)      # the two precisions keep different scratch tensors
         if self._ws is None or self._ws_key != key:
             nbytes = L.load().ru_unet_workspace_bytes(self.h, n, d, h, w, int(training))
             if nbytes == 0:

@@ -253,3 +253,18 @@ def test_unet128_forward_bf16x3_mask_and_probs(golden):
     assert diff.sum() <= 1e-4 * mask.size
     d = O.dice_metric(mask.astype(np.float32), ref_mask.astype(np.float32))
     assert (d > 1.0 - 1e-4).all()
+
+
+def test_precision_switch_reallocates_workspace():
+    """the two precisions keep different scratch tensors: switching on an unchanged shape must not reuse the other's arena size
+    (the library reports a too-small workspace loudly; the engine wrapper has to size per precision)"""
+    from brats2019_amd import model as M
+    torch.manual_seed(0)
+    net = M.UNet(4, [1, 2, 2, 4], [1, 1, 1, 1], [16, 32, 64, 128], 3).cuda()
+    x = torch.randn(2, 4, 32, 32, 32, device="cuda")
+    for prec in ("f32", "bf16x3", "f32", "bf16x3"):
+        net.set_precision(prec)
+        net.zero_grad()
+        p = net([x])[0]
+        p.mean().backward()
+        assert torch.isfinite(p).all() and all(torch.isfinite(q.grad).all() for q in net.parameters() if q.grad is not None)
