@@ -776,8 +776,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 // ------------------------------------------------------------------ weight fragments
 // unit u = ((cog*nchunk + chunk)*14 + ks)*2 + hl, 64 lanes x 16 bytes each: lane l (col = l&15, k-group g = l>>4) holds,
 // for e = 0..7, W[cout = cog*16 + col][cin = chunk*16 + (g&1)*8 + e][tap = 2*ks + (g>>1)].
-__global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int i) {
     const int total = ncog * nchunk * SB_KSTEPS * 64;
     if (i >= total) return;
     const int lane = i & 63;
@@ -802,6 +801,34 @@ __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restr
     const size_t unit = ((size_t)(cog * nchunk + chunk) * SB_KSTEPS + ks) * 2;
     wfrag[(unit + 0) * 64 + lane] = hi;
     wfrag[(unit + 1) * 64 + lane] = lo;
+}
+__global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
+    sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// all 3x3x3 weights of a network in ONE launch (blockIdx.y = entry): the ~50 pack launches of a training step were 4.5 us each,
+// almost all of it launch latency (5 % of a batch-1 forward)
+__global__ void conv3_sb_pack_batch_kernel(const SbPackBatch b) {
+    const SbPackEntry& e = b.e[blockIdx.y];
+    sb_pack_one(e.w, reinterpret_cast<u32x4*>(e.wfrag), e.Cin_f, e.Cout_f, e.mode, e.nchunk, e.ncog, blockIdx.x * blockDim.x + threadIdx.x);
+}
+int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
+    if (b.n == 0) return RU_OK;
+    int maxtotal = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const int t = b.e[i].ncog * b.e[i].nchunk * SB_KSTEPS * 64;
+        if (t > maxtotal) maxtotal = t;
+    }
+    hipLaunchKernelGGL(conv3_sb_pack_batch_kernel, dim3(cdiv(maxtotal, 256), b.n), dim3(256), 0, s, b);
+    RU_CHECK_LAUNCH("conv3_sb_pack_batch_kernel");
+    b.n = 0;
+    return RU_OK;
+}
+int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
+    if (b.n == RU_PACK_BATCH) { const int rc = conv3_sb_pack_batch(b, s); if (rc) return rc; }
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    SbPackEntry& e = b.e[b.n++];
+    e.w = w; e.wfrag = wfrag; e.Cin_f = Cin_f; e.Cout_f = Cout_f; e.mode = mode; e.nchunk = cdiv(cin_conv, 16); e.ncog = cdiv(cout_conv, 16);
+    return RU_OK;
 }
 
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {

@@ -277,9 +277,11 @@ static inline float* G(const ru_unet* h, float* grads, int idx) { return grads ?
 
 static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     float* pk = h->pack;
-    // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments)
+    SbPackBatch batch;
+    batch.n = 0;
+    // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments, all in one launch)
     auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
-        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
+        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
         // outside the voxel-major flow the f32 layout is always kept: ragged W falls back to the f32 kernel
         if (!h->c16) RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
         return RU_OK;
@@ -304,9 +306,11 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     for (auto& lv : h->enc_blocks) for (auto& b : lv) { int rc = blk(b); if (rc) return rc; }
     for (int i = 0; i < h->depth - 1; ++i) for (auto& b : h->dec_blocks[i]) { int rc = blk(b); if (rc) return rc; }
     for (int i = 0; i < h->depth - 1; ++i) {
+        if (h->c16 && !h->training) continue;             // the C16 forward reads the 1x1 weights as stored; the transposes feed its backward only
         RU_RUN(transpose_launch(P(h, params, h->up_w[i]), pk + h->pk_upT[i], h->ch[i], h->ch[i + 1], s));
         RU_RUN(transpose_launch(P(h, params, h->dec1_w[i]), pk + h->pk_decT[i], h->ch[i], 2 * h->ch[i], s));
     }
+    RU_RUN(conv3_sb_pack_batch(batch, s));
     return RU_OK;
 }
 
