@@ -245,10 +245,15 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                 const bool ok = (vmask >> r) & 1u;
                 const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
                 float t[8];
+                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float u = fmaf(f[c], sc[c], sh[c]);
-                    t[c] = ok ? fmaxf(u, u * slope) : 0.f;          // zero padding applies to the ACTIVATED tensor
+                    for (int c = 0; c < 8; ++c) {
+                        const float u = fmaf(f[c], sc[c], sh[c]);
+                        t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
                 split8(t, hi, lo);
@@ -578,10 +583,15 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const bool ok = (vmask >> r) & 1u;
                 const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
                 float t[8];
+                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float u = fmaf(f[c], sc[c], sh[c]);
-                    t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                    for (int c = 0; c < 8; ++c) {
+                        const float u = fmaf(f[c], sc[c], sh[c]);
+                        t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
                 split8(t, hi, lo);

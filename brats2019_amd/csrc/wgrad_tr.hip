@@ -239,10 +239,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = (mx >> r) & 1u;
                 const float f[8] = {vx[r][0].x, vx[r][0].y, vx[r][0].z, vx[r][0].w, vx[r][1].x, vx[r][1].y, vx[r][1].z, vx[r][1].w};
                 float t[8];
+                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float u2 = fmaf(f[c], sc[c], sh[c]);
-                    t[c] = ok ? fmaxf(u2, u2 * slope) : 0.f;       // zero padding applies to the ACTIVATED tensor
+                    for (int c = 0; c < 8; ++c) {
+                        const float u2 = fmaf(f[c], sc[c], sh[c]);
+                        t[c] = ok ? fmaxf(u2, u2 * slope) : 0.f;   // zero padding applies to the ACTIVATED tensor
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
                 wt_split8(t, hi, lo);
