@@ -8,8 +8,11 @@ A "step" is one data-parallel training step on synthetic 128^3 4-modality crops,
 configs[2]/[3]; weak scaling): UNet forward + Dice/BCE criterion + backward + RCCL all-reduce of the criterion
 sums and of the flat gradient buffer + Adam(amsgrad) -- every kernel hand-written HIP behind the C-ABI.  Inputs
 are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=1 it also carries
-  roofline     : the dominant kernel (conv3_f32_kernel<4,8,8,1>, the 16->16 3x3x3 conv at 128^3) timed live with HIP
-                 events on the launch stream: algorithmic FLOPs / average launch time vs the f32 MFMA peak,
+  roofline     : the dominant kernel (the 16->16 3x3x3 conv at 4 x 128^3: conv3_sb2_kernel on voxel-major tensors in the default
+                 split-bf16 mode, conv3_f32_kernel with --precision f32) timed live with HIP events on the launch stream:
+                 algorithmic bytes / average launch time vs the HBM peak (split-bf16: the memory side limits, see the comment in
+                 roofline_probe), algorithmic FLOPs vs the f32 MFMA peak (f32); `traffic` = HBM bytes from the PMC passes
+                 committed under profiles/,
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample,
   fwd          : forward-only volumes/s at batch 1 (BASELINE configs[1]).
 """
