@@ -783,6 +783,246 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     }
 }
 
+// ------------------------------------------------------------------ few input channels (network input: 4; head gradient: 3)
+// conv3_sb2c4_kernel: the same persistent producer/consumer skeleton for Cin <= 4, where padding the channels to 16 would make
+// 3/4 of the MFMA work multiplications by zero.  Input: "C4" copy [N][D][H][W][4] (pad_to_c4).  A 16-byte LDS packet holds the 4
+// channels of position p AND of p+1, so one A fragment carries TWO dx taps of 4 channels: K-step = 4 tap pairs, tap pair t =
+// ((dz,dy) row t>>1, side t&1: dx {0,1} or {2, -}) -> 18 pairs = 5 K-steps instead of 14, 120 MFMAs per item instead of 336; the
+// kernel then runs at the speed of its output stores.  No fused input transform (neither caller has one).
+constexpr int SB4_KSTEPS = 5;
+__host__ __device__ constexpr int sb4_tap(int t, int half) {          // tap index of K-slot half (0: first 4 K values, 1: last 4) of pair t; -1: none
+    const int r = t >> 1, side = t & 1;
+    if (r >= 9) return -1;
+    const int dx = side * 2 + half;
+    return dx > 2 ? -1 : r * 3 + dx;
+}
+
+template <bool OUT16>
+__global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx) {
+    constexpr int TZ = 4, TY = 8;
+    using P = SB<TZ, TY>;
+    constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NROW = P::NROW;
+    constexpr int BUF = 2 * HVOLP;                      // packets per LDS buffer: [hi/lo][pos]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* lds = reinterpret_cast<u32x4*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int rw = wave & 3, ptid = tid & 255;
+    const int cog = blockIdx.y;
+    const int D = a.D, H = a.H, W = a.W;
+    const size_t DHW = (size_t)D * H * W;
+    const int tiles_per_sample = ntz * nty * ntx;
+    const int ntile = a.N * tiles_per_sample;
+    const int G = gridDim.x;
+    const int swz = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int nitems = swz < ntile ? (ntile - swz + G - 1) / G : 0;
+
+    auto tile_origin = [&](int item, int& n, int& z0, int& y0, int& x0) {
+        int b = swz + item * G;
+        n = b / tiles_per_sample;
+        b -= n * tiles_per_sample;
+        const int tx = b % ntx; b /= ntx;
+        const int ty = b % nty;
+        const int tz = b / nty;
+        z0 = tz * TZ; y0 = ty * TY; x0 = tx * 16;
+    };
+
+    if (producer) {
+        constexpr int NPOS = NROW * HX, NR = (NPOS + 255) / 256;
+        float4 va[NR], vb[NR];
+        unsigned ma = 0, mb = 0;
+        auto issue = [&](int item) {
+            int n, z0, y0, x0;
+            tile_origin(item, n, z0, y0, x0);
+            const float4* xb = reinterpret_cast<const float4*>(a.x) + (size_t)n * DHW;
+            ma = 0; mb = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 256 + ptid;
+                const int row = p / HX, xc = p - row * HX;
+                const int hz = row / HY, hy = row - hz * HY;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
+                const bool rok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H;
+                const bool oka = rok && (unsigned)gx < (unsigned)W, okb = rok && xc + 1 < HX && (unsigned)(gx + 1) < (unsigned)W;
+                const size_t rb = rok ? (size_t)(gz * H + gy) * W : 0;
+                ma |= oka ? (1u << r) : 0u;
+                mb |= okb ? (1u << r) : 0u;
+                va[r] = xb[rb + (oka ? gx : 0)];                 // unconditional, clamped
+                vb[r] = xb[rb + (okb ? gx + 1 : 0)];
+            }
+        };
+        auto store = [&](u32x4* buf) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int p = r * 256 + ptid;
+                if ((r + 1) * 256 > NPOS && p >= NPOS) continue;
+                const bool oka = (ma >> r) & 1u, okb = (mb >> r) & 1u;
+                const float t[8] = {oka ? va[r].x : 0.f, oka ? va[r].y : 0.f, oka ? va[r].z : 0.f, oka ? va[r].w : 0.f,
+                                    okb ? vb[r].x : 0.f, okb ? vb[r].y : 0.f, okb ? vb[r].z : 0.f, okb ? vb[r].w : 0.f};
+                u32x4 hi, lo;
+                split8(t, hi, lo);
+                buf[p] = hi;
+                buf[HVOLP + p] = lo;
+            }
+        };
+        if (nitems > 0) {
+            issue(0);
+            store(lds);
+            if (nitems > 1) issue(1);
+        }
+        __syncthreads();
+        for (int w = 0; w < nitems; ++w) {
+            if (w + 1 < nitems) {
+                store(lds + ((w + 1) & 1) * BUF);
+                if (w + 2 < nitems) issue(w + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
+        const int kg = lane >> 4;
+        int aoff[SB4_KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < SB4_KSTEPS; ++ks) {
+            int t = 4 * ks + kg;
+            if (t > 17) t = 17;                          // phantom pairs 18, 19: zero weights, any valid address
+            const int r = t >> 1, dz = r / 3, dy = r % 3, dxb = (t & 1) * 2;
+            aoff[ks] = ((mz + dz) * HY + my0 + dy) * HX + dxb + (lane & 15);
+        }
+        u32x4 wreg[SB4_KSTEPS][2];
+        {
+            const u32x4* wp = wfrag + ((size_t)cog * (SB4_KSTEPS * 2)) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < SB4_KSTEPS; ++ks) {
+                wreg[ks][0] = wp[(ks * 2 + 0) * 64];
+                wreg[ks][1] = wp[(ks * 2 + 1) * 64];
+            }
+        }
+        auto mm = [](const bf16x8& av, const bf16x8& wv, const f32x4& c) -> f32x4 {
+            if constexpr (OUT16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
+        };
+        constexpr int NS = OUT16 ? 4 : 1;
+        float s1[NS], s2[NS];
+#pragma unroll
+        for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
+        unsigned flushed = 0;
+        int n_acc = -1;
+        auto flush_stats = [&](int n) {
+            sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+            flushed |= 1u << (n & 31);
+#pragma unroll
+            for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        };
+        f32x4 acc[MT];
+        __syncthreads();                                // item 0 is staged
+        for (int w = 0; w < nitems; ++w) {
+            const u32x4* buf = lds + (w & 1) * BUF;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + i * HX]);
+                al[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + HVOLP + i * HX]);
+            }
+            static_for<SB4_KSTEPS>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                constexpr bool more = ks + 1 < SB4_KSTEPS;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                const int nofs = aoff[more ? ks + 1 : ks];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    acc[i] = mm(al[i], bh, acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && i > 0) {
+                        al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + HVOLP + (i - 1) * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    acc[i] = mm(ah[i], bl, acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && i == 0) {
+                        al[MT - 1] = __builtin_bit_cast(bf16x8, buf[nofs + HVOLP + (MT - 1) * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    acc[i] = mm(ah[i], bh, acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        ah[i] = __builtin_bit_cast(bf16x8, buf[nofs + i * HX]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+            int n, z0, y0, x0;
+            tile_origin(w, n, z0, y0, x0);
+            if (n != n_acc) {
+                if (n_acc >= 0) flush_stats(n_acc);
+                n_acc = n;
+            }
+            const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+            float4 radd[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int yy = y0 + my0 + i;
+                radd[i] = a.add ? *reinterpret_cast<const float4*>(a.add + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0))
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
+            __syncthreads();
+        }
+        if (n_acc >= 0) flush_stats(n_acc);
+        if (a.stat_partials) {
+            for (int n = 0; n < a.N; ++n)
+                if (n >= 32 || !((flushed >> n) & 1u)) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+        }
+    }
+}
+
+// weight fragments of the 4-channel kernel: unit (cog*5 + ks)*2 + hl, lane (col, g): pair t = 4*ks + g, elements e < 4: channel e at
+// the first tap of the pair, e >= 4: channel e - 4 at the second
+__global__ void conv3_sb_pack4_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int ncog) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncog * SB4_KSTEPS * 64) return;
+    const int lane = i & 63, ks = (i >> 6) % SB4_KSTEPS, cog = (i >> 6) / SB4_KSTEPS;
+    const int col = lane & 15, g = lane >> 4, t = 4 * ks + g;
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    const int co = cog * 16 + col;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int tap = sb4_tap(t, e >> 2), ci = e & 3;
+        float x = 0.f;
+        if (tap >= 0 && ci < cin_conv && co < cout_conv)
+            x = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+        v[e] = x;
+    }
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    const size_t unit = ((size_t)cog * SB4_KSTEPS + ks) * 2;
+    wfrag[(unit + 0) * 64 + lane] = hi;
+    wfrag[(unit + 1) * 64 + lane] = lo;
+}
+size_t conv3_sb4_frag_bytes(int Cout_conv) { return (size_t)cdiv(Cout_conv, 16) * SB4_KSTEPS * 2 * 64 * 16; }
+int conv3_sb4_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    RU_REQUIRE(cin_conv <= 4, "conv3_sb4: at most 4 input channels");
+    const int ncog = cdiv(cout_conv, 16);
+    hipLaunchKernelGGL(conv3_sb_pack4_kernel, dim3(cdiv(ncog * SB4_KSTEPS * 64, 256)), dim3(256), 0, s, w, (u32x4*)wfrag, Cin_f, Cout_f, mode, ncog);
+    RU_CHECK_LAUNCH("conv3_sb_pack4_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ weight fragments
 // unit u = ((cog*nchunk + chunk)*14 + ks)*2 + hl, 64 lanes x 16 bytes each: lane l (col = l&15, k-group g = l>>4) holds,
 // for e = 0..7, W[cout = cog*16 + col][cin = chunk*16 + (g&1)*8 + e][tap = 2*ks + (g>>1)].
@@ -929,7 +1169,35 @@ static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     return RU_OK;
 }
 
+bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W) {
+    return Cin <= 4 && sb_use_v2(sb_choose(N, Cout, D, H, W));
+}
+
+template <bool OUT16>
+static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
+    using P = SB<4, 8>;
+    static bool attr_done = false;
+    constexpr int LDS = 2 * 2 * P::HVOLP * 16;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2c4_kernel<OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2c4)");
+        attr_done = true;
+    }
+    RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2c4: at most 32 samples per call when statistics are requested");
+    dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
+    hipLaunchKernelGGL((conv3_sb2c4_kernel<OUT16>), grid, dim3(512), LDS, s, a, (const u32x4*)a.wfrag, cdiv(a.D, 4), cdiv(a.H, 8), cdiv(a.W, 16));
+    RU_CHECK_LAUNCH("conv3_sb2c4_kernel");
+    return RU_OK;
+}
+
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
+    if (a.in_c4) {
+        RU_REQUIRE(a.Cin <= 4 && !a.in_scale, "conv3_sb: the 4-channel kernel takes Cin <= 4 and no fused input transform");
+        RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
+        const SBChoice c4 = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
+        RU_REQUIRE(sb_use_v2(c4), "conv3_sb: the 4-channel kernel needs at least 256 (4,8,16) tiles x cout groups");
+        return a.out_c16 ? sb2c4_cfg<true>(a, s) : sb2c4_cfg<false>(a, s);
+    }
     RU_REQUIRE((a.W & 3) == 0 || (a.in_c16 && a.out_c16), "conv3_sb: W must be a multiple of 4 for NCDHW tensors");
     RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_sb: C16 input needs Cin %% 16 == 0");
     RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");

@@ -316,7 +316,8 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
 
 // y = conv3(x) with optional fused input transform, tile statistics -> GNSave (mean/rstd/scale/shift)
 static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, const char* wf, float* y, const GNSave* in_gn,
-                    const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W, bool x_c16 = true) {
+                    const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W, bool x_c16 = true,
+                    bool x_c4 = false) {
     const int nblk = h->c16 ? conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
     out_gn.mean = A.alloc((size_t)N * kGroups);
@@ -330,7 +331,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.in_slope = kSlope;
     a.stat_partials = partials;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
-    a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16;
+    a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16; a.in_c4 = x_c4;
     RU_RUN(conv3_launch(a, s));
     RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
                               (size_t)D * H * W, kGroups, kEps, s));
@@ -396,7 +397,17 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     const int C0 = h->ch[0];
     h->x_in = x;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0], false);
+    if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
+        // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
+        float* x4 = A.alloc((size_t)N * 4 * Vl(0));
+        float* wf4 = A.alloc(conv3_sb4_frag_bytes(C0) / sizeof(float) + 64);
+        RU_RUN(pad_to_c4_launch(x, x4, N, kInCh, Vl(0), s));
+        RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_in), wf4, kInCh, C0, 0, s));
+        rc = conv3_gn(h, A, s, x4, nullptr, reinterpret_cast<const char*>(wf4), h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0,
+                      N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, true);
+    } else {
+        rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0], false);
+    }
     if (rc) return rc;
     h->t0 = A.alloc((size_t)N * C0 * Vl(0));
     if (h->c16) RU_RUN(gn_apply16_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
@@ -615,6 +626,13 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
     dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.out_c16 = c16; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
+    if (c16 && conv3_sb4_usable(N, h->nout, C0, Dl[0], Hl[0], Wl[0])) {      // few input channels: 4-channel copy + tap-pair kernel
+        float* d4 = A.alloc((size_t)N * 4 * Vl(0));
+        float* wf4 = A.alloc(conv3_sb4_frag_bytes(C0) / sizeof(float) + 64);
+        RU_RUN(pad_to_c4_launch(dlog, d4, N, h->nout, Vl(0), s));
+        RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_out_w), wf4, C0, h->nout, 1, s));
+        dh.x = d4; dh.wfrag = wf4; dh.in_c4 = 1;
+    }
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
     std::vector<const float*> dskip(depth - 1, nullptr);
@@ -1078,6 +1096,18 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     a.mode = RU_PREC_BF16X3; a.wfrag = wf;
     a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    if (flags & 4) {                                             // x NCDHW with Cin <= 4: 4-channel copy + tap-pair kernel
+        RU_REQUIRE(!(flags & 1) && conv3_sb4_usable(N, Cin, Cout, D, H, W), "ru_conv3d_fwd_l: shape does not fit the 4-channel kernel");
+        const size_t V = (size_t)D * H * W;
+        float* x4 = C.take((size_t)N * 4 * V);
+        void* wf4 = C.take(conv3_sb4_frag_bytes(Cout) / 4 + 64);
+        RU_WS_OK(C);
+        rc = pad_to_c4_launch(x, x4, N, Cin, V, s);
+        if (rc) return rc;
+        rc = conv3_sb4_pack_weights(w, wf4, Cin, Cout, 0, s);
+        if (rc) return rc;
+        a.x = x4; a.wfrag = wf4; a.in_c4 = 1;
+    }
     return conv3_sb_launch(a, s);
 }
 

@@ -922,6 +922,26 @@ int pad_to_c16_launch(const float* src, float* dst, int N, int C, size_t V, hipS
     return RU_OK;
 }
 
+__global__ __launch_bounds__(256) void pad_to_c4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, size_t V) {
+    const size_t n = blockIdx.y;
+    const float* sp = src + n * C * V;
+    float4* dp = reinterpret_cast<float4*>(dst) + n * V;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+        float4 o;
+        o.x = sp[v];
+        o.y = C > 1 ? sp[V + v] : 0.f;
+        o.z = C > 2 ? sp[2 * V + v] : 0.f;
+        o.w = C > 3 ? sp[3 * V + v] : 0.f;
+        dp[v] = o;
+    }
+}
+int pad_to_c4_launch(const float* src, float* dst, int N, int C, size_t V, hipStream_t s) {
+    RU_REQUIRE(C > 0 && C <= 4, "pad_to_c4: 1..4 channels");
+    hipLaunchKernelGGL(pad_to_c4_kernel, dim3(grid1d(V, 256, 4096), (unsigned)N), dim3(256), 0, s, src, dst, C, V);
+    RU_CHECK_LAUNCH("pad_to_c4_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ evaluation metric (metrics.py:108-133)
 // per (sample, channel): counts[row] = { sum(p>0.5 & g>0.5), sum(p>0.5) + sum(g>0.5) } as integers (order independent)
 __global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ p, const float* __restrict__ g,

@@ -52,6 +52,7 @@ struct Conv3Args {
     // Engine-internal voxel-major layout "C16" (split-bf16 kernels only): [N][C/16][D][H][W][16], C % 16 == 0.
     // in_c16: x (and in_scale/in_shift semantics unchanged); out_c16: y, add.  0 = NCDHW.
     int in_c16, out_c16;
+    int in_c4;               // x is a [N][D][H][W][4] copy (pad_to_c4) of a tensor with Cin <= 4: conv3_sb2c4_kernel, wfrag from conv3_sb4_pack_weights
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
@@ -64,6 +65,9 @@ int conv3_launch(const Conv3Args& a, hipStream_t s);
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s);
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);
+size_t conv3_sb4_frag_bytes(int Cout_conv);
+int conv3_sb4_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);
+bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W);                                   // shape fits the 4-channel kernel
 int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);   // mode 0 fwd, 1 data-gradient
 // the same for many weights in one launch: add entries, then flush (add flushes by itself when the table is full)
 constexpr int RU_PACK_BATCH = 64;
@@ -145,6 +149,8 @@ int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream
 int layout_convert_launch(const float* src, float* dst, int N, int C, size_t V, int to_c16, hipStream_t s);
 // NCDHW [N][C][V] with C < 16 -> one zero-padded C16 block [N][1][V][16]
 int pad_to_c16_launch(const float* src, float* dst, int N, int C, size_t V, hipStream_t s);
+// NCDHW [N][C][V] with C <= 4 -> zero-padded [N][V][4]
+int pad_to_c4_launch(const float* src, float* dst, int N, int C, size_t V, hipStream_t s);
 
 // space-to-depth for the 2x2x2 stride-2 conv: y[n][c*8 + (i*4+j*2+k)][z][y][x] = x[n][c][2z+i][2y+j][2x+k]
 int s2d_launch(const float* x, float* y, int N, int C, int D, int H, int W, hipStream_t s);   // D,H,W = input (even)

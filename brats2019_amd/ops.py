@@ -239,8 +239,9 @@ def from_c16(x):
     return y
 
 
-def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False):
-    """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16)."""
+def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False):
+    """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16); few_channels: NCDHW input
+    with Cin <= 4 through the 4-channel tap-pair kernel."""
     x, w, bias = _prep(x), _prep(w), _prep(bias)
     if in_c16:
         n, cb, d, h, wd, _ = (int(v) for v in x.shape)
@@ -250,8 +251,9 @@ def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False):
     cout = int(w.shape[0])
     y = torch.empty((n, cout // 16, d, h, wd, 16) if out_c16 else (n, cout, d, h, wd), dtype=torch.float32, device=x.device)
     lib = L.load()
-    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3), x.device)
-    L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd, int(in_c16) | (int(out_c16) << 1),
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3) + (n * d * h * wd * 16 + 65536 if few_channels else 0), x.device)
+    L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd,
+                                int(in_c16) | (int(out_c16) << 1) | (int(few_channels) << 2),
                                 L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd_l")
     return y
 

@@ -81,3 +81,20 @@ def test_engine_c16_flow_matches_ncdhw_flow_multi_sample():
     print("worst relative L2 gradient difference: %.2e (%s)" % worst)
     for n in ga:
         assert float((ga[n] - gb[n]).norm()) < 2e-2 * float(ga[n].norm()) + 1e-12, n
+
+
+@pytest.mark.parametrize("cin,out16", [(4, True), (3, True), (4, False), (1, True)])
+def test_conv3_few_input_channels(cin, out16):
+    """4-channel tap-pair kernel (network input / head gradient) against the 16-channel-padded split-bf16 kernel and the exact
+    convolution: same products, another summation order -> 2e-5 of the largest output"""
+    from brats2019_amd import ops
+    n, cout, d, h, w = 2, 16, 32, 32, 64
+    x = _rand(n, cin, d, h, w, seed=5)
+    wt = _rand(cout, cin, 3, 3, 3, seed=6) * 0.2
+    exact = torch.nn.functional.conv3d(x.double(), wt.double(), padding=1).float()
+    ref = ops.conv3d(x, wt, precision="bf16x3")
+    y = ops.conv3d_layout(x, wt, out_c16=out16, few_channels=True)
+    if out16:
+        y = ops.from_c16(y)
+    tol = 2e-5 * float(exact.abs().max())
+    assert float((y - exact).abs().max()) < tol and float((ref - exact).abs().max()) < tol
