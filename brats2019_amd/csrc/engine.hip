@@ -135,6 +135,7 @@ struct ru_unet {
     size_t ws_bytes = 0, fwd_end = 0;
     float* pack = nullptr;
     const float* x_in = nullptr;
+    const float* x_in4 = nullptr;   // 4-channel copy of the input made for the stem conv (C16 flow), reused by its weight gradient
     float *y0 = nullptr, *t0 = nullptr, *probs = nullptr;
     GNSave g0;
     const float* head_in = nullptr;
@@ -396,11 +397,13 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     // stem: conv_input -> norm_input (no activation, model.py:412-413)
     const int C0 = h->ch[0];
     h->x_in = x;
+    h->x_in4 = nullptr;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
     if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
         // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
         float* x4 = A.alloc((size_t)N * 4 * Vl(0));
         float* wf4 = A.alloc(conv3_sb4_frag_bytes(C0) / sizeof(float) + 64);
+        h->x_in4 = x4;
         RU_RUN(pad_to_c4_launch(x, x4, N, kInCh, Vl(0), s));
         RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_in), wf4, kInCh, C0, 0, s));
         rc = conv3_gn(h, A, s, x4, nullptr, reinterpret_cast<const char*>(wf4), h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0,
@@ -507,15 +510,20 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
 }
 
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
-                      bool x_c16 = false, bool dy_c16 = false) {
+                      bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr) {
     if (x_c16 != dy_c16 && mode == RU_PREC_BF16X3 && Cin <= 16 && Cout <= 16) {
-        // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side is copied into one zero-padded
-        // voxel-major block so the transpose-read kernel runs (0.42 + 0.11 ms instead of 0.74-0.88 ms at 4 x 128^3)
+        // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side enters the transpose-read kernel as a
+        // 16-channel block that is zero beyond its real channels -- from the 4-channel copy the conv of that tensor already made
+        // (`few4`), else from a zero-padded voxel-major copy made here
         const size_t V = (size_t)D * H * W;
-        float* pad = A.alloc((size_t)N * 16 * V);
-        RU_RUN(pad_to_c16_launch(x_c16 ? dy : x, pad, N, x_c16 ? Cout : Cin, V, s));
+        const int cfew = x_c16 ? Cout : Cin;
+        const bool use4 = few4 != nullptr && cfew <= 4;
+        float* pad = use4 ? nullptr : A.alloc((size_t)N * 16 * V);
+        if (!use4) RU_RUN(pad_to_c16_launch(x_c16 ? dy : x, pad, N, cfew, V, s));
+        const float* fewp = use4 ? few4 : pad;
         Wgrad3Args w{};
-        w.x = x_c16 ? x : pad; w.dy = x_c16 ? pad : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
+        w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
+        w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0;
         w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
         w.dw_cin = Cin; w.dw_cout = Cout;
         w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
@@ -616,7 +624,10 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dlog = A.alloc((size_t)N * h->nout * Vl(0));
     RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
     const bool c16 = h->c16;
-    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false);
+    const bool head4 = c16 && conv3_sb4_usable(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);      // few channels: one 4-channel copy feeds both head kernels
+    float* d4 = head4 ? A.alloc((size_t)N * 4 * Vl(0)) : nullptr;
+    if (head4) RU_RUN(pad_to_c4_launch(dlog, d4, N, h->nout, Vl(0), s));
+    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
     if (rc) return rc;
     {
         const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
@@ -626,10 +637,8 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
     dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.out_c16 = c16; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];
-    if (c16 && conv3_sb4_usable(N, h->nout, C0, Dl[0], Hl[0], Wl[0])) {      // few input channels: 4-channel copy + tap-pair kernel
-        float* d4 = A.alloc((size_t)N * 4 * Vl(0));
+    if (head4) {                                                 // few input channels: tap-pair kernel on the 4-channel copy
         float* wf4 = A.alloc(conv3_sb4_frag_bytes(C0) / sizeof(float) + 64);
-        RU_RUN(pad_to_c4_launch(dlog, d4, N, h->nout, Vl(0), s));
         RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_out_w), wf4, C0, h->nout, 1, s));
         dh.x = d4; dh.wfrag = wf4; dh.in_c4 = 1;
     }
@@ -718,7 +727,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
     rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16);
+    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks

@@ -95,6 +95,7 @@ struct Wgrad3Args {
     int mode;                // RU_PREC_F32 / RU_PREC_BF16X3 (split-bf16 kernel, wgrad_sb.hip; needs W % 4 == 0)
     int x_c16, dy_c16;       // voxel-major x / dy (split-bf16 kernel only); 0 = NCDHW
     int dw_cin, dw_cout;     // wgrad_tr only: real channel counts of dw when x / dy are zero-padded to 16 channels (0 = Cin / Cout)
+    int x_c4, dy_c4;         // wgrad_tr only: that operand is a [N][D][H][W][4] copy (pad_to_c4) standing for a 16-channel block whose channels 4..15 are zero
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);

@@ -197,10 +197,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool live = pl < npl;
                 const bool ok = live && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                mx |= ok ? (1u << r) : 0u;
-                if (r * 128 < npl * PPOS) {              // wave-uniform: rounds beyond the new planes issue nothing
-                    vx[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
-                    vx[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
+                if (a.x_c4) {                            // 4-channel copy: channels 0-3 real (half 0), the rest of the block is zero
+                    mx |= (ok && hsel == 0) ? (1u << r) : 0u;
+                    if (r * 128 < npl * PPOS) {
+                        vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
+                        vx[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    mx |= ok ? (1u << r) : 0u;
+                    if (r * 128 < npl * PPOS) {          // wave-uniform: rounds beyond the new planes issue nothing
+                        vx[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
+                        vx[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
+                    }
                 }
             }
 #pragma unroll
@@ -213,9 +221,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = p < DPOS && gz < D && gy < H && gx < W;
                 const float* db = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + hsel * 8;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                md |= ok ? (1u << r) : 0u;
-                vd[r][0] = *reinterpret_cast<const float4*>(db + ofs);
-                vd[r][1] = *reinterpret_cast<const float4*>(db + ofs + 4);
+                if (a.dy_c4) {
+                    md |= (ok && hsel == 0) ? (1u << r) : 0u;
+                    vd[r][0] = *reinterpret_cast<const float4*>(a.dy + (size_t)n * DHW * 4 + (ofs >> 2));
+                    vd[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    md |= ok ? (1u << r) : 0u;
+                    vd[r][0] = *reinterpret_cast<const float4*>(db + ofs);
+                    vd[r][1] = *reinterpret_cast<const float4*>(db + ofs + 4);
+                }
             }
             if (xform) {
                 const int cofs = n * a.Cin + cgp * 16 + hsel * 8;
