@@ -10,7 +10,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libresunet_hip.so")
+# RU_LIB_PATH: another build of the same library (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("RU_LIB_PATH") or os.path.join(_PKG, "lib", "libresunet_hip.so")
 
 _lib = None
 PRECISIONS = {"f32": 0, "bf16x3": 1}      # RU_PREC_F32 / RU_PREC_BF16X3

@@ -68,9 +68,8 @@ __device__ __forceinline__ void split8(const float (&t)[8], u32x4& hi, u32x4& lo
 //   C16 output   (OUT16 = true) : the MFMA ran with swapped operands, D[m = cout][n = voxel]: lane = (voxel x0 + (l&15),
 //                                 4 consecutive couts co0 + 4*(l>>4)): one aligned float4 of the voxel-major tensor; NS = 4
 struct SbOut {
-    size_t plane;        // OUT16: ((n*CB + cog)*D + zz)*H ; NCDHW: ((n*Cout + co)*D + zz)*H*W
-    int xx;              // first x of this lane
-    int cq;              // OUT16: channel quad offset inside the voxel
+    size_t base;         // float index of this lane's element in row y = 0 of plane zz; row y is base + y*rs (one v_mad_u64_u32: the
+    unsigned rs;         // epilogue's VALU instructions sit between the consumer's MFMAs, so they are kept few)
     bool ok;             // lane-level validity (z, x, cout)
     float4 bias;
 };
@@ -80,18 +79,18 @@ __device__ __forceinline__ SbOut sb_out_prepare(const Conv3Args& a, int n, int z
     const int D = a.D, H = a.H, W = a.W;
     const int zc = zz < D ? zz : 0;
     if constexpr (OUT16) {
-        o.xx = x0 + (lane & 15);
-        o.cq = 4 * (lane >> 4);
-        o.plane = ((size_t)(n * (a.Cout >> 4) + cog) * D + zc) * H;
-        o.ok = zz < D && o.xx < W;
-        o.bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + cog * 16 + o.cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int xx = x0 + (lane & 15), cq = 4 * (lane >> 4);
+        o.base = ((((size_t)(n * (a.Cout >> 4) + cog) * D + zc) * H) * W + xx) * 16 + cq;
+        o.rs = (unsigned)W * 16u;
+        o.ok = zz < D && xx < W;
+        o.bias = a.bias ? *reinterpret_cast<const float4*>(a.bias + cog * 16 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
         const int co = cog * 16 + (lane & 15);
-        o.xx = x0 + (lane >> 4) * 4;
-        o.cq = 0;
+        const int xx = x0 + (lane >> 4) * 4;
         const int cc = co < a.Cout ? co : 0;
-        o.plane = (((size_t)n * a.Cout + cc) * D + zc) * (size_t)H * W;
-        o.ok = zz < D && co < a.Cout && o.xx < W;            // W % 4 == 0: the 4 voxels are in or out together
+        o.base = (((size_t)n * a.Cout + cc) * D + zc) * (size_t)H * W + xx;
+        o.rs = (unsigned)W;
+        o.ok = zz < D && co < a.Cout && xx < W;              // W % 4 == 0: the 4 voxels are in or out together
         const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
         o.bias = make_float4(b, b, b, b);
     }
@@ -99,20 +98,22 @@ __device__ __forceinline__ SbOut sb_out_prepare(const Conv3Args& a, int n, int z
 }
 template <bool OUT16>
 __device__ __forceinline__ size_t sb_out_index(const Conv3Args& a, const SbOut& o, int yy) {
-    if constexpr (OUT16) return ((o.plane + yy) * a.W + o.xx) * 16 + o.cq;
-    else return o.plane + (size_t)yy * a.W + o.xx;
+    (void)a;
+    return o.base + (size_t)(unsigned)yy * o.rs;
 }
 template <bool OUT16, int NS>
 __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, float (&s1)[NS], float (&s2)[NS]) {
     if (!(o.ok && yy < a.H)) return;
-    v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w;
+    if (a.bias) { v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w; }     // wave-uniform branches
     if (a.add) { v[0] += radd.x; v[1] += radd.y; v[2] += radd.z; v[3] += radd.w; }
-    if constexpr (OUT16) {
+    if (a.stat_partials) {
+        if constexpr (OUT16) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-    } else {
-        s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
-        s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+        } else {
+            s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
     }
     if (a.sigmoid) {
         // hardware exp2 / rcp (1 ulp each): the library expf is ~14 VALU instructions per value, and they sit in the consumer
