@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
             constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
             const int hsel = (tid >> 3) & 1;
             const int pslot = (tid >> 4) * 8 + (tid & 7);
-            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + hsel * 8;
+            const bool s16 = a.in_s16 != 0;              // split form in HBM: hi packet at float offset half*4, lo at 8 + half*4: plain copy
+            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
+            const int second = s16 ? 8 : 4;
             float4 v16[NR][2];
             unsigned vmask = 0;
 #pragma unroll
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
                 vmask |= ok ? (1u << r) : 0u;
                 v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
-                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
+                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + second);
             }
             float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (xform) {
@@ -259,7 +261,13 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                     for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
-                split8(t, hi, lo);
+                if (s16) {
+                    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                    hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
+                    lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
+                } else {
+                    split8(t, hi, lo);
+                }
                 lds[hsel * HVOLP + p] = hi;
                 lds[(2 + hsel) * HVOLP + p] = lo;
             }
@@ -535,6 +543,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
         const int hsel = (ptid >> 3) & 1;
         const int pslot = (ptid >> 4) * 8 + (ptid & 7);
+        const bool s16 = a.in_s16 != 0;                  // split form in HBM (gn_bwd_apply16_launch): the staging is a plain copy of hi / lo packets
         float4 v16[NR][2];
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
             int n, z0, y0, x0, tis;
             tile_origin(tile, n, z0, y0, x0, tis);
-            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + hsel * 8;
+            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
             vmask = 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
                 vmask |= ok ? (1u << r) : 0u;
                 v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
-                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
+                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + (s16 ? 8 : 4));
             }
             if (xform) {
                 const int cofs = n * a.Cin + chunk * 16 + hsel * 8;
@@ -597,7 +606,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
-                split8(t, hi, lo);
+                if (s16) {
+                    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                    hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
+                    lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
+                } else {
+                    split8(t, hi, lo);
+                }
                 buf[hsel * HVOLP + p] = hi;
                 buf[(2 + hsel) * HVOLP + p] = lo;
             }
@@ -1203,6 +1218,7 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     }
     RU_REQUIRE((a.W & 3) == 0 || (a.in_c16 && a.out_c16), "conv3_sb: W must be a multiple of 4 for NCDHW tensors");
     RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_sb: C16 input needs Cin %% 16 == 0");
+    RU_REQUIRE(!a.in_s16 || (a.in_c16 && !a.in_scale), "conv3_sb: a split-form input is voxel-major and has no fused transform");
     RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
     const SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
     if (sb_use_v2(c)) {

@@ -504,13 +504,13 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
     if (c16) RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
     else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
     RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s));
-    if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
+    if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, 1, s));   // split form: read by MFMA kernels only
     else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
     return RU_OK;
 }
 
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
-                      bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr) {
+                      bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr, bool dy_s16 = false) {
     if (x_c16 != dy_c16 && mode == RU_PREC_BF16X3 && Cin <= 16 && Cout <= 16) {
         // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side enters the transpose-read kernel as a
         // 16-channel block that is zero beyond its real channels -- from the 4-channel copy the conv of that tensor already made
@@ -523,7 +523,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         const float* fewp = use4 ? few4 : pad;
         Wgrad3Args w{};
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
-        w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0;
+        w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
         w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
         w.dw_cin = Cin; w.dw_cout = Cout;
         w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
@@ -533,7 +533,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         return RU_OK;
     }
     Wgrad3Args w{};
-    w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16;
+    w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16; w.dy_s16 = dy_s16 ? 1 : 0;
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -565,21 +565,21 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const bool c16 = h->c16;
     int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16);
+    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16);
+    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
-    d1.in_c16 = c16; d1.out_c16 = c16;
+    d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = c16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
@@ -727,7 +727,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
     rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4);
+    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks
@@ -736,7 +736,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         Conv3Args di{};
         if (c16) {                                               // dy0 is voxel-major: the split-bf16 kernel reads it
             RU_RUN(conv3_sb_pack_weights(P(h, params, h->conv_in), wfd, kInCh, C0, 1, s));
-            di.mode = RU_PREC_BF16X3; di.wfrag = wfd; di.in_c16 = 1;
+            di.mode = RU_PREC_BF16X3; di.wfrag = wfd; di.in_c16 = 1; di.in_s16 = 1;
         } else {
             RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), wpd, kInCh, C0, 1, s));
         }

@@ -138,10 +138,47 @@ __global__ __launch_bounds__(256) void gn_bwd_apply16_kernel(const float* __rest
         op[f] = o;
     }
 }
+// the same, output in split form: a thread owns 8 channels (one half) of a voxel: hi packet at voxel*64 + half*16, lo at + 32
+__global__ __launch_bounds__(256) void gn_bwd_apply16_split_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ coef, float slope,
+                                                                   float* __restrict__ dx, int C, size_t V) {
+    const int nb = blockIdx.y, CB = C >> 4;
+    const int n = nb / CB, cb = nb - n * CB;
+    const int hf = threadIdx.x & 1;
+    const size_t row = (size_t)n * C + cb * 16 + 8 * hf;
+    float a[8], b[8], cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = scale[row + k]; b[k] = shift[row + k];
+        cA[k] = coef[(row + k) * 3]; cB[k] = coef[(row + k) * 3 + 1]; cC[k] = coef[(row + k) * 3 + 2];
+    }
+    const size_t base = (size_t)nb * V * 4, F = V * 2;           // float4 units; F = (voxel, half) pairs
+    const float4* xp = reinterpret_cast<const float4*>(x) + base;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    pw_u32x4* op = reinterpret_cast<pw_u32x4*>(dx) + base;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (size_t)gridDim.x * 256) {
+        const size_t v = f >> 1;
+        const float4 t0 = xp[v * 4 + 2 * hf], t1 = xp[v * 4 + 2 * hf + 1], d0 = dp[v * 4 + 2 * hf], d1 = dp[v * 4 + 2 * hf + 1];
+        const float tx[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}, dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = cA[k] * ((tx[k] * a[k] + b[k]) > 0.f ? dd[k] : dd[k] * slope) + (cB[k] * tx[k] + cC[k]);
+        pw_u32x4 hi, lo;
+        pw_split8(o, hi, lo);
+        op[v * 4 + hf] = hi;
+        op[v * 4 + 2 + hf] = lo;
+    }
+}
 int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef, float slope, float* dx,
-                          int N, int C, size_t V, hipStream_t s) {
+                          int N, int C, size_t V, int split, hipStream_t s) {
     RU_REQUIRE(C % 16 == 0, "gn_bwd_apply16: C must be a multiple of 16");
-    hipLaunchKernelGGL(gn_bwd_apply16_kernel, c16_grid(V, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, C, V);
+    if (split) {
+        size_t bx = (V * 2 + 255) / 256;
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(gn_bwd_apply16_split_kernel, dim3((unsigned)bx, (unsigned)(N * (C / 16))), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, C, V);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_apply16_kernel, c16_grid(V, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, coef, slope, dx, C, V);
+    }
     RU_CHECK_LAUNCH("gn_bwd_apply16_kernel");
     return RU_OK;
 }

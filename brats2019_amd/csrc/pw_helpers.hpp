@@ -38,6 +38,26 @@ static inline unsigned grid1d(size_t n, int per_block, unsigned cap = 1u << 20) 
     return (unsigned)(b > cap ? cap : b);
 }
 
+// 8 floats -> 8 bf16 hi (bf16_rne(v)) and 8 bf16 lo (bf16_rne(v - hi)), 16 bytes each (the split-bf16 operand format)
+typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pw_split8(const float (&t)[8], pw_u32x4& hi, pw_u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pw_bf16x2 h;
+        h[0] = (__bf16)t[2 * i];
+        h[1] = (__bf16)t[2 * i + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hb << 16);
+        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+        pw_bf16x2 l;
+        l[0] = (__bf16)(t[2 * i] - h0);
+        l[1] = (__bf16)(t[2 * i + 1] - h1);
+        hi[i] = hb;
+        lo[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
 // ------------------------------------------------------------------ trilinear x2 index helpers (model.py:12-14)
 // source index of output o: src = max(o/2 - 0.25, 0); i0 = floor(src); l1 = src - i0; i1 = i0 + (i0 < n-1)
 __device__ __forceinline__ void up2_src(int o, int n, int& i0, int& i1, float& l0, float& l1) {

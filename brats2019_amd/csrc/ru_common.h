@@ -52,6 +52,7 @@ struct Conv3Args {
     // Engine-internal voxel-major layout "C16" (split-bf16 kernels only): [N][C/16][D][H][W][16], C % 16 == 0.
     // in_c16: x (and in_scale/in_shift semantics unchanged); out_c16: y, add.  0 = NCDHW.
     int in_c16, out_c16;
+    int in_s16;              // x is C16 in SPLIT form (see gn_bwd_apply16_launch): the staging copies hi/lo packets, no conversion, no transform
     int in_c4;               // x is a [N][D][H][W][4] copy (pad_to_c4) of a tensor with Cin <= 4: conv3_sb2c4_kernel, wfrag from conv3_sb4_pack_weights
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
@@ -95,6 +96,7 @@ struct Wgrad3Args {
     int mode;                // RU_PREC_F32 / RU_PREC_BF16X3 (split-bf16 kernel, wgrad_sb.hip; needs W % 4 == 0)
     int x_c16, dy_c16;       // voxel-major x / dy (split-bf16 kernel only); 0 = NCDHW
     int dw_cin, dw_cout;     // wgrad_tr only: real channel counts of dw when x / dy are zero-padded to 16 channels (0 = Cin / Cout)
+    int dy_s16;              // wgrad_tr only: dy is C16 in split form: its staging is a plain copy
     int x_c4, dy_c4;         // wgrad_tr only: that operand is a [N][D][H][W][4] copy (pad_to_c4) standing for a 16-channel block whose channels 4..15 are zero
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
@@ -192,8 +194,11 @@ int gn_apply16_launch(const float* x, const float* scale, const float* shift, co
 int gn_bwd_tiles16(size_t V);
 int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
                            float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
+// split = 1: dx is written in SPLIT form -- per voxel and 16-channel block 64 bytes = [hi bf16 ch 0-7 | hi ch 8-15 | lo ch 0-7 | lo ch 8-15]
+// (hi = bf16(v), lo = bf16(v - hi)): exactly the packets the split-bf16 conv and weight-gradient kernels stage, so their producer
+// waves copy instead of converting (the conversion VALU work was what bounded the weight gradient).  Only MFMA kernels read it.
 int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef, float slope, float* dx,
-                          int N, int C, size_t V, hipStream_t s);
+                          int N, int C, size_t V, int split, hipStream_t s);
 int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, float slope, hipStream_t s);   // D,H,W = coarse extents; LeakyReLU(slope) on the output (1 = none)
 int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
 int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin, hipStream_t s);       // [Cout][Cin][8] -> [Cout][8*Cin], [8*Cin][Cout]

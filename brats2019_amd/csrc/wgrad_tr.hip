@@ -221,7 +221,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = p < DPOS && gz < D && gy < H && gx < W;
                 const float* db = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + hsel * 8;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                if (a.dy_c4) {
+                if (a.dy_s16) {                          // split form in HBM: hi and lo packets of this half, copied as they are
+                    md |= ok ? (1u << r) : 0u;
+                    const float* ds = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 4;
+                    vd[r][0] = *reinterpret_cast<const float4*>(ds);
+                    vd[r][1] = *reinterpret_cast<const float4*>(ds + 8);
+                } else if (a.dy_c4) {
                     md |= (ok && hsel == 0) ? (1u << r) : 0u;
                     vd[r][0] = *reinterpret_cast<const float4*>(a.dy + (size_t)n * DHW * 4 + (ofs >> 2));
                     vd[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,7 +285,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #pragma unroll
                 for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 u32x4 hi, lo;
-                wt_split8(t, hi, lo);
+                if (a.dy_s16) {
+                    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                    hi = ok ? __builtin_bit_cast(u32x4, vd[r][0]) : z;
+                    lo = ok ? __builtin_bit_cast(u32x4, vd[r][1]) : z;
+                } else {
+                    wt_split8(t, hi, lo);
+                }
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + p * 32 + hsel * 16) = hi;
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
             }
