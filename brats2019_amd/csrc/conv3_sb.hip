@@ -243,34 +243,39 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 #pragma unroll
                 for (int c = 0; c < 8; ++c) { sc[c] = a.in_scale[cofs + c]; sh[c] = a.in_shift[cofs + c]; }
             }
+            auto body = [&](auto MODE) {                  // one wave-uniform dispatch, then a branch-free unrolled loop
+                constexpr int mode = decltype(MODE)::value;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int p = r * 128 + pslot;
-                if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
-                const bool ok = (vmask >> r) & 1u;
-                const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
-                float t[8];
-                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
+                for (int r = 0; r < NR; ++r) {
+                    const int p = r * 128 + pslot;
+                    if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
+                    const bool ok = (vmask >> r) & 1u;
+                    u32x4 hi, lo;
+                    if constexpr (mode == 2) {
+                        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                        hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
+                        lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
+                    } else {
+                        const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
+                        float t[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float u = fmaf(f[c], sc[c], sh[c]);
-                        t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                        for (int c = 0; c < 8; ++c) {
+                            if constexpr (mode == 1) {
+                                const float u = fmaf(f[c], sc[c], sh[c]);
+                                t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                            } else {
+                                t[c] = ok ? f[c] : 0.f;
+                            }
+                        }
+                        split8(t, hi, lo);
                     }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
+                    lds[hsel * HVOLP + p] = hi;
+                    lds[(2 + hsel) * HVOLP + p] = lo;
                 }
-                u32x4 hi, lo;
-                if (s16) {
-                    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-                    hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
-                    lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
-                } else {
-                    split8(t, hi, lo);
-                }
-                lds[hsel * HVOLP + p] = hi;
-                lds[(2 + hsel) * HVOLP + p] = lo;
-            }
+            };
+            if (s16) body(std::integral_constant<int, 2>{});
+            else if (xform) body(std::integral_constant<int, 1>{});
+            else body(std::integral_constant<int, 0>{});
         } else {
             // ---- NCDHW input (W % 4 == 0): halo row [x0-1, x0+17) = six aligned 16-byte segments [x0-4+4q, +4); slot = (row, q).
             //      Per slot and channel-half, 8 float4 loads (8 channels x 4 voxels) in flight, then transform + split + transpose
@@ -588,34 +593,40 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 sc[0] = sc4[0].x; sc[1] = sc4[0].y; sc[2] = sc4[0].z; sc[3] = sc4[0].w; sc[4] = sc4[1].x; sc[5] = sc4[1].y; sc[6] = sc4[1].z; sc[7] = sc4[1].w;
                 sh[0] = sh4[0].x; sh[1] = sh4[0].y; sh[2] = sh4[0].z; sh[3] = sh4[0].w; sh[4] = sh4[1].x; sh[5] = sh4[1].y; sh[6] = sh4[1].z; sh[7] = sh4[1].w;
             }
+            // ONE wave-uniform dispatch per item, then a branch-free unrolled loop: mode 0 plain, 1 fused transform, 2 split-form copy
+            auto body = [&](auto MODE) {
+                constexpr int mode = decltype(MODE)::value;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int p = r * 128 + pslot;
-                if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
-                const bool ok = (vmask >> r) & 1u;
-                const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
-                float t[8];
-                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
+                for (int r = 0; r < NR; ++r) {
+                    const int p = r * 128 + pslot;
+                    if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
+                    const bool ok = (vmask >> r) & 1u;
+                    u32x4 hi, lo;
+                    if constexpr (mode == 2) {
+                        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                        hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
+                        lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
+                    } else {
+                        const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
+                        float t[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float u = fmaf(f[c], sc[c], sh[c]);
-                        t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                        for (int c = 0; c < 8; ++c) {
+                            if constexpr (mode == 1) {
+                                const float u = fmaf(f[c], sc[c], sh[c]);
+                                t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
+                            } else {
+                                t[c] = ok ? f[c] : 0.f;
+                            }
+                        }
+                        split8(t, hi, lo);
                     }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
+                    buf[hsel * HVOLP + p] = hi;
+                    buf[(2 + hsel) * HVOLP + p] = lo;
                 }
-                u32x4 hi, lo;
-                if (s16) {
-                    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-                    hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
-                    lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
-                } else {
-                    split8(t, hi, lo);
-                }
-                buf[hsel * HVOLP + p] = hi;
-                buf[(2 + hsel) * HVOLP + p] = lo;
-            }
+            };
+            if (s16) body(std::integral_constant<int, 2>{});
+            else if (xform) body(std::integral_constant<int, 1>{});
+            else body(std::integral_constant<int, 0>{});
         };
         if (nitems > 0) {
             issue(0);

@@ -139,7 +139,10 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
     });
 }
 
-template <int OT>
+// XS: source of x -- 0 C16, 1 C4 copy (a 16-channel block that is zero beyond channel 3).  DS: source of dy -- 0 C16, 1 split C16 (hi/lo
+// packets in HBM, copied), 2 C4 copy.  Compile-time: a runtime branch inside the unrolled load loops breaks the load batches apart
+// (it cost ~100 us per launch when these were kernel arguments).
+template <int OT, int XS, int DS>
 __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WTZ<OT>;
     constexpr int HY = P::HY, HX = P::HX, PPOS = P::PPOS, DPOS = P::DPOS, TY = P::TY;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool live = pl < npl;
                 const bool ok = live && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                if (a.x_c4) {                            // 4-channel copy: channels 0-3 real (half 0), the rest of the block is zero
+                if constexpr (XS == 1) {                 // 4-channel copy: channels 0-3 real (half 0), the rest of the block is zero
                     mx |= (ok && hsel == 0) ? (1u << r) : 0u;
                     if (r * 128 < npl * PPOS) {
                         vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
@@ -221,12 +224,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = p < DPOS && gz < D && gy < H && gx < W;
                 const float* db = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + hsel * 8;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                if (a.dy_s16) {                          // split form in HBM: hi and lo packets of this half, copied as they are
+                if constexpr (DS == 1) {                 // split form in HBM: hi and lo packets of this half, copied as they are
                     md |= ok ? (1u << r) : 0u;
                     const float* ds = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 4;
                     vd[r][0] = *reinterpret_cast<const float4*>(ds);
                     vd[r][1] = *reinterpret_cast<const float4*>(ds + 8);
-                } else if (a.dy_c4) {
+                } else if constexpr (DS == 2) {
                     md |= (ok && hsel == 0) ? (1u << r) : 0u;
                     vd[r][0] = *reinterpret_cast<const float4*>(a.dy + (size_t)n * DHW * 4 + (ofs >> 2));
                     vd[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 sh[0] = sh4[0].x; sh[1] = sh4[0].y; sh[2] = sh4[0].z; sh[3] = sh4[0].w; sh[4] = sh4[1].x; sh[5] = sh4[1].y; sh[6] = sh4[1].z; sh[7] = sh4[1].w;
             }
             const int hp0 = st_k == 0 ? 0 : 2 * st_k + 2, npl = st_k == 0 ? 4 : 2;
+            auto xbody = [&](auto XFORM) {                // one wave-uniform dispatch, then a branch-free unrolled loop
+                constexpr bool XF = decltype(XFORM)::value;
 #pragma unroll
             for (int r = 0; r < NRX; ++r) {
                 if (r * 128 >= npl * PPOS) continue;     // wave-uniform
@@ -258,15 +263,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = (mx >> r) & 1u;
                 const float f[8] = {vx[r][0].x, vx[r][0].y, vx[r][0].z, vx[r][0].w, vx[r][1].x, vx[r][1].y, vx[r][1].z, vx[r][1].w};
                 float t[8];
-                if (xform) {                             // wave-uniform: the conversion VALU work is the expensive part of staging
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < 8; ++c) {
+                    if constexpr (XF) {
                         const float u2 = fmaf(f[c], sc[c], sh[c]);
                         t[c] = ok ? fmaxf(u2, u2 * slope) : 0.f;   // zero padding applies to the ACTIVATED tensor
+                    } else {
+                        t[c] = ok ? f[c] : 0.f;
                     }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo;
                 wt_split8(t, hi, lo);
@@ -275,6 +279,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 *reinterpret_cast<u32x4*>(dst + P::X_OFF) = hi;
                 *reinterpret_cast<u32x4*>(dst + P::XLO_OFF) = lo;
             }
+            };
+            if (xform) xbody(std::true_type{});
+            else xbody(std::false_type{});
 #pragma unroll
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #pragma unroll
                 for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 u32x4 hi, lo;
-                if (a.dy_s16) {
+                if constexpr (DS == 1) {
                     const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                     hi = ok ? __builtin_bit_cast(u32x4, vd[r][0]) : z;
                     lo = ok ? __builtin_bit_cast(u32x4, vd[r][1]) : z;
@@ -367,12 +374,12 @@ size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) 
     return (size_t)c.nbx * (c.ot == 1 ? 4 : 2) * 27 * Cout * Cin * sizeof(float);       // one partial per (workgroup, wave share)
 }
 
-template <int OT>
+template <int OT, int XS, int DS>
 static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     using P = WTZ<OT>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_tz_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_tz_kernel<OT, XS, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_tz)");
         attr_done = true;
     }
@@ -380,7 +387,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     const long ncol = (long)a.N * nty * ntx;
     int nbx = c.nbx;
     if (nbx > ncol) nbx = (int)ncol;
-    hipLaunchKernelGGL((wgrad3_tz_kernel<OT>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
+    hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
     const int total = 27 * co * ci;
@@ -397,7 +404,14 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         set_error("wgrad3_tr: workspace too small");
         return RU_ENOMEM;
     }
-    return c.ot == 2 ? wtz_cfg<2>(a, c, s) : wtz_cfg<1>(a, c, s);
+    const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
+    if (c.ot == 2) {
+        RU_REQUIRE(xs == 0 && ds != 2, "wgrad3_tr: 4-channel copies stand for ONE 16-channel block");
+        return ds == 1 ? wtz_cfg<2, 0, 1>(a, c, s) : wtz_cfg<2, 0, 0>(a, c, s);
+    }
+    if (xs == 1) { RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy"); return ds == 1 ? wtz_cfg<1, 1, 1>(a, c, s) : wtz_cfg<1, 1, 0>(a, c, s); }
+    if (ds == 2) return wtz_cfg<1, 0, 2>(a, c, s);
+    return ds == 1 ? wtz_cfg<1, 0, 1>(a, c, s) : wtz_cfg<1, 0, 0>(a, c, s);
 }
 
 }  // namespace ru
