@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 
     if (producer) {
         // x units: (plane of the new set, halo position, channel half); dy units: (o-block, position, half)
-        constexpr int NRX = (4 * PPOS + 127) / 128, NRD = OT * ((DPOS + 127) / 128);     // first step of a column: 4 planes
+        constexpr int NRX = (4 * PPOS + 127) / 128, NR2 = (2 * PPOS + 127) / 128, NRD = OT * ((DPOS + 127) / 128);     // first step of a column: 4 planes
         const int hsel = ptid & 1, pslot = ptid >> 1;
         float4 vx[NRX][2], vd[NRD][2];
         float4 sc4[2], sh4[2];
@@ -191,8 +191,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             const int hp0 = k == 0 ? 0 : 2 * k + 2, npl = k == 0 ? 4 : 2;       // new halo planes hp0 .. hp0 + npl - 1 (halo plane hp <-> z = hp - 1)
             const float* xb = a.x + ((size_t)(n * CBi + cgp) * DHW) * 16 + hsel * 8;
             mx = 0; md = 0;
-#pragma unroll
-            for (int r = 0; r < NRX; ++r) {
+            // rounds 0 .. NR2-1 cover the two planes every step loads; rounds NR2 .. NRX-1 only exist at the start of a column (four
+            // planes): ONE wave-uniform branch around them, none inside the unrolled loops (a branch per round splits the load batch)
+            auto xround = [&](auto R) {
+                constexpr int r = decltype(R)::value;
                 const int u = r * 128 + pslot;
                 const int pl = u / PPOS, p = u - pl * PPOS;
                 const int hy = p / HX, xc = p - hy * HX;
@@ -202,18 +204,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
                 if constexpr (XS == 1) {                 // 4-channel copy: channels 0-3 real (half 0), the rest of the block is zero
                     mx |= (ok && hsel == 0) ? (1u << r) : 0u;
-                    if (r * 128 < npl * PPOS) {
-                        vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
-                        vx[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
+                    vx[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     mx |= ok ? (1u << r) : 0u;
-                    if (r * 128 < npl * PPOS) {          // wave-uniform: rounds beyond the new planes issue nothing
-                        vx[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
-                        vx[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
-                    }
+                    vx[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
+                    vx[r][1] = *reinterpret_cast<const float4*>(xb + ofs + 4);
                 }
-            }
+            };
+            wt_static_for<NR2>(xround);
+            if (k == 0) wt_static_for<NRX - NR2>([&](auto R) { xround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
 #pragma unroll
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
@@ -254,12 +254,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             const int hp0 = st_k == 0 ? 0 : 2 * st_k + 2, npl = st_k == 0 ? 4 : 2;
             auto xbody = [&](auto XFORM) {                // one wave-uniform dispatch, then a branch-free unrolled loop
                 constexpr bool XF = decltype(XFORM)::value;
-#pragma unroll
-            for (int r = 0; r < NRX; ++r) {
-                if (r * 128 >= npl * PPOS) continue;     // wave-uniform
+            auto sround = [&](auto R) {
+                constexpr int r = decltype(R)::value;
                 const int u = r * 128 + pslot;
                 const int pl = u / PPOS, p = u - pl * PPOS;
-                if (pl >= npl) continue;
+                if (pl >= npl) return;
                 const bool ok = (mx >> r) & 1u;
                 const float f[8] = {vx[r][0].x, vx[r][0].y, vx[r][0].z, vx[r][0].w, vx[r][1].x, vx[r][1].y, vx[r][1].z, vx[r][1].w};
                 float t[8];
@@ -278,7 +277,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 char* dst = lds + slot * P::PLANE + p * 32 + hsel * 16;
                 *reinterpret_cast<u32x4*>(dst + P::X_OFF) = hi;
                 *reinterpret_cast<u32x4*>(dst + P::XLO_OFF) = lo;
-            }
+            };
+            wt_static_for<NR2>(sround);
+            if (st_k == 0) wt_static_for<NRX - NR2>([&](auto R) { sround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
             };
             if (xform) xbody(std::true_type{});
             else xbody(std::false_type{});
