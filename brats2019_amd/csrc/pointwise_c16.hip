@@ -295,7 +295,8 @@ int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin,
 // 4g..4g+3 of a 16-channel block of voxel r (B) / of weight row o0 + r (A) -- and MFMA step e consumes element e, i.e. the
 // K index of lane group g in step e is channel 4g + e on both sides.  D: lane holds output channels 4g..4g+3 of voxel r:
 // one aligned float4 of the C16 output.  A wave owns 64 voxels x COB*16 output channels.
-template <int COB>
+// S2D: 0 plain, 1 gather (stride-2 conv), 2 scatter (its transpose) -- compile-time, so the K loop has no branch around its loads
+template <int COB, int S2D>
 __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nvt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.z, cog = blockIdx.y;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
         if (v >= V) v = V - 1;
         vb[t] = v * 16 + 4 * g;
         fv[t] = 0;
-        if (a.s2d) {
+        if constexpr (S2D != 0) {
             const int xc = (int)(v % a.Wc);
             const size_t rr = v / a.Wc;
             const int yc = (int)(rr % a.Hc), zc = (int)(rr / a.Hc);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
 #pragma unroll 2
     for (int kb = 0; kb < nkb; ++kb) {
         float4 xb[4];
-        if (a.s2d == 1) {
+        if constexpr (S2D == 1) {
             const int tap = kb / CBf_in, cbf = kb - tap * CBf_in;
             const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
             const float* src = a.x0 + ((size_t)(n * CBf_in + cbf) * Vf) * 16 + 4 * g;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             const int cob = cog * COB + cb;
             if (cob >= CBo) continue;
             size_t idx;
-            if (a.s2d == 2) {
+            if constexpr (S2D == 2) {
                 const int tap = cob / CBf_out, cbf = cob - tap * CBf_out;
                 const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
                 idx = ((size_t)(n * CBf_out + cbf) * Vf + fv[t] + toff) * 16 + 4 * g;
@@ -400,9 +401,16 @@ int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
     const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
     const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
     dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
-    if (cob == 4) hipLaunchKernelGGL(conv1_16_kernel<4>, grid, dim3(256), 0, s, a, nvt);
-    else if (cob == 2) hipLaunchKernelGGL(conv1_16_kernel<2>, grid, dim3(256), 0, s, a, nvt);
-    else hipLaunchKernelGGL(conv1_16_kernel<1>, grid, dim3(256), 0, s, a, nvt);
+#define RU_C1_LAUNCH(COB_)                                                                                          \
+    do {                                                                                                           \
+        if (a.s2d == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 1>), grid, dim3(256), 0, s, a, nvt);              \
+        else if (a.s2d == 2) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2>), grid, dim3(256), 0, s, a, nvt);         \
+        else hipLaunchKernelGGL((conv1_16_kernel<COB_, 0>), grid, dim3(256), 0, s, a, nvt);                         \
+    } while (0)
+    if (cob == 4) RU_C1_LAUNCH(4);
+    else if (cob == 2) RU_C1_LAUNCH(2);
+    else RU_C1_LAUNCH(1);
+#undef RU_C1_LAUNCH
     RU_CHECK_LAUNCH("conv1_16_kernel");
     return RU_OK;
 }
