@@ -65,6 +65,8 @@ SIGNATURES = {
     "ru_zscore_stats": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
     "ru_augment_patch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ru_layout_convert": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
+    "ru_upsample2x_trilinear_fwd_l": (_i, [_vp, _vp] + [_i] * 5 + [_f, _vp]),
+    "ru_upsample2x_trilinear_bwd_l": (_i, [_vp, _vp] + [_i] * 5 + [_vp]),
     "ru_conv3d_fwd_l": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
     "ru_conv3d_bwd_weight_l": (_i, [_vp, _vp, _vp] + [_i] * 7 + [_vp, _sz, _vp]),
 }
@@ -81,6 +83,8 @@ def load():
             "(hipcc, gfx950).  There is no CPU fallback for this path." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("RU_LIB_PATH") and not hasattr(lib, name):
+            continue                 # A/B timing against an older build: entry points added since are simply absent
         fn = getattr(lib, name)      # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args

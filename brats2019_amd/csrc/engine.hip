@@ -1092,6 +1092,14 @@ extern "C" int ru_layout_convert(const float* src, float* dst, int N, int C, siz
     return layout_convert_launch(src, dst, N, C, V, to_c16, (hipStream_t)stream);
 }
 
+extern "C" int ru_upsample2x_trilinear_fwd_l(const float* x, float* y, int N, int C, int D, int H, int W, float out_slope, ru_stream_t stream) {
+    RU_REQUIRE(x && y && N > 0 && C > 0 && D > 0 && H > 0 && W > 0, "ru_upsample2x_trilinear_fwd_l: bad argument");
+    return up2_fwd16_launch(x, y, N, C, D, H, W, out_slope, (hipStream_t)stream);
+}
+extern "C" int ru_upsample2x_trilinear_bwd_l(const float* dy, float* dx, int N, int C, int D, int H, int W, ru_stream_t stream) {
+    RU_REQUIRE(dy && dx && N > 0 && C > 0 && D > 0 && H > 0 && W > 0, "ru_upsample2x_trilinear_bwd_l: bad argument");
+    return up2_bwd16_launch(dy, dx, N, C, D, H, W, (hipStream_t)stream);
+}
 extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout, int D, int H, int W,
                                int flags, void* ws, size_t ws_bytes, ru_stream_t stream) {
     RU_REQUIRE(x && w && y, "ru_conv3d_fwd_l: null argument");

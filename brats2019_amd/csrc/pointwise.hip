@@ -395,6 +395,9 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
 
 // one workgroup per group g.  Every (sample, channel-of-group) pair is reduced by ONE wave with shuffles only (fixed order:
 // deterministic), one barrier, then the per-sample coefficients and the batch-ordered dgamma/dbeta sums.
+// LPI lanes share one (sample, channel) item: 64 for long partial lists, 16 / 4 when a deep level has only a few partials per
+// item but many items (then a wave finishes 4 / 16 items per pass instead of one).
+template <int LPI>
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G) {
@@ -402,14 +405,25 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     const int g = blockIdx.x;
     const int cpg = C / G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int item = wave; item < N * cpg; item += 4) {
-        const int n = item / cpg, j = item - n * cpg;
-        const float* p = partials + ((size_t)n * C + g * cpg + j) * nblk * 2;
+    constexpr int IPW = 64 / LPI;
+    const int sub = lane / LPI, sl = lane % LPI;
+    for (int item0 = wave * IPW; item0 < N * cpg; item0 += 4 * IPW) {
+        const int item = item0 + sub;
+        const bool ok = item < N * cpg;
+        const int it = ok ? item : 0;
+        const int n = it / cpg, j = it - n * cpg;
+        const float2* p = reinterpret_cast<const float2*>(partials + ((size_t)n * C + g * cpg + j) * nblk * 2);
         double s1 = 0.0, s2 = 0.0;
-        for (int i = lane; i < nblk; i += 64) { s1 += (double)p[2 * i]; s2 += (double)p[2 * i + 1]; }
-        s1 = wave_sum_d(s1);
-        s2 = wave_sum_d(s2);
-        if (lane == 0) { S[item * 2] = s1; S[item * 2 + 1] = s2; }
+        int i = sl;
+        for (; i + 3 * LPI < nblk; i += 4 * LPI) {
+            const float2 a = p[i], b = p[i + LPI], c = p[i + 2 * LPI], d = p[i + 3 * LPI];
+            s1 += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
+            s2 += ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+        }
+        for (; i < nblk; i += LPI) { const float2 a = p[i]; s1 += (double)a.x; s2 += (double)a.y; }
+#pragma unroll
+        for (int o = LPI / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (sl == 0 && ok) { S[item * 2] = s1; S[item * 2 + 1] = s2; }
     }
     __syncthreads();
     const double m = (double)cpg * (double)V;
@@ -442,7 +456,9 @@ int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, 
     RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
     const size_t shm = (size_t)N * (C / G) * 2 * sizeof(double);
     RU_REQUIRE(shm <= 60000, "groupnorm backward: batch x channels-per-group too large for the finalize kernel");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    if (nblk > 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    else if (nblk > 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    else hipLaunchKernelGGL(gn_bwd_finalize_kernel<4>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
     RU_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     return RU_OK;
 }

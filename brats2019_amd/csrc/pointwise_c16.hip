@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __res
     const size_t v0 = (size_t)blockIdx.x * GN16_CHUNK;
     const size_t v1 = v0 + GN16_CHUNK < V ? v0 + GN16_CHUNK : V;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (size_t f = v0 * 4 + threadIdx.x; f < v1 * 4; f += 256) {
         const float4 t = xp[f], d = dp[f];
         const float tx[4] = {t.x, t.y, t.z, t.w}, dx[4] = {d.x, d.y, d.z, d.w};
@@ -184,89 +185,130 @@ int gn_bwd_apply16_launch(const float* x, const float* dy, const float* scale, c
 }
 
 // ------------------------------------------------------------------ trilinear x2 (model.py:12-14), same nesting z(y(x)) as the NCDHW kernel
+// A thread owns one output x (and channel quad) of one source cell pair (kz, ky), kz in [-1, D-1]: the outputs zo = 2kz+1, 2kz+2 and
+// yo = 2ky+1, 2ky+2 interpolate between the same source planes / rows (clamped at the borders, where up2_src gives the second
+// corner weight 0), so 8 loads serve 4 outputs (the one-output-per-thread form issued 8 loads per output and ran at half the
+// write bandwidth).  Lanes run over (quad, xo): every store instruction of a wave covers 1 KB of one output row.
 __global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict__ x, float* __restrict__ y, int D, int H, int W, float slope) {
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t nb = blockIdx.y;
     const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
     const float4* xp = reinterpret_cast<const float4*>(x) + nb * Vi * 4;
     float4* yp = reinterpret_cast<float4*>(y) + nb * Vo * 4;
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vo * 4; f += (size_t)gridDim.x * 256) {
+    const size_t total = (size_t)(D + 1) * (H + 1) * Wo * 4;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < total; f += (size_t)gridDim.x * 256) {
         const int q = (int)(f & 3);
         size_t r = f >> 2;
         const int xo = (int)(r % Wo); r /= Wo;
-        const int yo = (int)(r % Ho);
-        const int zo = (int)(r / Ho);
-        int z0, z1, y0, y1, x0, x1; float lz0, lz1, ly0, ly1, lx0, lx1;
-        up2_src(zo, D, z0, z1, lz0, lz1);
-        up2_src(yo, H, y0, y1, ly0, ly1);
+        const int ky = (int)(r % (H + 1)) - 1;
+        const int kz = (int)(r / (H + 1)) - 1;
+        int x0, x1; float lx0, lx1;
         up2_src(xo, W, x0, x1, lx0, lx1);
-        const size_t r00 = ((size_t)z0 * H + y0) * W, r01 = ((size_t)z0 * H + y1) * W, r10 = ((size_t)z1 * H + y0) * W, r11 = ((size_t)z1 * H + y1) * W;
-        const float4 a00 = xp[(r00 + x0) * 4 + q], b00 = xp[(r00 + x1) * 4 + q];
-        const float4 a01 = xp[(r01 + x0) * 4 + q], b01 = xp[(r01 + x1) * 4 + q];
-        const float4 a10 = xp[(r10 + x0) * 4 + q], b10 = xp[(r10 + x1) * 4 + q];
-        const float4 a11 = xp[(r11 + x0) * 4 + q], b11 = xp[(r11 + x1) * 4 + q];
-        float4 o;
-#define RU_UP2(c) o.c = lz0 * (ly0 * (lx0 * a00.c + lx1 * b00.c) + ly1 * (lx0 * a01.c + lx1 * b01.c)) + \
-                        lz1 * (ly0 * (lx0 * a10.c + lx1 * b10.c) + ly1 * (lx0 * a11.c + lx1 * b11.c))
-        RU_UP2(x); RU_UP2(y); RU_UP2(z); RU_UP2(w);
+        const int zA = kz < 0 ? 0 : kz, zB = kz + 1 > D - 1 ? D - 1 : kz + 1;
+        const int yA = ky < 0 ? 0 : ky, yB = ky + 1 > H - 1 ? H - 1 : ky + 1;
+        const size_t rAA = ((size_t)zA * H + yA) * W, rAB = ((size_t)zA * H + yB) * W, rBA = ((size_t)zB * H + yA) * W, rBB = ((size_t)zB * H + yB) * W;
+        const float4 a00 = xp[(rAA + x0) * 4 + q], b00 = xp[(rAA + x1) * 4 + q];
+        const float4 a01 = xp[(rAB + x0) * 4 + q], b01 = xp[(rAB + x1) * 4 + q];
+        const float4 a10 = xp[(rBA + x0) * 4 + q], b10 = xp[(rBA + x1) * 4 + q];
+        const float4 a11 = xp[(rBB + x0) * 4 + q], b11 = xp[(rBB + x1) * 4 + q];
+        float4 e00, e01, e10, e11;                        // x-interpolated corners [z corner][y corner]
+#define RU_UPX(c) e00.c = lx0 * a00.c + lx1 * b00.c; e01.c = lx0 * a01.c + lx1 * b01.c; e10.c = lx0 * a10.c + lx1 * b10.c; e11.c = lx0 * a11.c + lx1 * b11.c
+        RU_UPX(x); RU_UPX(y); RU_UPX(z); RU_UPX(w);
+#undef RU_UPX
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
+            const int zo = 2 * kz + 1 + dz;
+            if (zo < 0 || zo >= Do) continue;
+            int z0, z1; float lz0, lz1;
+            up2_src(zo, D, z0, z1, lz0, lz1);             // z0 == zA; z1 == zB wherever lz1 != 0
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yo = 2 * ky + 1 + dy;
+                if (yo < 0 || yo >= Ho) continue;
+                int y0, y1; float ly0, ly1;
+                up2_src(yo, H, y0, y1, ly0, ly1);
+                float4 o;
+#define RU_UP2(c) o.c = lrelu(lz0 * (ly0 * e00.c + ly1 * e01.c) + lz1 * (ly0 * e10.c + ly1 * e11.c), slope)
+                RU_UP2(x); RU_UP2(y); RU_UP2(z); RU_UP2(w);   // slope 1: no activation
 #undef RU_UP2
-        o.x = lrelu(o.x, slope); o.y = lrelu(o.y, slope); o.z = lrelu(o.z, slope); o.w = lrelu(o.w, slope);   // slope 1: none
-        yp[f] = o;
+                yp[(((size_t)zo * Ho + yo) * Wo + xo) * 4 + q] = o;
+            }
+        }
     }
 }
 int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W, float slope, hipStream_t s) {
     RU_REQUIRE(C % 16 == 0, "up2_fwd16: C must be a multiple of 16");
-    hipLaunchKernelGGL(up2_fwd16_kernel, c16_grid((size_t)D * H * W * 8, N * (C / 16), 8192), dim3(256), 0, s, x, y, D, H, W, slope);
+    const size_t total = (size_t)(D + 1) * (H + 1) * (2 * W) * 4;
+    size_t bx = (total + 255) / 256;
+    if (bx > 16384) bx = 16384;
+    hipLaunchKernelGGL(up2_fwd16_kernel, dim3((unsigned)bx, (unsigned)(N * (C / 16))), dim3(256), 0, s, x, y, D, H, W, slope);
     RU_CHECK_LAUNCH("up2_fwd16_kernel");
     return RU_OK;
 }
 
-// transpose in gather form: coarse voxel k collects from fine 2k-1 .. 2k+2 on each axis
+// transpose in gather form: coarse voxel k collects from fine 2k-1 .. 2k+2 on each axis.  A thread owns a coarse (ky, kx) column
+// (and channel quad) and marches through a chunk of UP2B_ZC coarse planes: the x/y-reduced value of fine plane z feeds the two
+// coarse planes it belongs to, so a coarse output costs 2 fine planes x 16 loads instead of 4 x 16.
+constexpr int UP2B_ZC = 8;
 __global__ __launch_bounds__(256) void up2_bwd16_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D, int H, int W) {
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t nb = blockIdx.y;
     const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
     const float4* dp = reinterpret_cast<const float4*>(dy) + nb * Vo * 4;
     float4* op = reinterpret_cast<float4*>(dx) + nb * Vi * 4;
-    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < Vi * 4; f += (size_t)gridDim.x * 256) {
+    const int nch = (D + UP2B_ZC - 1) / UP2B_ZC;
+    const size_t total = (size_t)nch * H * W * 4;
+    for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < total; f += (size_t)gridDim.x * 256) {
         const int q = (int)(f & 3);
         size_t r = f >> 2;
         const int kx = (int)(r % W); r /= W;
         const int ky = (int)(r % H);
-        const int kz = (int)(r / H);
-        float wz[4], wy[4], wx[4];
-        int oz[4], oy[4], ox[4];
+        const int k0 = (int)(r / H) * UP2B_ZC;
+        const int k1 = k0 + UP2B_ZC < D ? k0 + UP2B_ZC : D;
+        float wy[4], wx[4];
+        size_t oy[4], ox[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int z = 2 * kz - 1 + t, y = 2 * ky - 1 + t, xx = 2 * kx - 1 + t;
-            wz[t] = (z >= 0 && z < Do) ? up2_coef(z, D, kz) : 0.f;
+            const int y = 2 * ky - 1 + t, xx = 2 * kx - 1 + t;
             wy[t] = (y >= 0 && y < Ho) ? up2_coef(y, H, ky) : 0.f;
             wx[t] = (xx >= 0 && xx < Wo) ? up2_coef(xx, W, kx) : 0.f;
-            oz[t] = z < 0 ? 0 : (z >= Do ? Do - 1 : z);            // clamped: the weight is 0 outside
-            oy[t] = y < 0 ? 0 : (y >= Ho ? Ho - 1 : y);
-            ox[t] = xx < 0 ? 0 : (xx >= Wo ? Wo - 1 : xx);
+            oy[t] = (size_t)(y < 0 ? 0 : (y >= Ho ? Ho - 1 : y)) * Wo;           // clamped: the weight is 0 outside
+            ox[t] = (size_t)(xx < 0 ? 0 : (xx >= Wo ? Wo - 1 : xx)) * 4 + q;
         }
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 accP = make_float4(0.f, 0.f, 0.f, 0.f), accC = accP;             // coarse planes m-1 and m
+        for (int m = k0; m <= k1; ++m) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float4 ay = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < 2; ++h) {
+                const int z = 2 * m - 1 + h;
+                const bool in = z >= 0 && z < Do;
+                const size_t zrow = (size_t)(z < 0 ? 0 : (z >= Do ? Do - 1 : z)) * Ho * Wo;
+                float4 pz = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const size_t row = ((size_t)oz[a] * Ho + oy[b]) * Wo;
-                const float4 p0 = dp[(row + ox[0]) * 4 + q], p1 = dp[(row + ox[1]) * 4 + q], p2 = dp[(row + ox[2]) * 4 + q], p3 = dp[(row + ox[3]) * 4 + q];
-                ay.x += wy[b] * (wx[0] * p0.x + wx[1] * p1.x + wx[2] * p2.x + wx[3] * p3.x);
-                ay.y += wy[b] * (wx[0] * p0.y + wx[1] * p1.y + wx[2] * p2.y + wx[3] * p3.y);
-                ay.z += wy[b] * (wx[0] * p0.z + wx[1] * p1.z + wx[2] * p2.z + wx[3] * p3.z);
-                ay.w += wy[b] * (wx[0] * p0.w + wx[1] * p1.w + wx[2] * p2.w + wx[3] * p3.w);
+                for (int b = 0; b < 4; ++b) {
+                    const float4* row = dp + (zrow + oy[b]) * 4;
+                    const float4 p0 = row[ox[0]], p1 = row[ox[1]], p2 = row[ox[2]], p3 = row[ox[3]];
+                    pz.x += wy[b] * (wx[0] * p0.x + wx[1] * p1.x + wx[2] * p2.x + wx[3] * p3.x);
+                    pz.y += wy[b] * (wx[0] * p0.y + wx[1] * p1.y + wx[2] * p2.y + wx[3] * p3.y);
+                    pz.z += wy[b] * (wx[0] * p0.z + wx[1] * p1.z + wx[2] * p2.z + wx[3] * p3.z);
+                    pz.w += wy[b] * (wx[0] * p0.w + wx[1] * p1.w + wx[2] * p2.w + wx[3] * p3.w);
+                }
+                const float cP = (in && m - 1 >= k0) ? up2_coef(z, D, m - 1) : 0.f;
+                const float cC = (in && m < k1) ? up2_coef(z, D, m) : 0.f;
+                accP.x += cP * pz.x; accP.y += cP * pz.y; accP.z += cP * pz.z; accP.w += cP * pz.w;
+                accC.x += cC * pz.x; accC.y += cC * pz.y; accC.z += cC * pz.z; accC.w += cC * pz.w;
             }
-            acc.x += wz[a] * ay.x; acc.y += wz[a] * ay.y; acc.z += wz[a] * ay.z; acc.w += wz[a] * ay.w;
+            if (m - 1 >= k0) op[(((size_t)(m - 1) * H + ky) * W + kx) * 4 + q] = accP;
+            accP = accC;
+            accC = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        op[f] = acc;
     }
 }
 int up2_bwd16_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s) {
     RU_REQUIRE(C % 16 == 0, "up2_bwd16: C must be a multiple of 16");
-    hipLaunchKernelGGL(up2_bwd16_kernel, c16_grid((size_t)D * H * W, N * (C / 16), 8192), dim3(256), 0, s, dy, dx, D, H, W);
+    const size_t total = (size_t)((D + UP2B_ZC - 1) / UP2B_ZC) * H * W * 4;
+    size_t bx = (total + 255) / 256;
+    if (bx > 16384) bx = 16384;
+    hipLaunchKernelGGL(up2_bwd16_kernel, dim3((unsigned)bx, (unsigned)(N * (C / 16))), dim3(256), 0, s, dy, dx, D, H, W);
     RU_CHECK_LAUNCH("up2_bwd16_kernel");
     return RU_OK;
 }

@@ -101,6 +101,8 @@ struct Wgrad3Args {
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
+// sum of `nparts` partial gradients [nparts][taps][CoP][CiP] into dw (fixed order; wgrad_f32.hip)
+int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s);
 size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s);
 // both tensors voxel-major: transpose-read kernel (wgrad_tr.hip); workspace 0 if the channel counts do not fit

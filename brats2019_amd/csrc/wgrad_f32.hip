@@ -280,11 +280,15 @@ __global__ __launch_bounds__(512, 4) void wgrad3_f32_kernel(const Wgrad3Args a, 
 
 // dw[o*so + c*sc + tap] = sum_parts partials[part][tap][o][c].  256 threads = 64 outputs x 4 partial slices (the slices are
 // combined in a fixed order through LDS: deterministic), so a 512-partial reduction is 128 loads deep instead of 512.
+// LO outputs per workgroup, 256 / LO slices of the partial range per output: few outputs with many partials (a 16x16 1x1x1
+// gradient has 1024) want narrow blocks -- 64-wide blocks left a 256-load dependent chain per thread on 4 workgroups.
+template <int LO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
                                                            int Cout, int Cin, float* __restrict__ dw, int so, int sc, int split) {
-    __shared__ float red[4][64];
-    const int lane_o = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane_o;
+    constexpr int NS = 256 / LO;
+    __shared__ float red[NS][LO];
+    const int lane_o = threadIdx.x % LO, slice = threadIdx.x / LO;
+    const int i = blockIdx.x * LO + lane_o;
     const int total = taps * Cout * Cin;
     const bool ok = i < total;
     const int ii = ok ? i : 0;
@@ -293,22 +297,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int tap = ii / (Cin * Cout);
     const size_t stride = (size_t)taps * CoP * CiP;
     const float* p = partials + ((size_t)tap * CoP + o) * CiP + c;
-    const int per = (nparts + 3) / 4;
+    const int per = (nparts + NS - 1) / NS;
     const int k0 = slice * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = k0;
-    for (; k + 3 < k1; k += 4) {
-        s0 += p[(size_t)k * stride];
-        s1 += p[(size_t)(k + 1) * stride];
-        s2 += p[(size_t)(k + 2) * stride];
-        s3 += p[(size_t)(k + 3) * stride];
+    for (; k + 7 < k1; k += 8) {
+        const float t0 = p[(size_t)k * stride], t1 = p[(size_t)(k + 1) * stride], t2 = p[(size_t)(k + 2) * stride], t3 = p[(size_t)(k + 3) * stride];
+        const float t4 = p[(size_t)(k + 4) * stride], t5 = p[(size_t)(k + 5) * stride], t6 = p[(size_t)(k + 6) * stride], t7 = p[(size_t)(k + 7) * stride];
+        s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+        s0 += t4; s1 += t5; s2 += t6; s3 += t7;
     }
     for (; k < k1; ++k) s0 += p[(size_t)k * stride];
     red[slice][lane_o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     // split > 0: c = t*split + ci enumerates (tap t, channel ci) of a 2x2x2 conv whose gradient layout is [o][ci][8]
     const size_t dst = split > 0 ? (size_t)o * so + (size_t)(c % split) * 8 + c / split : (size_t)o * so + (size_t)c * sc + tap;
-    if (slice == 0 && ok) dw[dst] = (red[0][lane_o] + red[1][lane_o]) + (red[2][lane_o] + red[3][lane_o]);
+    if (slice == 0 && ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) t += red[j][lane_o];
+        dw[dst] = t;
+    }
+}
+// fixed summation order for a given (nparts, shape): deterministic
+int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s) {
+    const int total = taps * Cout * Cin;
+    if (nparts >= 128) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split);
+    RU_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return RU_OK;
 }
 
 struct W3Choice { int tz, ty, ot, ct, nbx, ngroups, ncg; };
@@ -357,10 +374,7 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
                        cdiv(a.D, TZ), cdiv(a.H, TY), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
     const int total = 27 * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0);
-    RU_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return RU_OK;
+    return wgrad_reduce_launch((const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s);
 }
 
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s) {
@@ -567,11 +581,7 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     hipLaunchKernelGGL((wgrad1_f32_kernel<OT, CT>), dim3(c.nbx, c.ngroups), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad1_f32_kernel");
-    const int total = a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 1, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split);
-    RU_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return RU_OK;
+    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 1, CoP, CiP, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s);
 }
 
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {

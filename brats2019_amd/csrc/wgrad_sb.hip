@@ -25,9 +25,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// defined in wgrad_f32.hip
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin,
-                                    float* __restrict__ dw, int so, int sc, int split);
 
 template <int TZ, int TY, int OT>
 struct WSB {
@@ -396,11 +393,7 @@ static int wsb_cfg(const Wgrad3Args& a, const WSBChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_sb_kernel");
-    const int total = 27 * a.Cout * a.Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, c.nbx, 27, CoP, CiP,
-                       a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0);
-    RU_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return RU_OK;
+    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s);
 }
 
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s) {

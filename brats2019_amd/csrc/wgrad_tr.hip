@@ -31,8 +31,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin,
-                                    float* __restrict__ dw, int so, int sc, int split);
 
 template <int... Is, class F>
 __device__ __forceinline__ void wt_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
@@ -391,11 +389,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
-    const int total = 27 * co * ci;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 64)), dim3(256), 0, s, (const float*)a.ws, nbx * (OT == 1 ? 4 : 2), 27, a.Cout, a.Cin,
-                       co, ci, a.dw, ci * 27, 27, 0);
-    RU_CHECK_LAUNCH("wgrad_reduce_kernel");
-    return RU_OK;
+    return wgrad_reduce_launch((const float*)a.ws, nbx * (OT == 1 ? 4 : 2), 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
 }
 
 int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {

@@ -239,6 +239,25 @@ def from_c16(x):
     return y
 
 
+def upsample2x_c16(x, out_slope=1.0):
+    """Trilinear x2 on a C16 tensor [N,C/16,D,H,W,16]; LeakyReLU(out_slope) fused on the output (1 = none)."""
+    x = _prep(x)
+    n, cb, d, h, w, _ = (int(v) for v in x.shape)
+    y = torch.empty((n, cb, 2 * d, 2 * h, 2 * w, 16), dtype=torch.float32, device=x.device)
+    L.check(L.load().ru_upsample2x_trilinear_fwd_l(L.f32(x), L.f32(y), n, cb * 16, d, h, w, float(out_slope), L.stream()),
+            "ru_upsample2x_trilinear_fwd_l")
+    return y
+
+
+def upsample2x_bwd_c16(dy):
+    dy = _prep(dy)
+    n, cb, d2, h2, w2, _ = (int(v) for v in dy.shape)
+    dx = torch.empty((n, cb, d2 // 2, h2 // 2, w2 // 2, 16), dtype=torch.float32, device=dy.device)
+    L.check(L.load().ru_upsample2x_trilinear_bwd_l(L.f32(dy), L.f32(dx), n, cb * 16, d2 // 2, h2 // 2, w2 // 2, L.stream()),
+            "ru_upsample2x_trilinear_bwd_l")
+    return dx
+
+
 def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False):
     """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16); few_channels: NCDHW input
     with Cin <= 4 through the 4-channel tap-pair kernel."""

@@ -98,3 +98,22 @@ def test_conv3_few_input_channels(cin, out16):
         y = ops.from_c16(y)
     tol = 2e-5 * float(exact.abs().max())
     assert float((y - exact).abs().max()) < tol and float((ref - exact).abs().max()) < tol
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 4, 6, 8), (1, 32, 9, 5, 12), (1, 16, 1, 1, 4), (1, 16, 17, 3, 20)])
+def test_upsample_c16_equals_ncdhw(shape):
+    """Trilinear x2 and its transpose on C16 tensors (cell-pair / z-marching kernels) against the NCDHW kernels, which are
+    themselves checked against the reference's F.interpolate in test_hip_ops.py (same nesting z(y(x)); the compiler contracts
+    the multiply-adds differently, so the forward agrees to an ulp or two rather than bit for bit).  Shapes cover odd extents, a single plane / row and a z extent that is not a multiple of the marching chunk."""
+    from brats2019_amd import ops
+    n, c, d, h, w = shape
+    x = _rand(n, c, d, h, w, seed=3)
+    y_ref = ops.upsample2x(x)
+    y = ops.from_c16(ops.upsample2x_c16(ops.to_c16(x)))
+    assert float((y - y_ref).abs().max()) <= 1e-6
+    y_act = ops.from_c16(ops.upsample2x_c16(ops.to_c16(x), out_slope=0.01))
+    assert torch.equal(y_act, torch.where(y > 0, y, y * 0.01))
+    dy = _rand(n, c, 2 * d, 2 * h, 2 * w, seed=4)
+    dx_ref = ops.upsample2x_bwd(dy)
+    dx = ops.from_c16(ops.upsample2x_bwd_c16(ops.to_c16(dy)))
+    assert float((dx - dx_ref).abs().max()) <= 1e-5
