@@ -621,19 +621,20 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     const int C0 = h->ch[0];
     RU_RUN(fill_launch(grads, 0.f, h->total, s));     // dead parameters keep zero gradient
     // head
-    float* dlog = A.alloc((size_t)N * h->nout * Vl(0));
-    RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
     const bool c16 = h->c16;
     const bool head4 = c16 && conv3_sb4_usable(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);      // few channels: one 4-channel copy feeds both head kernels
     float* d4 = head4 ? A.alloc((size_t)N * 4 * Vl(0)) : nullptr;
-    if (head4) RU_RUN(pad_to_c4_launch(dlog, d4, N, h->nout, Vl(0), s));
-    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
-    if (rc) return rc;
-    {
-        const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
-        float* wsp = A.alloc(wsb / sizeof(float) + 1);
+    float* dlog = head4 ? nullptr : A.alloc((size_t)N * h->nout * Vl(0));
+    const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
+    float* wsp = A.alloc(wsb / sizeof(float) + 1);
+    if (head4) {                                                 // sigmoid backward, 4-channel copy and bias gradient in one pass
+        RU_RUN(head_grad_c4_launch(h->probs, dprobs, d4, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
+    } else {
+        RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
         RU_RUN(bias_grad_launch(dlog, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
     }
+    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
+    if (rc) return rc;
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
     dh.x = dlog; dh.wp = h->pack + h->pk_out_d; dh.y = dcur_buf; dh.mode = h->precision; dh.wfrag = h->fpack + h->fk_out_d; dh.out_c16 = c16; dh.N = N; dh.Cin = h->nout; dh.Cout = C0; dh.D = Dl[0]; dh.H = Hl[0]; dh.W = Wl[0];

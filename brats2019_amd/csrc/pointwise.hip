@@ -737,6 +737,52 @@ int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* w
     return RU_OK;
 }
 
+// Head of the backward pass on the 4-channel path, one pass instead of three (sigmoid backward, 4-channel copy, bias partials):
+// dz = dp*p*(1-p) (model.py:431) goes straight into the zero-padded voxel-major copy [N][V][4] that the head's weight- and
+// data-gradient kernels read, and the bias gradient's partial sums (model.py:348) are taken on the way.  V % 4 == 0.
+__global__ __launch_bounds__(256) void head_grad_c4_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ d4,
+                                                           float* __restrict__ part, int C, size_t V, int nblk) {
+    __shared__ float buf[4];
+    const size_t n = blockIdx.y;
+    const size_t v0 = (size_t)blockIdx.x * BG_CHUNK;
+    const size_t v1 = v0 + BG_CHUNK < V ? v0 + BG_CHUNK : V;
+    const float* pp = p + n * C * V;
+    const float* dpp = dp + n * C * V;
+    float4* op = reinterpret_cast<float4*>(d4) + n * V;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t v = v0 + (size_t)threadIdx.x * 4; v < v1; v += 1024) {
+        float d[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = c < C;
+            const float4 q = *reinterpret_cast<const float4*>(pp + (ok ? c : 0) * V + v);
+            const float4 g = *reinterpret_cast<const float4*>(dpp + (ok ? c : 0) * V + v);
+            d[c][0] = ok ? g.x * q.x * (1.f - q.x) : 0.f;
+            d[c][1] = ok ? g.y * q.y * (1.f - q.y) : 0.f;
+            d[c][2] = ok ? g.z * q.z * (1.f - q.z) : 0.f;
+            d[c][3] = ok ? g.w * q.w * (1.f - q.w) : 0.f;
+            sum[c] += (d[c][0] + d[c][1]) + (d[c][2] + d[c][3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) op[v + e] = make_float4(d[0][e], d[1][e], d[2][e], d[3][e]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float t = block_sum(sum[c], buf);
+        if (threadIdx.x == 0 && c < C) part[(n * C + c) * nblk + blockIdx.x] = t;
+    }
+}
+int head_grad_c4_launch(const float* p, const float* dp, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s) {
+    RU_REQUIRE(C > 0 && C <= 4 && V % 4 == 0, "head_grad_c4: 1..4 channels, V % 4 == 0");
+    if (!ws || ws_bytes < bias_grad_workspace_bytes(N, C, V)) { set_error("head_grad_c4: workspace too small"); return RU_ENOMEM; }
+    const int nblk = (int)((V + BG_CHUNK - 1) / BG_CHUNK);
+    hipLaunchKernelGGL(head_grad_c4_kernel, dim3(nblk, N), dim3(256), 0, s, p, dp, d4, (float*)ws, C, V, nblk);
+    RU_CHECK_LAUNCH("head_grad_c4_kernel");
+    hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, db, N, C, nblk);
+    RU_CHECK_LAUNCH("bias_final_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ criterion: Dice_loss_joint + BCE_Loss (loss.py:64-79,98-122)
 constexpr int CR_CHUNK = 8192;
 int crit_tiles(size_t V) { return (int)((V + CR_CHUNK - 1) / CR_CHUNK); }

@@ -51,12 +51,13 @@ int gn_apply16_launch(const float* x, const float* scale, const float* shift, co
 // ------------------------------------------------------------------ GroupNorm backward
 // reduce: per (n, c) and voxel chunk S1 = sum dyh, S2 = sum dyh * xhat (dyh = dy * lrelu'(x*scale+shift)); partials
 // [N][C][nblk][2] exactly like the NCDHW kernel, so gn_bwd_finalize is shared.  Fixed reduction order: deterministic.
-constexpr int GN16_CHUNK = 2048;   // voxels of one (n, channel block) reduced by one workgroup
-int gn_bwd_tiles16(size_t V) { return (int)((V + GN16_CHUNK - 1) / GN16_CHUNK); }
+// voxels of one (n, channel block) reduced by one workgroup: large volumes take 8192 so the whole grid is resident at once
+static inline int gn16_chunk(size_t V) { return V >= ((size_t)1 << 20) ? 8192 : 2048; }
+int gn_bwd_tiles16(size_t V) { const int ch = gn16_chunk(V); return (int)((V + ch - 1) / ch); }
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk) {
+                                                              float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk, int chunk) {
     __shared__ float red[4][16][2];
     const int nb = blockIdx.y, CB = C >> 4;
     const int n = nb / CB, cb = nb - n * CB;
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __res
     const size_t base = (size_t)nb * V * 4;
     const float4* xp = reinterpret_cast<const float4*>(x) + base;
     const float4* dp = reinterpret_cast<const float4*>(dy) + base;
-    const size_t v0 = (size_t)blockIdx.x * GN16_CHUNK;
-    const size_t v1 = v0 + GN16_CHUNK < V ? v0 + GN16_CHUNK : V;
+    const size_t v0 = (size_t)blockIdx.x * chunk;
+    const size_t v1 = v0 + chunk < V ? v0 + chunk : V;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (size_t f = v0 * 4 + threadIdx.x; f < v1 * 4; f += 256) {
@@ -106,7 +107,7 @@ int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, 
                            float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s) {
     RU_REQUIRE(C % 16 == 0 && C % G == 0, "gn_bwd_reduce16: bad channel count");
     const int nblk = gn_bwd_tiles16(V);
-    hipLaunchKernelGGL(gn_bwd_reduce16_kernel, dim3(nblk, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk);
+    hipLaunchKernelGGL(gn_bwd_reduce16_kernel, dim3(nblk, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk, gn16_chunk(V));
     RU_CHECK_LAUNCH("gn_bwd_reduce16_kernel");
     return RU_OK;
 }

@@ -190,6 +190,8 @@ int up2_fwd_launch(const float* x, float* y, int N, int C, int D, int H, int W, 
 int up2_bwd_launch(const float* dy, float* dx, int N, int C, int D, int H, int W, hipStream_t s);
 int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
 size_t bias_grad_workspace_bytes(int N, int C, size_t V);
+// dz = dp*p*(1-p) written as the zero-padded [N][V][4] copy + bias gradient, one pass (workspace as bias_grad)
+int head_grad_c4_launch(const float* p, const float* dp, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
 
 // ------------------------------------------------------------------ the same on the voxel-major layout C16 (pointwise_c16.hip)
 int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s);
