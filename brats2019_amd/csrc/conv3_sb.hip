@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 // loads of item w+2 in flight.  One __syncthreads per item.  Each SIMD hosts one consumer and one producer wave, so
 // the matrix pipe and the VALU/LDS-store work of the staging overlap instead of alternating.
 // Per-tile GroupNorm statistics are written per consumer WAVE (no cross-wave reduction -> no extra barrier).
-template <int TZ, int TY, bool IN16, bool OUT16>
+// MULTI (more than one 16-channel input chunk): the weight fragments of the NEXT item's chunk are fetched K-step by K-step into
+// the registers group 1 has just finished with, instead of 28 loads at the start of every item with the matrix pipe waiting on
+// the first (that exposed L2 latency was ~20 % of the kernel at 32..128 channels).
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
@@ -655,15 +658,16 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             aoff[ks] = (kg & 1) * HVOLP + ((mz + dz) * HY + my0 + dy) * HX + dx + (lane & 15);
         }
         u32x4 wreg[SB_KSTEPS][2];
+        auto wptr = [&](int chunk) { return wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane; };
         auto load_w = [&](int chunk) {
-            const u32x4* wp = wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane;
+            const u32x4* wp = wptr(chunk);
 #pragma unroll
             for (int ks = 0; ks < SB_KSTEPS; ++ks) {
                 wreg[ks][0] = wp[(ks * 2 + 0) * 64];
                 wreg[ks][1] = wp[(ks * 2 + 1) * 64];
             }
         };
-        if (nchunk == 1) load_w(0);                     // one chunk: the weights stay in registers for the whole run of tiles
+        load_w(0);                                      // one chunk: the weights stay in registers for the whole run of tiles
         f32x4 acc[MT];
         // OUT16: operands swapped -> D[m = cout][n = voxel] (lane owns 4 couts of one voxel, see sb_out_tile)
         auto mm = [](const bf16x8& av, const bf16x8& wv, const f32x4& c) -> f32x4 {
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // (32 KB per CU from all CUs at once) is HBM-write bound and used to stall the matrix pipe for ~25 % of the kernel.
         // Inside a group, the A fragment of K-step ks+1 is read right after the last MFMA that uses the register: one LDS
         // instruction between two MFMAs instead of a burst (sched_barrier pins the written order).
-        auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase) {
+        auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase, const u32x4* wnext) {
             constexpr int gsel = decltype(GSEL)::value, cb = gsel * HM, sb = (1 - gsel) * HM;
             float4 radd[HM];
 #pragma unroll
@@ -739,6 +743,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if constexpr (MULTI && gsel == 1) {       // this K-step's fragments are dead for this item: fetch the next chunk's
+                    wreg[ks][0] = wnext[(ks * 2 + 0) * 64];
+                    wreg[ks][1] = wnext[(ks * 2 + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (ks % 3 == 2 && ks / 3 < HM) {
                     if (do_store) sb_out_tile<OUT16, NS>(a, so, ybase + sb + ks / 3, acc[sb + ks / 3], radd[ks / 3], s1, s2);
                     __builtin_amdgcn_sched_barrier(0);
@@ -764,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         for (int w = 0; w < nitems; ++w) {
             const int chunk = w % nchunk;
             const bool last = chunk == nchunk - 1 && !(dbg & 8);
-            if (nchunk > 1) load_w(chunk);
+            const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
             const u32x4* buf = lds + (w & 1) * BUF;
             int n = 0, tis = 0;
             const int n_item = (t_begin + (w / nchunk) * G) / tiles_per_sample;      // sample of this item's tile
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
                 for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev);
+            run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev, wnext);
             if (pend) {
                 if (n_item != n_prev) flush_stats(n_prev);   // the previous tile was the last one of its sample here
                 pend = false;
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
                 for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur);
+            run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur, wnext);
             if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
             __syncthreads();
         }
@@ -1161,13 +1170,13 @@ int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
 }
 
-template <int TZ, int TY, bool IN16, bool OUT16>
-static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI>
+static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static bool attr_done = false;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         attr_done = true;
     }
@@ -1177,9 +1186,13 @@ static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
+}
+template <int TZ, int TY, bool IN16, bool OUT16>
+static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
+    return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false>(a, s);
 }
 
 template <int TZ, int TY, bool IN16, bool OUT16>
