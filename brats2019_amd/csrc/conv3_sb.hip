@@ -104,16 +104,16 @@ __device__ __forceinline__ size_t sb_out_index(const Conv3Args& a, const SbOut& 
 template <bool OUT16, int NS>
 __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, float (&s1)[NS], float (&s2)[NS]) {
     if (!(o.ok && yy < a.H)) return;
-    if (a.bias) { v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w; }     // wave-uniform branches
-    if (a.add) { v[0] += radd.x; v[1] += radd.y; v[2] += radd.z; v[3] += radd.w; }
-    if (a.stat_partials) {
-        if constexpr (OUT16) {
+    // straight-line: bias and residual are zeros when absent and the statistics are always taken -- each wave-uniform `if (a.x)` here
+    // was a branch (plus phi moves) in the consumer's instruction stream between its MFMAs, ~375 cycles per tile row
+    v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w;
+    v[0] += radd.x; v[1] += radd.y; v[2] += radd.z; v[3] += radd.w;
+    if constexpr (OUT16) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-        } else {
-            s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
-            s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
+        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+    } else {
+        s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
+        s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     if (a.sigmoid) {
         // hardware exp2 / rcp (1 ulp each): the library expf is ~14 VALU instructions per value, and they sit in the consumer
@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
 // loads of item w+2 in flight.  One __syncthreads per item.  Each SIMD hosts one consumer and one producer wave, so
 // the matrix pipe and the VALU/LDS-store work of the staging overlap instead of alternating.
 // Per-tile GroupNorm statistics are written per consumer WAVE (no cross-wave reduction -> no extra barrier).
+// RU_SB2_DEBUG bit 64: consumer wave 0 of every workgroup brackets the sections of its item loop with s_memtime and adds the sums
+// here (cycles): [0] index math before group 0, [1] group 0, [2] between the groups, [3] group 1, [4] barrier, [5] items, [6] drain, [7] workgroups
+__device__ unsigned long long sb2_prof[8];
 // MULTI (more than one 16-channel input chunk): the weight fragments of the NEXT item's chunk are fetched K-step by K-step into
 // the registers group 1 has just finished with, instead of 28 loads at the start of every item with the matrix pipe waiting on
 // the first (that exposed L2 latency was ~20 % of the kernel at 32..128 channels).
@@ -770,7 +773,10 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
         };
         __syncthreads();                                // item 0 is staged
+        const bool prof = (dbg & 64) != 0;
+        unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
         for (int w = 0; w < nitems; ++w) {
+            if (prof) t0 = __builtin_readcyclecounter();
             const int chunk = w % nchunk;
             const bool last = chunk == nchunk - 1 && !(dbg & 8);
             const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
@@ -788,7 +794,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
                 for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            if (prof) { t1 = __builtin_readcyclecounter(); pt[0] += t1 - t0; t0 = t1; }
             run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev, wnext);
+            if (prof) { t1 = __builtin_readcyclecounter(); pt[1] += t1 - t0; t0 = t1; }
             if (pend) {
                 if (n_item != n_prev) flush_stats(n_prev);   // the previous tile was the last one of its sample here
                 pend = false;
@@ -798,10 +806,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
                 for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            if (prof) { t1 = __builtin_readcyclecounter(); pt[2] += t1 - t0; t0 = t1; }
             run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur, wnext);
             if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
+            if (prof) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; t0 = t1; }
             __syncthreads();
+            if (prof) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; pt[5] += 1; }
         }
+        if (prof) t0 = __builtin_readcyclecounter();
         if (pend) {                                     // drain: group 1 of the last tile
             float4 radd[HM];
 #pragma unroll
@@ -813,6 +825,12 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
             for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
             flush_stats(n_prev);
+        }
+        if (prof && rw == 0 && lane == 0) {
+            pt[6] = __builtin_readcyclecounter() - t0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) atomicAdd(&sb2_prof[i], pt[i]);
+            atomicAdd(&sb2_prof[7], 1ull);
         }
         if (a.stat_partials && !(dbg & 8)) {            // zeros for the samples this workgroup did not touch (s1 = s2 = 0 here)
             for (int n = 0; n < a.N; ++n)
@@ -1168,6 +1186,15 @@ int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     const SBChoice c = sb_choose(N, Cout, D, H, W);
     if (sb_use_v2(c)) return (int)sb2_grid_x(N, Cout, D, H, W) * 4;    // persistent kernel: one per (workgroup, consumer wave)
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
+}
+
+// tools only (not in include/resunet_hip.h): read and clear the RU_SB2_DEBUG=64 section counters
+extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(sb2_prof), 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol(sb2_prof)");
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(sb2_prof), z, sizeof(z));
+    return e == hipSuccess ? RU_OK : hip_fail(e, "hipMemcpyToSymbol(sb2_prof)");
 }
 
 template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI>

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-section cycle breakdown of the conv3_sb2 consumer loop (RU_SB2_DEBUG=64): usage sb2_sections.py [C] [size] [N]
+Prints the average cycles per item that consumer wave 0 of a workgroup spends in each section."""
+import ctypes, os, sys
+os.environ["RU_SB2_DEBUG"] = str(64 | int(os.environ.get("RU_SB2_EXTRA", "0")))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from brats2019_amd import _lib as L
+
+c = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+lib = L.load()
+fn = lib.ru_dbg_sb2_prof
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_void_p]
+dev = torch.device("cuda")
+x = torch.randn(n, c // 16, size, size, size, 16, device=dev)
+w = torch.randn(c, c, 3, 3, 3, device=dev) * 0.05
+y = torch.empty_like(x)
+ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, c, c, size, size, size, 3), dev)
+buf = (ctypes.c_ulonglong * 8)()
+for rep in range(3):
+    L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "fwd_l")
+    torch.cuda.synchronize()
+    fn(ctypes.addressof(buf))
+v = list(buf)
+items, wgs = max(v[5], 1), max(v[7], 1)
+names = ["index math", "group 0", "between", "group 1", "barrier"]
+tot = sum(v[:5])
+print("C=%d size=%d N=%d: %d workgroups, %.1f items each; cycles per item (consumer wave 0):" % (c, size, n, wgs, items / wgs))
+for i, nm in enumerate(names):
+    print("  %-12s %8.0f  (%4.1f %%)" % (nm, v[i] / items, 100.0 * v[i] / tot))
+print("  %-12s %8.0f ; ideal MFMA time per item 336 x 16 = 5376" % ("total", tot / items))
