@@ -115,11 +115,13 @@ __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, 
         s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
         s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    if (a.sigmoid) {
-        // hardware exp2 / rcp (1 ulp each): the library expf is ~14 VALU instructions per value, and they sit in the consumer
-        // wave's instruction stream between its MFMAs (the head conv was 75 us slower than the same conv without sigmoid)
+    if constexpr (!OUT16) {                                 // only the head has an activation, and its output is NCDHW (checked at launch)
+        if (a.sigmoid) {
+            // hardware exp2 / rcp (1 ulp each): the library expf is ~14 VALU instructions per value, and they sit in the consumer
+            // wave's instruction stream between its MFMAs (the head conv was 75 us slower than the same conv without sigmoid)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]));
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]));
+        }
     }
     *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -775,19 +777,32 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         __syncthreads();                                // item 0 is staged
         const bool prof = (dbg & 64) != 0;
         unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+        // The tile of step k is t_begin + k*G: its (sample, tz, ty, tx) digits advance by the digits of G with carries -- scalar adds
+        // instead of the five integer divisions per item (each ~40 instructions in this wave's stream between its MFMAs)
+        int cn, ctz, cty, ctx;
+        {
+            int b = t_begin;
+            cn = b / tiles_per_sample; b -= cn * tiles_per_sample;
+            ctx = b % ntx; b /= ntx;
+            cty = b % nty; ctz = b / nty;
+        }
+        int gn, gz, gy, gx;
+        {
+            int b = G;
+            gx = b % ntx; b /= ntx;
+            gy = b % nty; b /= nty;
+            gz = b % ntz; gn = b / ntz;
+        }
+        int chunk = 0;
         for (int w = 0; w < nitems; ++w) {
             if (prof) t0 = __builtin_readcyclecounter();
-            const int chunk = w % nchunk;
             const bool last = chunk == nchunk - 1 && !(dbg & 8);
             const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
             const u32x4* buf = lds + (w & 1) * BUF;
-            int n = 0, tis = 0;
-            const int n_item = (t_begin + (w / nchunk) * G) / tiles_per_sample;      // sample of this item's tile
+            const int n = cn, n_item = cn;               // sample of this item's tile
             if (last) {
-                int z0, y0, x0;
-                tile_origin(t_begin + (w / nchunk) * G, n, z0, y0, x0, tis);
-                out_cur = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
-                yb_cur = y0 + my0;
+                out_cur = sb_out_prepare<OUT16>(a, cn, ctz * TZ + mz, ctx * 16, cog, lane);
+                yb_cur = cty * TY + my0;
             }
             // ---- group 0 computes; group 1 of the previous tile is stored underneath, then that tile's statistics are flushed
             if (chunk == 0) {
@@ -809,6 +824,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (prof) { t1 = __builtin_readcyclecounter(); pt[2] += t1 - t0; t0 = t1; }
             run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur, wnext);
             if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
+            if (++chunk == nchunk) {                    // next tile
+                chunk = 0;
+                ctx += gx; if (ctx >= ntx) { ctx -= ntx; ++cty; }
+                cty += gy; if (cty >= nty) { cty -= nty; ++ctz; }
+                ctz += gz; if (ctz >= ntz) { ctz -= ntz; ++cn; }
+                cn += gn;
+            }
             if (prof) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; t0 = t1; }
             __syncthreads();
             if (prof) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; pt[5] += 1; }
@@ -1260,6 +1282,7 @@ static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
 }
 
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
+    RU_REQUIRE(!(a.sigmoid && a.out_c16), "conv3_sb: the fused sigmoid exists for NCDHW output only");
     if (a.in_c4) {
         RU_REQUIRE(a.Cin <= 4 && !a.in_scale, "conv3_sb: the 4-channel kernel takes Cin <= 4 and no fused input transform");
         RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
