@@ -143,7 +143,7 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
 template <int OT, int XS, int DS>
 __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WTZ<OT>;
-    constexpr int HY = P::HY, HX = P::HX, PPOS = P::PPOS, DPOS = P::DPOS, TY = P::TY;
+    constexpr int HX = P::HX, PPOS = P::PPOS, DPOS = P::DPOS, TY = P::TY;
     extern __shared__ __attribute__((aligned(256))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -182,9 +182,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         float4 sc4[2], sh4[2];
         unsigned mx = 0, md = 0;
         int st_ring0 = 0, st_k = 0;                      // of the item whose loads are in the registers
+        // issue() is called for items 0, 1, 2, ... in order: (column, step) advance as counters and the column origin is recomputed
+        // once per column, not with four integer divisions per item in this wave's VALU stream
+        int is_k = 0, is_n = 0, is_y0 = 0, is_x0 = 0, is_ring0 = 0;
         auto issue = [&](int item) {
-            int n, k, y0, x0, ring0;
-            item_origin(item, n, k, y0, x0, ring0);
+            if (is_k == 0) item_origin(item, is_n, is_k, is_y0, is_x0, is_ring0);
+            const int n = is_n, k = is_k, y0 = is_y0, x0 = is_x0, ring0 = is_ring0;
+            if (++is_k == ntz) is_k = 0;
             st_ring0 = ring0; st_k = k;
             const int hp0 = k == 0 ? 0 : 2 * k + 2, npl = k == 0 ? 4 : 2;       // new halo planes hp0 .. hp0 + npl - 1 (halo plane hp <-> z = hp - 1)
             const float* xb = a.x + ((size_t)(n * CBi + cgp) * DHW) * 16 + hsel * 8;
@@ -327,8 +331,10 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         const int xrow_off = yb * HX * 32 + lane_off;
         const int drow_off = (zw * TY + yb) * 16 * 32 + qw * 2 * P::DPLANE + lane_off;
         __syncthreads();                                // item 0 is staged
+        int cj = 0, ck = 0;
         for (int w = 0; w < nitems; ++w) {
-            const int j = w / ntz, k = w - j * ntz;
+            const int j = cj, k = ck;
+            if (++ck == ntz) { ck = 0; ++cj; }
             const int s0 = j * colstride + 2 * k + zw;   // ring number of halo plane (z0 - 1) + zw: tap dz reads plane s0 + dz
             int pw[3];
 #pragma unroll
