@@ -420,8 +420,23 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     const int G = gridDim.x;
     const int swz = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const int t_begin = swz;
-    const int nsteps = swz < ntile ? (ntile - swz + G - 1) / G : 0;
+    // z-walk order (when the shape allows): the G/8 workgroups of an XCD own a fixed panel of G/8 (ty, tx) tile positions of one
+    // sample and walk DOWN z with it, step by step, then take their next panel.  The two z-halo planes a tile shares with the tile
+    // above it were loaded by the same XCD one step earlier and are still in its L2 (a step stages ~2 MB per XCD); in the plain order
+    // the z neighbour belongs to another XCD in the same step and both L2s fetch the planes.
+    const int tiles_xy = nty * ntx, Pn = G / 8;
+    const bool zwalk = !(dbg & 256) && (G % 8 == 0) && Pn > 0 && (tiles_xy % Pn == 0) && ((a.N * (tiles_xy / Pn)) % 8 == 0);
+    const int zw_pps = zwalk ? tiles_xy / Pn : 1;        // panels per sample
+    const int zw_xcd = blockIdx.x % 8, zw_j = blockIdx.x / 8;
+    const int nsteps = zwalk ? (a.N * zw_pps / 8) * ntz : (swz < ntile ? (ntile - swz + G - 1) / G : 0);
     const int nitems = nsteps * nchunk;
+    auto tile_of = [&](int step) {
+        if (!zwalk) return t_begin + step * G;
+        const int q = step / ntz, tz = step - q * ntz;
+        const int panel = zw_xcd + 8 * q;
+        const int n = panel / zw_pps, pb = panel - n * zw_pps;
+        return (n * ntz + tz) * tiles_xy + pb * Pn + zw_j;
+    };
     const bool xform = a.in_scale != nullptr;
     const float slope = xform ? a.in_slope : 1.f;    // neutral constants make the fused transform branch-free
 
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         float ve[16];
         auto issue = [&](int item) {                          // issue every load of `item` (no waits)
             if (dbg & 2) return;
-            const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
+            const int tile = tile_of(item / nchunk), chunk = item % nchunk;
             int z0, y0, x0, tis;
             tile_origin(tile, n_cur, z0, y0, x0, tis);
             {
@@ -562,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         unsigned vmask = 0;
         auto issue = [&](int item) {
             if (dbg & 2) return;
-            const int tile = t_begin + (item / nchunk) * G, chunk = item % nchunk;
+            const int tile = tile_of(item / nchunk), chunk = item % nchunk;
             int n, z0, y0, x0, tis;
             tile_origin(tile, n, z0, y0, x0, tis);
             const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
@@ -779,13 +794,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         unsigned long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
         // The tile of step k is t_begin + k*G: its (sample, tz, ty, tx) digits advance by the digits of G with carries -- scalar adds
         // instead of the five integer divisions per item (each ~40 instructions in this wave's stream between its MFMAs)
-        int cn, ctz, cty, ctx;
-        {
-            int b = t_begin;
+        int cn, ctz, cty, ctx, cstep = 0;
+        auto digits_of_step = [&](int step) {
+            int b = tile_of(step);
             cn = b / tiles_per_sample; b -= cn * tiles_per_sample;
             ctx = b % ntx; b /= ntx;
             cty = b % nty; ctz = b / nty;
-        }
+        };
+        digits_of_step(0);
         int gn, gz, gy, gx;
         {
             int b = G;
@@ -826,10 +842,15 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
             if (++chunk == nchunk) {                    // next tile
                 chunk = 0;
-                ctx += gx; if (ctx >= ntx) { ctx -= ntx; ++cty; }
-                cty += gy; if (cty >= nty) { cty -= nty; ++ctz; }
-                ctz += gz; if (ctz >= ntz) { ctz -= ntz; ++cn; }
-                cn += gn;
+                ++cstep;
+                if (zwalk) {
+                    if (++ctz == ntz) digits_of_step(cstep);    // next panel (once per ntz steps)
+                } else {
+                    ctx += gx; if (ctx >= ntx) { ctx -= ntx; ++cty; }
+                    cty += gy; if (cty >= nty) { cty -= nty; ++ctz; }
+                    ctz += gz; if (ctz >= ntz) { ctz -= ntz; ++cn; }
+                    cn += gn;
+                }
             }
             if (prof) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; t0 = t1; }
             __syncthreads();
