@@ -705,6 +705,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // (32 KB per CU from all CUs at once) is HBM-write bound and used to stall the matrix pipe for ~25 % of the kernel.
         // Inside a group, the A fragment of K-step ks+1 is read right after the last MFMA that uses the register: one LDS
         // instruction between two MFMAs instead of a burst (sched_barrier pins the written order).
+        bf16x8 ah[HM], al[HM];                          // A fragments (hi / lo) of the group's M-tiles; live from group 0 into group 1
         auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase, const u32x4* wnext) {
             constexpr int gsel = decltype(GSEL)::value, cb = gsel * HM, sb = (1 - gsel) * HM;
             float4 radd[HM];
@@ -724,24 +725,27 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 }
                 return;
             }
-            bf16x8 ah[HM], al[HM];
+            if constexpr (gsel == 0) {                  // group 1's first fragments are read under group 0's last K-step
 #pragma unroll
-            for (int i = 0; i < HM; ++i) {
-                ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (cb + i) * HX]);
-                al[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (cb + i) * HX]);
+                for (int i = 0; i < HM; ++i) {
+                    ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (cb + i) * HX]);
+                    al[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (cb + i) * HX]);
+                }
             }
             static_for<SB_KSTEPS>([&](auto KS) {
                 constexpr int ks = decltype(KS)::value;
-                constexpr bool more = ks + 1 < SB_KSTEPS;
+                constexpr bool within = ks + 1 < SB_KSTEPS;
+                constexpr bool more = within || gsel == 0;         // fragments to fetch: this group's next K-step, or group 1's first
+                constexpr int nb = within ? cb : HM;                // first M-tile of the group they belong to
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                const int nofs = aoff[more ? ks + 1 : ks];
+                const int nofs = aoff[within ? ks + 1 : 0];
 #pragma unroll
                 for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
                     acc[cb + i] = mm(al[i], bh, acc[cb + i]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && i > 0) {
-                        al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (cb + i - 1) * HX]);
+                        al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (nb + i - 1) * HX]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     acc[cb + i] = mm(ah[i], bl, acc[cb + i]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && i == 0) {
-                        al[HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (cb + HM - 1) * HX]);
+                        al[HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (nb + HM - 1) * HX]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     acc[cb + i] = mm(ah[i], bh, acc[cb + i]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
-                        ah[i] = __builtin_bit_cast(bf16x8, buf[nofs + (cb + i) * HX]);
+                        ah[i] = __builtin_bit_cast(bf16x8, buf[nofs + (nb + i) * HX]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
