@@ -93,6 +93,7 @@ struct BlockP {           // parameter indices of one Residual (model.py:81-97)
 
 struct GNSave {
     float *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr;
+    float act_slope = 0.01f;        // LeakyReLU slope that follows this GroupNorm (norm_input has none: 1)
 };
 
 struct BlockSave {
@@ -100,6 +101,7 @@ struct BlockSave {
     const float* xprev = nullptr;   // input before the optional down-sampling conv
     float* xs2d = nullptr;          // space-to-depth of xprev (down blocks)
     const float* x = nullptr;       // block input (after down-sampling)
+    const GNSave* xg = nullptr;     // ... which is GroupNorm(+activation) of x applied on the fly when set (first block after the stem)
     float *y1 = nullptr, *y2 = nullptr, *out = nullptr;
     GNSave g1, g2;
     int N = 0, C = 0, D = 0, H = 0, W = 0;   // extents of x / y / out
@@ -329,7 +331,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.x = x; a.wp = wp; a.y = y; a.mode = h->precision; a.wfrag = wf;
     a.in_scale = in_gn ? in_gn->scale : nullptr;
     a.in_shift = in_gn ? in_gn->shift : nullptr;
-    a.in_slope = kSlope;
+    a.in_slope = in_gn ? in_gn->act_slope : kSlope;
     a.stat_partials = partials;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16; a.in_c4 = x_c4;
@@ -340,9 +342,12 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     return RU_OK;
 }
 
+// xin_gn: the block input is GroupNorm(+activation) of the RAW tensor xprev, applied on the fly (voxel-major flow, no down-sampling
+// conv): the first conv and its weight gradient stage it with the fused transform, the residual add applies it per element
 static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, const BlockP& bp, const float* xprev,
-                     int N, int D, int H, int W /* extents of xprev */, BlockSave& sv, const float** out) {
+                     int N, int D, int H, int W /* extents of xprev */, BlockSave& sv, const float** out, const GNSave* xin_gn = nullptr) {
     sv = BlockSave();
+    sv.xg = xin_gn;
     sv.bp = &bp;
     sv.xprev = xprev;
     const int C = bp.c;
@@ -369,13 +374,14 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     const size_t V = (size_t)D * H * W;
     sv.x = x; sv.N = N; sv.C = C; sv.D = D; sv.H = H; sv.W = W;
     sv.y1 = A.alloc((size_t)N * C * V);
-    int rc = conv3_gn(h, A, s, x, h->pack + bp.pk_f1, h->fpack + bp.fk_f1, sv.y1, nullptr, P(h, params, bp.n1w), P(h, params, bp.n1b), sv.g1, N, C, C, D, H, W);
+    int rc = conv3_gn(h, A, s, x, h->pack + bp.pk_f1, h->fpack + bp.fk_f1, sv.y1, xin_gn, P(h, params, bp.n1w), P(h, params, bp.n1b), sv.g1, N, C, C, D, H, W);
     if (rc) return rc;
     sv.y2 = A.alloc((size_t)N * C * V);
     rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, h->fpack + bp.fk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
     if (rc) return rc;
     sv.out = A.alloc((size_t)N * C * V);
-    if (h->c16) RU_RUN(gn_apply16_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
+    if (h->c16) RU_RUN(gn_apply16_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s,
+                                         xin_gn ? xin_gn->scale : nullptr, xin_gn ? xin_gn->shift : nullptr, xin_gn ? xin_gn->act_slope : 1.f));
     else RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
     *out = sv.out;
     return RU_OK;
@@ -412,13 +418,20 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0], false);
     }
     if (rc) return rc;
-    h->t0 = A.alloc((size_t)N * C0 * Vl(0));
-    if (h->c16) RU_RUN(gn_apply16_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
-    else RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
-    const float* cur = h->t0;
+    // norm_input has no activation.  Voxel-major flow: its output is never written -- the first block reads the raw stem output with
+    // the affine fused into its staging (conv, weight gradient) and into its residual add
+    h->g0.act_slope = 1.0f;
+    const bool stem_fused = h->c16 && !h->first_blocks.empty() && h->first_blocks[0].down < 0;
+    h->t0 = nullptr;
+    if (!stem_fused) {
+        h->t0 = A.alloc((size_t)N * C0 * Vl(0));
+        if (h->c16) RU_RUN(gn_apply16_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
+        else RU_RUN(gn_apply_launch(h->y0, h->g0.scale, h->g0.shift, nullptr, h->t0, N, C0, Vl(0), 1.0f, s));
+    }
+    const float* cur = stem_fused ? h->y0 : h->t0;
     h->first_s.assign(h->first_blocks.size(), BlockSave());
     for (size_t j = 0; j < h->first_blocks.size(); ++j) {
-        rc = block_fwd(h, params, A, s, h->first_blocks[j], cur, N, Dl[0], Hl[0], Wl[0], h->first_s[j], &cur);
+        rc = block_fwd(h, params, A, s, h->first_blocks[j], cur, N, Dl[0], Hl[0], Wl[0], h->first_s[j], &cur, (stem_fused && j == 0) ? &h->g0 : nullptr);
         if (rc) return rc;
     }
     // encoder (model.py:416-418)
@@ -524,7 +537,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         Wgrad3Args w{};
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
         w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
-        w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
+        w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
         w.dw_cin = Cin; w.dw_cout = Cout;
         w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
         w.ws_bytes = wgrad3_workspace_bytes(N, w.Cin, w.Cout, D, H, W);
@@ -534,7 +547,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     }
     Wgrad3Args w{};
     w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16; w.dy_s16 = dy_s16 ? 1 : 0;
-    w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = kSlope;
+    w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
     w.N = N; w.Cin = Cin; w.Cout = Cout; w.D = D; w.H = H; w.W = W;
@@ -574,7 +587,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.x, nullptr, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16);
+    rc = wgrad3_run(A, s, h->precision, sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};

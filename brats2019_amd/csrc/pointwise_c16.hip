@@ -21,29 +21,47 @@ static inline dim3 c16_grid(size_t V, int blocks_nc, unsigned cap = 2048) {
 }
 
 // ------------------------------------------------------------------ GroupNorm apply: y = (res) + lrelu(x*scale[n,c] + shift[n,c])
+// RES: 0 none, 1 plain residual, 2 residual = lrelu(res*rscale[n,c] + rshift[n,c]) (a GroupNorm output that was never written)
+template <int RES>
 __global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         const float* __restrict__ res, float* __restrict__ y, int C, size_t V, float slope) {
+                                                         const float* __restrict__ res, float* __restrict__ y, int C, size_t V, float slope,
+                                                         const float* __restrict__ rscale, const float* __restrict__ rshift, float rslope) {
     const int nb = blockIdx.y, CB = C >> 4;
     const int n = nb / CB, cb = nb - n * CB;
     const int q = threadIdx.x & 3;
-    const float4 a = *reinterpret_cast<const float4*>(scale + (size_t)n * C + cb * 16 + 4 * q);
-    const float4 b = *reinterpret_cast<const float4*>(shift + (size_t)n * C + cb * 16 + 4 * q);
+    const size_t pc = (size_t)n * C + cb * 16 + 4 * q;
+    const float4 a = *reinterpret_cast<const float4*>(scale + pc);
+    const float4 b = *reinterpret_cast<const float4*>(shift + pc);
+    float4 ra = make_float4(1.f, 1.f, 1.f, 1.f), rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RES == 2) { ra = *reinterpret_cast<const float4*>(rscale + pc); rb = *reinterpret_cast<const float4*>(rshift + pc); }
     const size_t base = (size_t)nb * V * 4, F = V * 4;
     const float4* xp = reinterpret_cast<const float4*>(x) + base;
-    const float4* rp = res ? reinterpret_cast<const float4*>(res) + base : nullptr;
+    const float4* rp = reinterpret_cast<const float4*>(res) + base;
     float4* yp = reinterpret_cast<float4*>(y) + base;
     for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (size_t)gridDim.x * 256) {
         const float4 t = xp[f];
         float4 o;
         o.x = lrelu(t.x * a.x + b.x, slope); o.y = lrelu(t.y * a.y + b.y, slope);
         o.z = lrelu(t.z * a.z + b.z, slope); o.w = lrelu(t.w * a.w + b.w, slope);
-        if (rp) { const float4 r = rp[f]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if constexpr (RES != 0) {
+            float4 r = rp[f];
+            if constexpr (RES == 2) {
+                r.x = lrelu(r.x * ra.x + rb.x, rslope); r.y = lrelu(r.y * ra.y + rb.y, rslope);
+                r.z = lrelu(r.z * ra.z + rb.z, rslope); r.w = lrelu(r.w * ra.w + rb.w, rslope);
+            }
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         yp[f] = o;
     }
 }
-int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s) {
+int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s,
+                      const float* rscale, const float* rshift, float rslope) {
     RU_REQUIRE(C % 16 == 0, "gn_apply16: C must be a multiple of 16");
-    hipLaunchKernelGGL(gn_apply16_kernel, c16_grid(V, N * (C / 16)), dim3(256), 0, s, x, scale, shift, res, y, C, V, slope);
+    RU_REQUIRE(!rscale || (res && rshift), "gn_apply16: a residual transform needs the residual and both of its vectors");
+    const dim3 grid = c16_grid(V, N * (C / 16));
+    if (!res) hipLaunchKernelGGL(gn_apply16_kernel<0>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
+    else if (!rscale) hipLaunchKernelGGL(gn_apply16_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
+    else hipLaunchKernelGGL(gn_apply16_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
     RU_CHECK_LAUNCH("gn_apply16_kernel");
     return RU_OK;
 }

@@ -194,7 +194,8 @@ size_t bias_grad_workspace_bytes(int N, int C, size_t V);
 int head_grad_c4_launch(const float* p, const float* dp, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
 
 // ------------------------------------------------------------------ the same on the voxel-major layout C16 (pointwise_c16.hip)
-int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s);
+int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s,
+                      const float* rscale = nullptr, const float* rshift = nullptr, float rslope = 1.f);   // optional: residual = lrelu(res*rscale + rshift)
 int gn_bwd_tiles16(size_t V);
 int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
                            float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
