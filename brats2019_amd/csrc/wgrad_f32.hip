@@ -545,6 +545,138 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
     }
 }
 
+// ---- weight gradient of the 2x2x2 stride-2 conv on voxel-major tensors (x = the FINE tensor, gathered; "input channel" kb*16 + c =
+// (tap, fine channel)).  wgrad1_f32_kernel gives every 32-channel group of the 8*Cin gathered channels its own workgroups, and each
+// of them re-reads the dy tile (Cin = 16: dy read 4 times, 2 units of traffic for 1.25 of data).  Here a workgroup keeps the dy tile
+// of a voxel chunk in LDS and walks W1S_NG = 4 channel groups over it (accumulators for all four in registers), the x tile of the
+// next group in flight while the current one is on the matrix cores.
+constexpr int W1S_NG = 4;
+__global__ __launch_bounds__(256, 2) void wgrad1_s2d_kernel(const Wgrad1Args a, float* __restrict__ partials, int nchunk, int ncgb, int CoP, int CiP) {
+    constexpr int OT = 2, CT = 2, NG = W1S_NG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dys = smem;
+    float* xs = smem + OT * 16 * W1_RS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = blockIdx.y / ncgb, cgb = blockIdx.y % ncgb;
+    const int o0 = og * OT * 16, cbase = cgb * NG * CT * 16;
+    const size_t V = a.V;
+    const int CBf = a.Cin >> 7;                          // channel blocks of the fine tensor
+    const int Hf = 2 * a.Hc, Wf = 2 * a.Wc;
+    f32x4 acc[NG][OT][CT];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int p = 0; p < OT; ++p)
+#pragma unroll
+            for (int q = 0; q < CT; ++q) acc[g][p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int abase = (lane & 15) * W1_RS + (lane >> 4) + wave * 64;
+    const int q4 = tid & 3, r0 = tid >> 2;               // a thread's float4 units: channel quad q4 of voxels r0 + 64*i, block p
+    constexpr int NU = 8;                                // units per thread and operand: (p = j >> 2, i = j & 3)
+    const long ntot = (long)a.N * nchunk;
+    for (long t = blockIdx.x; t < ntot; t += gridDim.x) {
+        const int n = (int)(t / nchunk);
+        const size_t v0 = (size_t)(t % nchunk) * W1_VC;
+        size_t fv[4];                                    // fine corner voxel of the 4 coarse voxels of this thread
+        bool okv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t v = v0 + r0 + 64 * i;
+            okv[i] = v < V;
+            const size_t vv = okv[i] ? v : 0;
+            const int xc = (int)(vv % a.Wc);
+            const size_t rr = vv / a.Wc;
+            const int yc = (int)(rr % a.Hc), zc = (int)(rr / a.Hc);
+            fv[i] = ((size_t)(2 * zc) * Hf + 2 * yc) * Wf + 2 * xc;
+        }
+        float4 dv[NU], xv[NU];
+        auto load_x = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const int p = j >> 2, i = j & 3;
+                const int kb = ((cbase + g * CT * 16) >> 4) + p, tap = kb / CBf, cbf = kb - tap * CBf;
+                const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
+                const float4 t4 = *reinterpret_cast<const float4*>(a.x + (((size_t)n * CBf + cbf) * (V * 8) + fv[i] + toff) * 16 + 4 * q4);
+                xv[j] = okv[i] ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto store_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                float* d = xs + ((j >> 2) * 16 + 4 * q4) * W1_RS + r0 + 64 * (j & 3);
+                d[0] = xv[j].x; d[W1_RS] = xv[j].y; d[2 * W1_RS] = xv[j].z; d[3 * W1_RS] = xv[j].w;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int p = j >> 2, i = j & 3;
+            const size_t v = okv[i] ? v0 + r0 + 64 * i : 0;
+            const float4 t4 = *reinterpret_cast<const float4*>(a.dy + (((size_t)n * (a.Cout >> 4) + (o0 >> 4) + p) * V + v) * 16 + 4 * q4);
+            dv[j] = okv[i] ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        load_x(0);
+        __syncthreads();                                 // the previous chunk's last group is off the LDS tiles
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            float* d = dys + ((j >> 2) * 16 + 4 * q4) * W1_RS + r0 + 64 * (j & 3);
+            d[0] = dv[j].x; d[W1_RS] = dv[j].y; d[2 * W1_RS] = dv[j].z; d[3 * W1_RS] = dv[j].w;
+        }
+        store_x();
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_x(g + 1);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                float af[OT], bf[CT];
+#pragma unroll
+                for (int p = 0; p < OT; ++p) af[p] = dys[abase + p * 16 * W1_RS + ks * 4];
+#pragma unroll
+                for (int q = 0; q < CT; ++q) bf[q] = xs[abase + q * 16 * W1_RS + ks * 4];
+#pragma unroll
+                for (int p = 0; p < OT; ++p)
+#pragma unroll
+                    for (int q = 0; q < CT; ++q)
+                        acc[g][p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p], bf[q], acc[g][p][q], 0, 0, 0);
+            }
+            if (g + 1 < NG) {
+                __syncthreads();
+                store_x();
+                __syncthreads();
+            }
+        }
+    }
+    // fold the four waves' accumulators through LDS (fixed order), one channel group at a time: ONE partial per workgroup
+    float* red = smem;                                   // [4][OT*CT][256]
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < OT; ++p)
+#pragma unroll
+            for (int q = 0; q < CT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((wave * OT * CT + p * CT + q) * 4 + r) * 64 + lane] = acc[g][p][q][r];
+        __syncthreads();
+        for (int e = tid; e < OT * CT * 256; e += 256) {
+            const int pq = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+            const float v = (red[((0 * OT * CT + pq) * 4 + r) * 64 + ln] + red[((1 * OT * CT + pq) * 4 + r) * 64 + ln]) +
+                            (red[((2 * OT * CT + pq) * 4 + r) * 64 + ln] + red[((3 * OT * CT + pq) * 4 + r) * 64 + ln]);
+            const int p = pq / CT, q = pq - p * CT;
+            const int c = cbase + g * CT * 16 + q * 16 + (ln & 15), o = o0 + p * 16 + (ln >> 4) * 4 + r;
+            if (o < CoP && c < CiP) partials[((size_t)blockIdx.x * CoP + o) * CiP + c] = v;
+        }
+    }
+}
+static bool wgrad1_s2d_usable(int Cin, int Cout) { return Cout % 32 == 0 && Cin % (W1S_NG * 32) == 0; }
+static int wgrad1_s2d_nbx(int N, int Cin, int Cout, size_t V) {
+    const int ngroups = (Cout / 32) * (Cin / (W1S_NG * 32));
+    long nbx = 512 / ngroups;                            // two resident workgroups per CU
+    if (nbx < 1) nbx = 1;
+    const long ntot = (long)N * (long)((V + W1_VC - 1) / W1_VC);
+    return (int)(nbx > ntot ? ntot : nbx);
+}
+
 struct W1Choice { int ot, ct, nbx, ngroups, ncg, nchunk; };
 
 static W1Choice wgrad1_choose(int N, int Cin, int Cout, size_t V) {
@@ -565,7 +697,9 @@ static W1Choice wgrad1_choose(int N, int Cin, int Cout, size_t V) {
 
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V) {
     const W1Choice c = wgrad1_choose(N, Cin, Cout, V);
-    return (size_t)c.nbx * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
+    int nbx = c.nbx;
+    if (wgrad1_s2d_usable(Cin, Cout)) { const int n2 = wgrad1_s2d_nbx(N, Cin, Cout, V); if (n2 > nbx) nbx = n2; }   // either kernel
+    return (size_t)nbx * round_up(Cout, 16) * round_up(Cin, 16) * sizeof(float);
 }
 
 template <int OT, int CT>
@@ -592,6 +726,19 @@ int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
     if (!a.ws || a.ws_bytes < wgrad1_workspace_bytes(a.N, a.Cin, a.Cout, a.V)) {
         set_error("wgrad1: workspace too small");
         return RU_ENOMEM;
+    }
+    if (a.s2d && wgrad1_s2d_usable(a.Cin, a.Cout)) {
+        static bool attr_done = false;
+        const size_t lds = (size_t)4 * 16 * W1_RS * sizeof(float);
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1_s2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1_s2d)");
+            attr_done = true;
+        }
+        const int nbx = wgrad1_s2d_nbx(a.N, a.Cin, a.Cout, a.V), ncgb = a.Cin / (W1S_NG * 32);
+        hipLaunchKernelGGL(wgrad1_s2d_kernel, dim3(nbx, (a.Cout / 32) * ncgb), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, ncgb, a.Cout, a.Cin);
+        RU_CHECK_LAUNCH("wgrad1_s2d_kernel");
+        return wgrad_reduce_launch((const float*)a.ws, nbx, 1, a.Cout, a.Cin, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s);
     }
     if (c.ot == 2 && c.ct == 2) return wgrad1_cfg<2, 2>(a, c, s);
     if (c.ot == 2) return wgrad1_cfg<2, 1>(a, c, s);
