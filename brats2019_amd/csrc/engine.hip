@@ -671,10 +671,19 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         // decoder_convs1x1[i] over cat([skip, v]) (model.py:424-425)
         const float* wdec = P(h, params, h->dec1_w[i]);          // [Ci][2Ci]
         float* gdec = G(h, grads, h->dec1_w[i]);
-        rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V, c16);
-        if (rc) return rc;
-        rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V, c16);
-        if (rc) return rc;
+        if (c16) {                                               // one pass over dcur for both halves of the (never materialised) concat
+            Wgrad1Args w{};
+            w.x = ds.skip; w.x1 = ds.v; w.C0 = Ci; w.dy = dcur; w.dw = gdec; w.ldw = 2 * Ci; w.c16 = 1;
+            w.ws_bytes = wgrad1_workspace_bytes(N, 2 * Ci, Ci, V);
+            w.ws = A.alloc(w.ws_bytes / sizeof(float));
+            w.N = N; w.Cin = 2 * Ci; w.Cout = Ci; w.V = V;
+            RU_RUN(wgrad1_launch(w, s));
+        } else {
+            rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V, c16);
+            if (rc) return rc;
+            rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V, c16);
+            if (rc) return rc;
+        }
         float* dsk = A.alloc((size_t)N * Ci * V);
         float* dv = A.alloc((size_t)N * Ci * V);
         Conv1Args a1{};

@@ -123,6 +123,8 @@ struct Wgrad1Args {
     int s2d, Dc, Hc, Wc;     // c16 only, s2d = 1: x is the FINE tensor of a 2x2x2 stride-2 conv (Cin/8 channels, extents 2Dc x 2Hc x 2Wc);
                              // input channel tap*(Cin/8) + c lives at fine voxel (2z+i, 2y+j, 2x+k); V = Dc*Hc*Wc
     int tap_split;           // > 0: the Cin index is tap*tap_split + c of a 2x2x2 conv: written to dw[o*ldw + c*8 + tap]
+    const float* x1;         // c16 only, optional: input channels C0 .. Cin-1 live in this second tensor (a channel concat that was never made)
+    int C0;                  // channels of x when x1 is set (multiple of 16)
 };
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s);

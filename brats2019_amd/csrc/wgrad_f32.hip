@@ -425,6 +425,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
             // voxel-major tensors: one aligned float4 = 4 channels of one voxel; scattered into the [channel][voxel] LDS rows
             constexpr int ND = OT * 16 * W1_VC / 4 / 256, NX = CT * 16 * W1_VC / 4 / 256;
             float4 dv[ND], xv[NX];
+            const int xCB0 = a.x1 ? a.C0 >> 4 : a.Cin >> 4, xCB1 = a.x1 ? (a.Cin - a.C0) >> 4 : 1;
+            const float* xsecond = a.x1 ? a.x1 : a.x;
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 const int e4 = tid + j * 256, q = e4 & 3, r = (e4 >> 2) % W1_VC, p = e4 / (4 * W1_VC);
@@ -448,7 +450,12 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
                 } else {
                     off = (((size_t)n * (a.Cin >> 4) + (c0 >> 4) + p) * V + vv) * 16 + 4 * q;
                 }
-                const float4 t4 = *reinterpret_cast<const float4*>(a.x + off);
+                // optional second input tensor (channel blocks >= xCB0): selects of base and block index, no branch around the load
+                const int kbx = (c0 >> 4) + p;
+                const bool second = kbx >= xCB0;
+                const float* xsrc = second ? xsecond : a.x;
+                if (!a.s2d) off = (((size_t)n * (second ? xCB1 : xCB0) + (second ? kbx - xCB0 : kbx)) * V + vv) * 16 + 4 * q;
+                const float4 t4 = *reinterpret_cast<const float4*>(xsrc + off);
                 xv[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -722,6 +729,7 @@ int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.V > 0 && a.ldw >= a.Cin, "wgrad1: bad shape");
     RU_REQUIRE(!a.c16 || (a.Cin % 16 == 0 && a.Cout % 16 == 0), "wgrad1: C16 tensors need channel counts that are multiples of 16");
     RU_REQUIRE(!a.s2d || (a.c16 && a.Cin % 128 == 0 && (size_t)a.Dc * a.Hc * a.Wc == a.V), "wgrad1: bad stride-2 geometry");
+    RU_REQUIRE(!a.x1 || (a.c16 && !a.s2d && a.C0 > 0 && a.C0 < a.Cin && a.C0 % 16 == 0), "wgrad1: a second input tensor needs voxel-major tensors and a split at a multiple of 16");
     const W1Choice c = wgrad1_choose(a.N, a.Cin, a.Cout, a.V);
     if (!a.ws || a.ws_bytes < wgrad1_workspace_bytes(a.N, a.Cin, a.Cout, a.V)) {
         set_error("wgrad1: workspace too small");
