@@ -695,8 +695,9 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             a1.wT = h->pack + h->pk_decT[i]; a1.ldw = Ci;
             a2.wT = h->pack + h->pk_decT[i] + (size_t)Ci * Ci; a2.ldw = Ci;
             a2.y = dpre; a2.mask = ds.v; a2.mask_slope = kSlope; // LeakyReLU backward (model.py:422) fused into the store
-            RU_RUN(conv1_16_launch(a1, s));
-            RU_RUN(conv1_16_launch(a2, s));
+            Conv1Args a12 = a1;                                  // both halves in one pass over dcur: [2Ci][Ci] weights, split output
+            a12.Cout = 2 * Ci; a12.Cout0 = Ci; a12.y1 = dpre; a12.mask = ds.v; a12.mask_slope = kSlope;
+            RU_RUN(conv1_16_launch(a12, s));
         } else {
             a1.wT = wdec; a1.ldw = 2 * Ci;
             a2.wT = A.dry ? nullptr : wdec + Ci; a2.ldw = 2 * Ci;

@@ -432,22 +432,32 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             const int cob = cog * COB + cb;
             if (cob >= CBo) continue;
             size_t idx;
+            float* ydst = a.y;
+            bool second = false;
             if constexpr (S2D == 2) {
                 const int tap = cob / CBf_out, cbf = cob - tap * CBf_out;
                 const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
                 idx = ((size_t)(n * CBf_out + cbf) * Vf + fv[t] + toff) * 16 + 4 * g;
             } else {
-                idx = ((size_t)(n * CBo + cob) * V + v) * 16 + 4 * g;
+                int cbt = CBo, cl = cob;
+                if (a.y1) {                              // split output: channel blocks >= Cout0/16 belong to the second tensor
+                    const int CB0o = a.Cout0 >> 4;
+                    second = cob >= CB0o;
+                    cbt = second ? CBo - CB0o : CB0o;
+                    cl = second ? cob - CB0o : cob;
+                    ydst = second ? a.y1 : a.y;
+                }
+                idx = ((size_t)(n * cbt + cl) * V + v) * 16 + 4 * g;
             }
             float4 o = make_float4(lrelu(acc[t][cb][0], a.out_slope), lrelu(acc[t][cb][1], a.out_slope),
                                    lrelu(acc[t][cb][2], a.out_slope), lrelu(acc[t][cb][3], a.out_slope));
-            if (a.mask) {
+            if (a.mask && (second || !a.y1)) {
                 const float4 m = *reinterpret_cast<const float4*>(a.mask + idx);
                 o.x = m.x > 0.f ? o.x : o.x * a.mask_slope; o.y = m.y > 0.f ? o.y : o.y * a.mask_slope;
                 o.z = m.z > 0.f ? o.z : o.z * a.mask_slope; o.w = m.w > 0.f ? o.w : o.w * a.mask_slope;
             }
             if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
-            *reinterpret_cast<float4*>(a.y + idx) = o;
+            *reinterpret_cast<float4*>(ydst + idx) = o;
         }
     }
 }
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
 int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
     RU_REQUIRE(a.N > 0 && a.C0 > 0 && a.Cout > 0 && a.V > 0, "conv1_16: bad shape");
     RU_REQUIRE(a.C0 % 16 == 0 && a.C1 % 16 == 0 && a.Cout % 16 == 0 && a.ldw >= a.C0 + a.C1 && a.ldw % 4 == 0, "conv1_16: channels must be multiples of 16");
+    RU_REQUIRE(!a.y1 || (!a.s2d && !a.add && a.Cout0 > 0 && a.Cout0 < a.Cout && a.Cout0 % 16 == 0), "conv1_16: a split output needs the plain mode, no residual and a split at a multiple of 16");
     if (a.s2d) {
         RU_REQUIRE(a.Dc > 0 && a.Hc > 0 && a.Wc > 0 && (size_t)a.Dc * a.Hc * a.Wc == a.V && a.C1 == 0, "conv1_16: bad stride-2 geometry");
         RU_REQUIRE(a.s2d == 1 ? a.C0 % 128 == 0 : a.Cout % 128 == 0, "conv1_16: stride-2 modes need 8 x (multiple of 16) channels");

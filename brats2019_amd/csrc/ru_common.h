@@ -149,6 +149,10 @@ struct Conv1Args {
     // conv1_16_launch only: LeakyReLU backward fused into the store: y = acc * (mask[idx] > 0 ? 1 : mask_slope), mask laid out like y
     const float* mask;
     float mask_slope;
+    // conv1_16_launch only, plain mode: output channels Cout0 .. Cout-1 go to a second tensor y1 ([N][(Cout-Cout0)/16][V][16]); `mask`
+    // then applies to (and is laid out like) y1 only.  Two 1x1 convs of one input in one pass.
+    float* y1;
+    int Cout0;
 };
 int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
