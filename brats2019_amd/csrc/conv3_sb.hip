@@ -102,15 +102,14 @@ __device__ __forceinline__ size_t sb_out_index(const Conv3Args& a, const SbOut& 
     return o.base + (size_t)(unsigned)yy * o.rs;
 }
 template <bool OUT16, int NS>
-__device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, float (&s1)[NS], float (&s2)[NS]) {
+__device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, f32x4& s1, f32x4& s2) {
     if (!(o.ok && yy < a.H)) return;
     // straight-line: bias and residual are zeros when absent and the statistics are always taken -- each wave-uniform `if (a.x)` here
     // was a branch (plus phi moves) in the consumer's instruction stream between its MFMAs, ~375 cycles per tile row
-    v[0] += o.bias.x; v[1] += o.bias.y; v[2] += o.bias.z; v[3] += o.bias.w;
-    v[0] += radd.x; v[1] += radd.y; v[2] += radd.z; v[3] += radd.w;
+    v += f32x4{o.bias.x, o.bias.y, o.bias.z, o.bias.w} + f32x4{radd.x, radd.y, radd.z, radd.w};
     if constexpr (OUT16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+        s1 += v;
+        s2 += v * v;
     } else {
         s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
         s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -127,7 +126,7 @@ __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, 
 }
 // per-wave statistics partial of one tile: [N][Cout][nblk][2] at block tile_in_sample*4 + wave
 template <bool OUT16, int NS>
-__device__ __forceinline__ void sb_out_stats(const Conv3Args& a, float (&s1)[NS], float (&s2)[NS], int n, int cog, int blk, int nblk, int lane) {
+__device__ __forceinline__ void sb_out_stats(const Conv3Args& a, f32x4& s1, f32x4& s2, int n, int cog, int blk, int nblk, int lane) {
     if (!a.stat_partials) return;
     if constexpr (OUT16) {
 #pragma unroll
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
     }
     // ---- epilogue: per-wave statistics partial (block tis*4 + wave), like the persistent kernel
     constexpr int NS = OUT16 ? 4 : 1;
-    float s1[NS], s2[NS];
+    f32x4 s1, s2;                                   // whole vectors: the per-row update is 2 v_pk_add + 2 v_pk_fma, no packing moves
 #pragma unroll
     for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
     const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
@@ -696,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         };
         constexpr int NS = OUT16 ? 4 : 1;
         constexpr int HM = MT / 2;
-        float s1[NS], s2[NS];
+        f32x4 s1, s2;                                   // whole vectors: the per-row update is 2 v_pk_add + 2 v_pk_fma, no packing moves
 #pragma unroll
         for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
         // The M-tiles of a wave form two groups (0..HM-1, HM..MT-1).  A group runs all 14 K-steps on its own accumulators while
@@ -742,7 +741,8 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const int nofs = aoff[within ? ks + 1 : 0];
 #pragma unroll
                 for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
-                    acc[cb + i] = mm(al[i], bh, acc[cb + i]);
+                    if constexpr (!MULTI && ks == 0) acc[cb + i] = mm(al[i], bh, f32x4{0.f, 0.f, 0.f, 0.f});    // one chunk: starts from the zero operand, no v_mov per accumulator
+                    else acc[cb + i] = mm(al[i], bh, acc[cb + i]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && i > 0) {
                         al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (nb + i - 1) * HX]);
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 yb_cur = cty * TY + my0;
             }
             // ---- group 0 computes; group 1 of the previous tile is stored underneath, then that tile's statistics are flushed
-            if (chunk == 0) {
+            if (MULTI && chunk == 0) {
 #pragma unroll
                 for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 pend = false;
             }
             // ---- group 1 computes; group 0 of this tile is stored underneath
-            if (chunk == 0) {
+            if (MULTI && chunk == 0) {
 #pragma unroll
                 for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
             else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
         };
         constexpr int NS = OUT16 ? 4 : 1;
-        float s1[NS], s2[NS];
+        f32x4 s1, s2;                                   // whole vectors: the per-row update is 2 v_pk_add + 2 v_pk_fma, no packing moves
 #pragma unroll
         for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
         const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
