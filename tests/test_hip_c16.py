@@ -22,9 +22,11 @@ def test_layout_roundtrip():
 
 
 @pytest.mark.parametrize("in16,out16", [(True, True), (True, False), (False, True)])
-@pytest.mark.parametrize("shape", [(4, 16, 16, 32, 32, 64), (1, 32, 32, 64, 64, 64)])
+@pytest.mark.parametrize("shape", [(4, 16, 16, 32, 32, 64), (1, 32, 32, 64, 64, 64), (2, 16, 16, 8, 128, 128)])
 def test_conv3_layouts_equal_ncdhw(shape, in16, out16):
-    """same split-bf16 arithmetic, different storage: identical K-order per output -> bit-equal results"""
+    """same split-bf16 arithmetic, different storage: identical K-order per output -> bit-equal results.  The last shape
+    (N * tiles per z-layer a multiple of 256) takes the z-walk tile order of the persistent kernel; every shape is also
+    checked against the exact-f32 kernel, which has its own tiling."""
     from brats2019_amd import ops
     n, cin, cout, d, h, w = shape
     x = _rand(n, cin, d, h, w, seed=1)
@@ -34,6 +36,8 @@ def test_conv3_layouts_equal_ncdhw(shape, in16, out16):
     if out16:
         y = ops.from_c16(y)
     assert torch.equal(y, ref), float((y - ref).abs().max())
+    exact = ops.conv3d(x, wt, precision="f32")
+    assert float((y - exact).abs().max()) <= 2e-4 * float(exact.abs().max())
 
 
 @pytest.mark.parametrize("x16,dy16", [(True, True), (True, False), (False, True)])
