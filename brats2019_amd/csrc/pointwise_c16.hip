@@ -69,8 +69,9 @@ int gn_apply16_launch(const float* x, const float* scale, const float* shift, co
 // ------------------------------------------------------------------ GroupNorm backward
 // reduce: per (n, c) and voxel chunk S1 = sum dyh, S2 = sum dyh * xhat (dyh = dy * lrelu'(x*scale+shift)); partials
 // [N][C][nblk][2] exactly like the NCDHW kernel, so gn_bwd_finalize is shared.  Fixed reduction order: deterministic.
-// voxels of one (n, channel block) reduced by one workgroup: large volumes take 8192 so the whole grid is resident at once
-static inline int gn16_chunk(size_t V) { return V >= ((size_t)1 << 20) ? 8192 : 2048; }
+// voxels of one (n, channel block) reduced by one workgroup: large volumes take 8192 so the whole grid is resident at once,
+// 16^3 volumes 512 (2048 left 64 workgroups for 256 CUs)
+static inline int gn16_chunk(size_t V) { return V >= ((size_t)1 << 20) ? 8192 : (V >= ((size_t)1 << 15) ? 2048 : 512); }   // small volumes: enough workgroups to fill the chip
 int gn_bwd_tiles16(size_t V) { const int ch = gn16_chunk(V); return (int)((V + ch - 1) / ch); }
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
