@@ -124,6 +124,20 @@ __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, 
     }
     *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
+// GroupNorm-backward sums are taken on the way: u = y*k1 + k2 (= sign(gamma)*xhat), dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
+__device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& yv, const f32x4 (&kc)[3], float slope,
+                                                f32x4& s1, f32x4& s2) {
+    if (!(o.ok && yy < a.H)) return;
+    const f32x4 u = f32x4{yv.x, yv.y, yv.z, yv.w} * kc[0] + kc[1];
+    const f32x4 vs = v * slope;
+    f32x4 dh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = u[r] > kc[2][r] ? v[r] : vs[r];
+    s1 += dh;
+    s2 += dh * u;
+    *reinterpret_cast<float4*>(a.y + sb_out_index<true>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
+}
 // per-wave statistics partial of one tile: [N][Cout][nblk][2] at block tile_in_sample*4 + wave
 template <bool OUT16, int NS>
 __device__ __forceinline__ void sb_out_stats(const Conv3Args& a, f32x4& s1, f32x4& s2, int n, int cog, int blk, int nblk, int lane) {
@@ -393,7 +407,8 @@ __device__ unsigned long long sb2_prof[8];
 // MULTI (more than one 16-channel input chunk): the weight fragments of the NEXT item's chunk are fetched K-step by K-step into
 // the registers group 1 has just finished with, instead of 28 loads at the start of every item with the matrix pipe waiting on
 // the first (that exposed L2 latency was ~20 % of the kernel at 32..128 channels).
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI>
+// BST: fused GroupNorm-backward statistics in the epilogue (Conv3Args::bst_*), C16 output only.
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
@@ -705,22 +720,42 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // Inside a group, the A fragment of K-step ks+1 is read right after the last MFMA that uses the register: one LDS
         // instruction between two MFMAs instead of a burst (sched_barrier pins the written order).
         bf16x8 ah[HM], al[HM];                          // A fragments (hi / lo) of the group's M-tiles; live from group 0 into group 1
+        f32x4 kc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // BST: (k1, k2, thr) of this lane's 4 channels for sample kc_n
+        int kc_n = -1;
+        auto need_kc = [&](int n) __attribute__((always_inline)) {      // wave-uniform, reloads only when the sample changes
+            if constexpr (BST) {
+                if (n != kc_n) {
+                    const float* kp = a.bst_k + (size_t)n * 3 * a.Cout + cog * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t * a.Cout);
+                        kc[t] = f32x4{q.x, q.y, q.z, q.w};
+                    }
+                    kc_n = n;
+                }
+            }
+        };
         auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase, const u32x4* wnext) {
             constexpr int gsel = decltype(GSEL)::value, cb = gsel * HM, sb = (1 - gsel) * HM;
             float4 radd[HM];
 #pragma unroll
             for (int j = 0; j < HM; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (do_store && a.add) {                    // residual: unconditional loads from clamped addresses
+            if (do_store && (BST || a.add)) {           // residual (or, BST, the forward tensor y): unconditional loads from clamped addresses
+                const float* src = BST ? a.bst_y : a.add;
 #pragma unroll
                 for (int j = 0; j < HM; ++j) {
                     const int yy = ybase + sb + j;
-                    radd[j] = *reinterpret_cast<const float4*>(a.add + ((so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
+                    radd[j] = *reinterpret_cast<const float4*>(src + ((so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
                 }
             }
+            auto store_row = [&](int yy, const f32x4& v, const float4& r) __attribute__((always_inline)) {
+                if constexpr (BST) sb_out_tile_bst(a, so, yy, v, r, kc, a.bst_slope, s1, s2);
+                else sb_out_tile<OUT16, NS>(a, so, yy, v, r, s1, s2);
+            };
             if (dbg & 4) {
                 if (do_store) {
 #pragma unroll
-                    for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, so, ybase + sb + j, acc[sb + j], radd[j], s1, s2);
+                    for (int j = 0; j < HM; ++j) store_row(ybase + sb + j, acc[sb + j], radd[j]);
                 }
                 return;
             }
@@ -773,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (ks % 3 == 2 && ks / 3 < HM) {
-                    if (do_store) sb_out_tile<OUT16, NS>(a, so, ybase + sb + ks / 3, acc[sb + ks / 3], radd[ks / 3], s1, s2);
+                    if (do_store) store_row(ybase + sb + ks / 3, acc[sb + ks / 3], radd[ks / 3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -830,6 +865,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (prof) { t1 = __builtin_readcyclecounter(); pt[0] += t1 - t0; t0 = t1; }
+            if (pend) need_kc(n_prev);
             run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev, wnext);
             if (prof) { t1 = __builtin_readcyclecounter(); pt[1] += t1 - t0; t0 = t1; }
             if (pend) {
@@ -842,6 +878,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (prof) { t1 = __builtin_readcyclecounter(); pt[2] += t1 - t0; t0 = t1; }
+            if (last) need_kc(n);
             run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur, wnext);
             if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
             if (++chunk == nchunk) {                    // next tile
@@ -863,14 +900,19 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         if (prof) t0 = __builtin_readcyclecounter();
         if (pend) {                                     // drain: group 1 of the last tile
             float4 radd[HM];
+            const float* src = BST ? a.bst_y : a.add;
 #pragma unroll
             for (int j = 0; j < HM; ++j) {
                 const int yy = yb_prev + HM + j;
-                radd[j] = a.add ? *reinterpret_cast<const float4*>(a.add + ((out_prev.ok && yy < H) ? sb_out_index<OUT16>(a, out_prev, yy) : 0))
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                radd[j] = src ? *reinterpret_cast<const float4*>(src + ((out_prev.ok && yy < H) ? sb_out_index<OUT16>(a, out_prev, yy) : 0))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            need_kc(n_prev);
 #pragma unroll
-            for (int j = 0; j < HM; ++j) sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
+            for (int j = 0; j < HM; ++j) {
+                if constexpr (BST) sb_out_tile_bst(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], kc, a.bst_slope, s1, s2);
+                else sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
+            }
             flush_stats(n_prev);
         }
         if (prof && rw == 0 && lane == 0) {
@@ -1244,13 +1286,13 @@ extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
     return e == hipSuccess ? RU_OK : hip_fail(e, "hipMemcpyToSymbol(sb2_prof)");
 }
 
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI>
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false>
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static bool attr_done = false;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         attr_done = true;
     }
@@ -1260,14 +1302,18 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
 }
 template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
+    if constexpr (IN16 && OUT16) {
+        if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true>(a, s);
+    }
     return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false>(a, s);
 }
+bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W) { return sb_use_v2(sb_choose(N, Cout, D, H, W)); }
 
 template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb_cfg(const Conv3Args& a, hipStream_t s) {
@@ -1308,6 +1354,9 @@ static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
 
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!(a.sigmoid && a.out_c16), "conv3_sb: the fused sigmoid exists for NCDHW output only");
+    RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && a.in_c16 && a.out_c16 && !a.in_c4 && !a.add && !a.bias && !a.sigmoid &&
+                            conv3_sb_bst_usable(a.N, a.Cout, a.D, a.H, a.W)),
+               "conv3_sb: fused GroupNorm-backward statistics need the persistent voxel-major kernel, a partial buffer and no bias / residual / activation");
     if (a.in_c4) {
         RU_REQUIRE(a.Cin <= 4 && !a.in_scale, "conv3_sb: the 4-channel kernel takes Cin <= 4 and no fused input transform");
         RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");

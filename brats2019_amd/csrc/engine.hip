@@ -509,14 +509,18 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
 
 // ---------------------------------------------------------------------- backward pieces
 // GroupNorm(+LeakyReLU) backward: d_act -> dy (gradient w.r.t. the raw conv output), dgamma/dbeta written
+// fused_part / fused_nblk: the partial sums were already taken by the conv that produced `dact` (Conv3Args::bst_*): no reduce pass
 static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
-                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V) {
-    const int nblk = c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V);
-    float* part = A.alloc((size_t)N * C * nblk * 2);
+                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const float* fused_part = nullptr, int fused_nblk = 0) {
+    const bool fused = fused_nblk > 0;
+    const int nblk = fused ? fused_nblk : (c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V));
+    float* part = fused ? const_cast<float*>(fused_part) : A.alloc((size_t)N * C * nblk * 2);
     float* coef = A.alloc((size_t)N * C * 3);
-    if (c16) RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
-    else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
-    RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s));
+    if (!fused) {
+        if (c16) RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+        else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+    }
+    RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s, fused ? 1 : 0));
     if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, 1, s));   // split form: read by MFMA kernels only
     else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
     return RU_OK;
@@ -583,9 +587,22 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
     d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
+    // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
+    static const bool no_bst = getenv("RU_NO_BST") != nullptr;      // A/B switch: separate reduce pass
+    const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && !no_bst;
+    float* part1 = nullptr;
+    int nblk1 = 0;
+    if (fuse1) {
+        nblk1 = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
+        part1 = A.alloc((size_t)N * C * nblk1 * 2);
+        float* k1 = A.alloc((size_t)N * 3 * C);
+        RU_RUN(gn_bst_consts_launch(sv.g1.mean, sv.g1.rstd, P(h, params, bp.n1w), P(h, params, bp.n1b), k1, N, C, kGroups, s));
+        d2.bst_y = sv.y1; d2.bst_k = k1; d2.bst_slope = kSlope; d2.stat_partials = part1;
+    }
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
-    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V);
+    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, part1, nblk1);
     if (rc) return rc;
     rc = wgrad3_run(A, s, h->precision, sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16);
     if (rc) return rc;

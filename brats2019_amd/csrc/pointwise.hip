@@ -400,7 +400,7 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
 template <int LPI>
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G, int s2_sign) {
     extern __shared__ double S[];            // [N][cpg][2]
     const int g = blockIdx.x;
     const int cpg = C / G;
@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
         for (; i < nblk; i += LPI) { const float2 a = p[i]; s1 += (double)a.x; s2 += (double)a.y; }
 #pragma unroll
         for (int o = LPI / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (s2_sign && ok && gamma[g * cpg + j] < 0.f) s2 = -s2;       // fused conv statistics carry sum dh * sign(gamma) * xhat
         if (sl == 0 && ok) { S[item * 2] = s1; S[item * 2 + 1] = s2; }
     }
     __syncthreads();
@@ -452,14 +453,33 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     }
 }
 int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
-                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s) {
+                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s, int s2_sign) {
     RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
     const size_t shm = (size_t)N * (C / G) * 2 * sizeof(double);
     RU_REQUIRE(shm <= 60000, "groupnorm backward: batch x channels-per-group too large for the finalize kernel");
-    if (nblk > 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
-    else if (nblk > 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
-    else hipLaunchKernelGGL(gn_bwd_finalize_kernel<4>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G);
+    if (nblk > 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
+    else if (nblk > 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
+    else hipLaunchKernelGGL(gn_bwd_finalize_kernel<4>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
     RU_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+    return RU_OK;
+}
+
+// constants of the fused GroupNorm-backward statistics (Conv3Args::bst_k): u = y*k1 + k2 = sign(gamma)*xhat, mask <=> u > thr
+__global__ void gn_bst_consts_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ k, int N, int C, int G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C, g = c / (C / G);
+    const float gm = gamma[c], bt = beta[c], mu = mean[n * G + g], rs = rstd[n * G + g];
+    const float sg = gm < 0.f ? -1.f : 1.f;
+    float* kn = k + (size_t)n * 3 * C;
+    kn[c] = sg * rs;
+    kn[C + c] = -sg * mu * rs;
+    kn[2 * C + c] = gm == 0.f ? (bt > 0.f ? -INFINITY : INFINITY) : -bt / fabsf(gm);     // gamma*xhat + beta > 0  <=>  u > -beta/|gamma|
+}
+int gn_bst_consts_launch(const float* mean, const float* rstd, const float* gamma, const float* beta, float* k, int N, int C, int G, hipStream_t s) {
+    hipLaunchKernelGGL(gn_bst_consts_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, mean, rstd, gamma, beta, k, N, C, G);
+    RU_CHECK_LAUNCH("gn_bst_consts_kernel");
     return RU_OK;
 }
 

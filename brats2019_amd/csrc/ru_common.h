@@ -54,6 +54,14 @@ struct Conv3Args {
     int in_c16, out_c16;
     int in_s16;              // x is C16 in SPLIT form (see gn_bwd_apply16_launch): the staging copies hi/lo packets, no conversion, no transform
     int in_c4;               // x is a [N][D][H][W][4] copy (pad_to_c4) of a tensor with Cin <= 4: conv3_sb2c4_kernel, wfrag from conv3_sb4_pack_weights
+    // Fused GroupNorm-BACKWARD statistics (persistent split-bf16 kernel, C16 in and out, no bias / add / sigmoid): this conv's output is
+    // the gradient d w.r.t. the activation that followed a GroupNorm of `bst_y` (same shape as y).  The epilogue then writes, instead
+    // of (sum, sumsq), the partial sums the GroupNorm backward needs -- S1 = sum dh, S2' = sum dh*u with u = y*k1 + k2 (= sign(gamma) *
+    // xhat), dh = u > thr ? d : d*bst_slope -- to stat_partials, saving the separate reduce pass over (y, d).  bst_k: [N][3][Cout] =
+    // (k1, k2, thr) from gn_bst_consts_launch; gn_bwd_finalize_launch(..., s2_sign = 1) undoes the sign.
+    const float* bst_y;
+    const float* bst_k;
+    float bst_slope;
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
@@ -182,7 +190,11 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
                          const float* rstd, float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
 // partials -> coefficient triples coef[N][C][3] (dx = cA*dyh + cB*x + cC) and dgamma/dbeta (overwritten or accumulated)
 int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
-                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s);
+                           float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s, int s2_sign = 0);
+// k[N][3][C] = (k1, k2, thr) of Conv3Args::bst_k from the saved statistics and the affine parameters
+int gn_bst_consts_launch(const float* mean, const float* rstd, const float* gamma, const float* beta, float* k, int N, int C, int G, hipStream_t s);
+// the fused statistics need the persistent kernel: true when conv3_sb_launch will use it for this shape
+bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W);
 int gn_bwd_apply_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef,
                         float slope, float* dx, int N, int C, size_t V, hipStream_t s);
 
