@@ -942,7 +942,7 @@ __host__ __device__ constexpr int sb4_tap(int t, int half) {          // tap ind
     return dx > 2 ? -1 : r * 3 + dx;
 }
 
-template <bool OUT16>
+template <bool OUT16, bool BST>
 __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx) {
     constexpr int TZ = 4, TY = 8;
     using P = SB<TZ, TY>;
@@ -1116,14 +1116,27 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
             }
             const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
             float4 radd[MT];
+            const float* src = BST ? a.bst_y : a.add;            // BST: the forward tensor of the GroupNorm this gradient enters (Conv3Args::bst_*)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int yy = y0 + my0 + i;
-                radd[i] = a.add ? *reinterpret_cast<const float4*>(a.add + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0))
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                radd[i] = src ? *reinterpret_cast<const float4*>(src + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if constexpr (BST) {
+                f32x4 kc[3];
+                const float* kp = a.bst_k + (size_t)n * 3 * a.Cout + cog * 16 + 4 * (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
+                for (int t = 0; t < 3; ++t) {
+                    const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t * a.Cout);
+                    kc[t] = f32x4{q.x, q.y, q.z, q.w};
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sb_out_tile_bst(a, out, y0 + my0 + i, acc[i], radd[i], kc, a.bst_slope, s1, s2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
+            }
             __syncthreads();
         }
         if (n_acc >= 0) flush_stats(n_acc);
@@ -1335,26 +1348,26 @@ bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W) {
     return Cin <= 4 && sb_use_v2(sb_choose(N, Cout, D, H, W));
 }
 
-template <bool OUT16>
+template <bool OUT16, bool BST = false>
 static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<4, 8>;
     static bool attr_done = false;
     constexpr int LDS = 2 * 2 * P::HVOLP * 16;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2c4_kernel<OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2c4_kernel<OUT16, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2c4)");
         attr_done = true;
     }
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2c4: at most 32 samples per call when statistics are requested");
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
-    hipLaunchKernelGGL((conv3_sb2c4_kernel<OUT16>), grid, dim3(512), LDS, s, a, (const u32x4*)a.wfrag, cdiv(a.D, 4), cdiv(a.H, 8), cdiv(a.W, 16));
+    hipLaunchKernelGGL((conv3_sb2c4_kernel<OUT16, BST>), grid, dim3(512), LDS, s, a, (const u32x4*)a.wfrag, cdiv(a.D, 4), cdiv(a.H, 8), cdiv(a.W, 16));
     RU_CHECK_LAUNCH("conv3_sb2c4_kernel");
     return RU_OK;
 }
 
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!(a.sigmoid && a.out_c16), "conv3_sb: the fused sigmoid exists for NCDHW output only");
-    RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && a.in_c16 && a.out_c16 && !a.in_c4 && !a.add && !a.bias && !a.sigmoid &&
+    RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && (a.in_c16 || a.in_c4) && a.out_c16 && !a.add && !a.bias && !a.sigmoid &&
                             conv3_sb_bst_usable(a.N, a.Cout, a.D, a.H, a.W)),
                "conv3_sb: fused GroupNorm-backward statistics need the persistent voxel-major kernel, a partial buffer and no bias / residual / activation");
     if (a.in_c4) {
@@ -1362,6 +1375,7 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
         RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
         const SBChoice c4 = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
         RU_REQUIRE(sb_use_v2(c4), "conv3_sb: the 4-channel kernel needs at least 256 (4,8,16) tiles x cout groups");
+        if (a.bst_y) return sb2c4_cfg<true, true>(a, s);
         return a.out_c16 ? sb2c4_cfg<true>(a, s) : sb2c4_cfg<false>(a, s);
     }
     RU_REQUIRE((a.W & 3) == 0 || (a.in_c16 && a.out_c16), "conv3_sb: W must be a multiple of 4 for NCDHW tensors");

@@ -572,15 +572,16 @@ static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, 
 
 // Residual backward: dout -> d(xprev); parameter gradients into `grads`
 // `join`: a second gradient arriving at the block input (the skip connection of a down block); *joined tells whether it was added here
+// part2 / nblk2: the GroupNorm-backward sums of norm2 were taken by the kernel that produced `dout` (Conv3Args::bst_*)
 static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hipStream_t s, const BlockSave& sv, const float* dout,
-                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr) {
+                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr, const float* part2 = nullptr, int nblk2 = 0) {
     if (joined) *joined = false;
     const BlockP& bp = *sv.bp;
     const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
     const size_t V = (size_t)D * H * W;
     float* dy2 = A.alloc((size_t)N * C * V);
     const bool c16 = h->c16;
-    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V);
+    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2);
     if (rc) return rc;
     rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16);
     if (rc) return rc;
@@ -673,13 +674,26 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_out_w), wf4, C0, h->nout, 1, s));
         dh.x = d4; dh.wfrag = wf4; dh.in_c4 = 1;
     }
+    // the head's data gradient is the gradient entering norm2 of the last decoder block: its GroupNorm-backward sums are taken here
+    static const bool no_bst = getenv("RU_NO_BST") != nullptr;
+    const BlockSave* hb = (depth >= 2 && !h->dec_s[0].empty()) ? &h->dec_s[0].back() : nullptr;
+    float* hpart = nullptr;
+    int hnblk = 0;
+    if (head4 && hb && !no_bst && conv3_sb_bst_usable(N, C0, Dl[0], Hl[0], Wl[0])) {
+        hnblk = conv3_sb_tiles_per_sample(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);
+        hpart = A.alloc((size_t)N * C0 * hnblk * 2);
+        float* hk = A.alloc((size_t)N * 3 * C0);
+        RU_RUN(gn_bst_consts_launch(hb->g2.mean, hb->g2.rstd, P(h, params, hb->bp->n2w), P(h, params, hb->bp->n2b), hk, N, C0, kGroups, s));
+        dh.bst_y = hb->y2; dh.bst_k = hk; dh.bst_slope = kSlope; dh.stat_partials = hpart;
+    }
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
     std::vector<const float*> dskip(depth - 1, nullptr);
     // decoder stages, reverse of execution order (forward ran i = depth-2 .. 0)
     for (int i = 0; i <= depth - 2; ++i) {
         for (int j = (int)h->dec_s[i].size() - 1; j >= 0; --j) {
-            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur);
+            const bool fused2 = hnblk > 0 && i == 0 && j == (int)h->dec_s[i].size() - 1;
+            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur, nullptr, nullptr, fused2 ? hpart : nullptr, fused2 ? hnblk : 0);
             if (rc) return rc;
         }
         const DecSave& ds = h->dstage[i];
