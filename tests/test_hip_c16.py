@@ -59,8 +59,11 @@ def test_wgrad3_layouts_equal_ncdhw(shape, x16, dy16):
         assert torch.equal(dw, ref), float((dw - ref).abs().max())
 
 
-def test_engine_c16_flow_matches_ncdhw_flow_multi_sample():
-    """whole network, 3 samples of a ragged shape: the split-bf16 engine (voxel-major working layout, fused decoder / stride-2
+@pytest.mark.parametrize("shape", [(3, 24, 40, 48), (2, 16, 128, 128)])
+def test_engine_c16_flow_matches_ncdhw_flow_multi_sample(shape):
+    """whole network, several samples -- a ragged shape (one-stage conv kernel) and a wide one that takes the persistent kernels at
+    the first level with every option on (z-walk tile order, statistics partials per workgroup and sample, GroupNorm-backward sums
+    in the data-gradient epilogue across a sample boundary, 4-channel stem / head kernels): the split-bf16 engine (voxel-major working layout, fused decoder / stride-2
     paths, per-workgroup GroupNorm partials) against the f32 engine (NCDHW throughout): probabilities within 1e-4, every
     parameter gradient within 2e-2 in relative L2 norm.  The gradient bar is loose on purpose: LeakyReLU is kinked, so the
     ~1e-5 relative difference of the activations flips the branch of a ~1e-5 fraction of the units, each changing its gradient by
@@ -68,8 +71,9 @@ def test_engine_c16_flow_matches_ncdhw_flow_multi_sample():
     from brats2019_amd import model as M
     torch.manual_seed(3)
     net = M.UNet(4, [1, 2, 2, 4], [1, 1, 1, 1], [16, 32, 64, 128], 3).cuda()
-    x = _rand(3, 4, 24, 40, 48, seed=9)
-    tgt = (_rand(3, 3, 24, 40, 48, seed=10) > 0.3).float()
+    n, d, hh, ww = shape
+    x = _rand(n, 4, d, hh, ww, seed=9)
+    tgt = (_rand(n, 3, d, hh, ww, seed=10) > 0.3).float()
     res = {}
     for prec in ("f32", "bf16x3"):
         net.set_precision(prec)
