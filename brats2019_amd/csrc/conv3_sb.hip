@@ -589,15 +589,22 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         float4 v16[NR][2];
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
+        // z-walk order, one chunk: the tile of this step sits right below the previous one, so its halo planes 0 and 1 ARE planes 4 and 5
+        // of the image staged one item earlier (already transformed and split, same y/x zero padding): the first CR rounds (positions
+        // < CR*128 <= 2 planes) are copied LDS -> LDS from the other buffer instead of being loaded and converted again
+        constexpr int CR = (2 * HY * HX) / 128;
+        bool st_chain = false;                           // of the item whose loads are in the registers
         auto issue = [&](int item) {
             if (dbg & 2) return;
-            const int tile = tile_of(item / nchunk), chunk = item % nchunk;
+            const int step = item / nchunk;
+            const int tile = tile_of(step), chunk = item % nchunk;
             int n, z0, y0, x0, tis;
             tile_origin(tile, n, z0, y0, x0, tis);
             const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
             vmask = 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
+            st_chain = zwalk && !MULTI && !(dbg & 512) && CR > 0 && (step % ntz) != 0;
+            auto ld_round = [&](auto R) __attribute__((always_inline)) {
+                constexpr int r = decltype(R)::value;
                 const int p = r * 128 + pslot;
                 const int row = p / HX, xc = p - row * HX;
                 const int hz = row / HY, hy = row - hz * HY;
@@ -607,7 +614,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 vmask |= ok ? (1u << r) : 0u;
                 v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
                 v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + (s16 ? 8 : 4));
-            }
+            };
+            if (st_chain) static_for<NR - CR>([&](auto R) { ld_round(std::integral_constant<int, decltype(R)::value + CR>{}); });    // one wave-uniform branch
+            else static_for<NR>(ld_round);
             if (xform) {
                 const int cofs = n * a.Cin + chunk * 16 + hsel * 8;
                 sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
@@ -630,11 +639,27 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 sc[0] = sc4[0].x; sc[1] = sc4[0].y; sc[2] = sc4[0].z; sc[3] = sc4[0].w; sc[4] = sc4[1].x; sc[5] = sc4[1].y; sc[6] = sc4[1].z; sc[7] = sc4[1].w;
                 sh[0] = sh4[0].x; sh[1] = sh4[0].y; sh[2] = sh4[0].z; sh[3] = sh4[0].w; sh[4] = sh4[1].x; sh[5] = sh4[1].y; sh[6] = sh4[1].z; sh[7] = sh4[1].w;
             }
+            if (st_chain) {                              // planes 0, 1 <- planes 4, 5 of the other buffer (complete since the last barrier)
+                const u32x4* prev = buf == lds ? lds + BUF : lds;
+                u32x4 ch[CR > 0 ? CR : 1][2];
+#pragma unroll
+                for (int r = 0; r < CR; ++r) {
+                    const int p = r * 128 + pslot;
+                    ch[r][0] = prev[hsel * HVOLP + p + 4 * HY * HX];
+                    ch[r][1] = prev[(2 + hsel) * HVOLP + p + 4 * HY * HX];
+                }
+#pragma unroll
+                for (int r = 0; r < CR; ++r) {
+                    const int p = r * 128 + pslot;
+                    buf[hsel * HVOLP + p] = ch[r][0];
+                    buf[(2 + hsel) * HVOLP + p] = ch[r][1];
+                }
+            }
             // ONE wave-uniform dispatch per item, then a branch-free unrolled loop: mode 0 plain, 1 fused transform, 2 split-form copy
-            auto body = [&](auto MODE) {
+            auto body = [&](auto MODE, auto R0) {
                 constexpr int mode = decltype(MODE)::value;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
+                for (int r = decltype(R0)::value; r < NR; ++r) {
                     const int p = r * 128 + pslot;
                     if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
                     const bool ok = (vmask >> r) & 1u;
@@ -661,9 +686,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     buf[(2 + hsel) * HVOLP + p] = lo;
                 }
             };
-            if (s16) body(std::integral_constant<int, 2>{});
-            else if (xform) body(std::integral_constant<int, 1>{});
-            else body(std::integral_constant<int, 0>{});
+            auto dispatch = [&](auto R0) __attribute__((always_inline)) {
+                if (s16) body(std::integral_constant<int, 2>{}, R0);
+                else if (xform) body(std::integral_constant<int, 1>{}, R0);
+                else body(std::integral_constant<int, 0>{}, R0);
+            };
+            if (st_chain) dispatch(std::integral_constant<int, CR>{});
+            else dispatch(std::integral_constant<int, 0>{});
         };
         if (nitems > 0) {
             issue(0);
