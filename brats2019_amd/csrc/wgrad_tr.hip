@@ -319,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             }
             __syncthreads();
         }
+        __syncthreads();                                // the consumers' accumulators are in LDS
     } else {
         f32x4 acc[27];
 #pragma unroll
@@ -343,17 +344,27 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             wtz_consume<OT>(lds, pw, dl, acc);
             __syncthreads();
         }
-        // ---- partials[part][tap][o][c], part = (workgroup, wave share): D lane = (rows o = 4*(l>>4) + r, column c = l&15)
-        constexpr int NW = OT == 1 ? 4 : 2;
-        const int part = blockIdx.x * NW + (OT == 1 ? rw : (rw >> 1));
-        const int o0 = og * OT * 16 + qw * 16, c0 = cgp * 16;
-        const int c = c0 + (lane & 15);
+        // ---- the waves that worked on the same output tile are summed through LDS (the staging memory is free now): ONE partial per
+        // workgroup instead of four / two -- a quarter / half of the partial traffic here and in the reduce kernel
+        f32x4* red = reinterpret_cast<f32x4*>(lds);      // [wave][tap][lane]
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
+        for (int t = 0; t < 27; ++t) red[(rw * 27 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+    }
+    // partials[workgroup][tap][o][c]; D lane = (rows o = 4*(l>>4) + r, column c = l&15); fixed summation order
+    {
+        const f32x4* red = reinterpret_cast<const f32x4*>(lds);
+        const int c0 = cgp * 16;
+        for (int e = tid; e < OT * 27 * 64; e += 512) {
+            const int q = e & 63, t = (e >> 6) % 27, ot = (e >> 6) / 27;
+            f32x4 v;
+            if constexpr (OT == 1) v = (red[(0 * 27 + t) * 64 + q] + red[(1 * 27 + t) * 64 + q]) + (red[(2 * 27 + t) * 64 + q] + red[(3 * 27 + t) * 64 + q]);
+            else v = red[(ot * 27 + t) * 64 + q] + red[((ot + 2) * 27 + t) * 64 + q];
+            const int c = c0 + (q & 15);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = o0 + (lane >> 4) * 4 + r;
-                if (o < CoP && c < CiP) partials[(((size_t)part * 27 + t) * CoP + o) * CiP + c] = acc[t][r];
+                const int o = og * OT * 16 + ot * 16 + (q >> 4) * 4 + r;
+                if (o < CoP && c < CiP) partials[(((size_t)blockIdx.x * 27 + t) * CoP + o) * CiP + c] = v[r];
             }
         }
     }
@@ -376,7 +387,7 @@ static WTRChoice wtr_choose(int N, int Cin, int Cout, int D, int H, int W) {
 size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
     if (Cin % 16 || Cout % 16) return 0;
     const WTRChoice c = wtr_choose(N, Cin, Cout, D, H, W);
-    return (size_t)c.nbx * (c.ot == 1 ? 4 : 2) * 27 * Cout * Cin * sizeof(float);       // one partial per (workgroup, wave share)
+    return (size_t)c.nbx * 27 * Cout * Cin * sizeof(float);       // one partial per workgroup
 }
 
 template <int OT, int XS, int DS>
@@ -395,7 +406,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
-    return wgrad_reduce_launch((const float*)a.ws, nbx * (OT == 1 ? 4 : 2), 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
+    return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
 }
 
 int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
