@@ -694,7 +694,7 @@ static W1Choice wgrad1_choose(int N, int Cin, int Cout, size_t V) {
     c.ncg = cdiv(CiP, 16 * c.ct);
     c.ngroups = cdiv(CoP, 16 * c.ot) * c.ncg;
     c.nchunk = (int)((V + W1_VC - 1) / W1_VC);
-    long nbx = 1024 / c.ngroups;
+    long nbx = 512 / c.ngroups;                    // two resident workgroups per CU: one round of blocks, half the partials of 1024
     if (nbx < 1) nbx = 1;
     const long ntot = (long)N * c.nchunk;
     if (nbx > ntot) nbx = ntot;
