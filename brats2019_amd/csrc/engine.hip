@@ -94,6 +94,7 @@ struct BlockP {           // parameter indices of one Residual (model.py:81-97)
 struct GNSave {
     float *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr;
     float act_slope = 0.01f;        // LeakyReLU slope that follows this GroupNorm (norm_input has none: 1)
+    float* k = nullptr;             // training, voxel-major flow: constants of the fused GroupNorm-backward statistics (Conv3Args::bst_k)
 };
 
 struct BlockSave {
@@ -336,8 +337,9 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16; a.in_c4 = x_c4;
     RU_RUN(conv3_launch(a, s));
+    out_gn.k = (h->training && h->c16) ? A.alloc((size_t)N * 3 * Cout) : nullptr;
     RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
-                              (size_t)D * H * W, kGroups, kEps, s));
+                              (size_t)D * H * W, kGroups, kEps, s, out_gn.k));
     h->gn_order.push_back(out_gn);
     return RU_OK;
 }
@@ -597,9 +599,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (fuse1) {
         nblk1 = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
         part1 = A.alloc((size_t)N * C * nblk1 * 2);
-        float* k1 = A.alloc((size_t)N * 3 * C);
-        RU_RUN(gn_bst_consts_launch(sv.g1.mean, sv.g1.rstd, P(h, params, bp.n1w), P(h, params, bp.n1b), k1, N, C, kGroups, s));
-        d2.bst_y = sv.y1; d2.bst_k = k1; d2.bst_slope = kSlope; d2.stat_partials = part1;
+        d2.bst_y = sv.y1; d2.bst_k = sv.g1.k; d2.bst_slope = kSlope; d2.stat_partials = part1;       // constants written by the forward finalize
     }
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
@@ -682,9 +682,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     if (head4 && hb && !no_bst && conv3_sb_bst_usable(N, C0, Dl[0], Hl[0], Wl[0])) {
         hnblk = conv3_sb_tiles_per_sample(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);
         hpart = A.alloc((size_t)N * C0 * hnblk * 2);
-        float* hk = A.alloc((size_t)N * 3 * C0);
-        RU_RUN(gn_bst_consts_launch(hb->g2.mean, hb->g2.rstd, P(h, params, hb->bp->n2w), P(h, params, hb->bp->n2b), hk, N, C0, kGroups, s));
-        dh.bst_y = hb->y2; dh.bst_k = hk; dh.bst_slope = kSlope; dh.stat_partials = hpart;
+        dh.bst_y = hb->y2; dh.bst_k = hb->g2.k; dh.bst_slope = kSlope; dh.stat_partials = hpart;
     }
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;

@@ -263,7 +263,8 @@ int gn_stats_launch(const float* x, float* partials, int N, int C, size_t V, hip
 // one workgroup per (n, g): float64 combine of the per-tile float32 (sum, sumsq) partials
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
-                                                          float* __restrict__ scale, float* __restrict__ shift, int C, size_t V, int G, float eps) {
+                                                          float* __restrict__ scale, float* __restrict__ shift, int C, size_t V, int G, float eps,
+                                                          float* __restrict__ bst_k) {
     __shared__ double buf[4][2];
     __shared__ float sh[2];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
@@ -294,12 +295,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         const float a = gamma[c] * sh[1];
         scale[n * C + c] = a;
         shift[n * C + c] = beta[c] - sh[0] * a;
+        if (bst_k) {                             // constants of the fused GroupNorm-backward statistics (Conv3Args::bst_k): u = y*k1 + k2 = sign(gamma)*xhat, mask <=> u > thr = -beta/|gamma|
+            const float gm = gamma[c], bt = beta[c], sg = gm < 0.f ? -1.f : 1.f;
+            float* kn = bst_k + (size_t)n * 3 * C;
+            kn[c] = sg * sh[1];
+            kn[C + c] = -sg * sh[0] * sh[1];
+            kn[2 * C + c] = gm == 0.f ? (bt > 0.f ? -INFINITY : INFINITY) : -bt / fabsf(gm);
+        }
     }
 }
 int gn_finalize_launch(const float* partials, int nblk, const float* gamma, const float* beta, float* mean, float* rstd,
-                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s) {
+                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s, float* bst_k) {
     RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, s, partials, nblk, gamma, beta, mean, rstd, scale, shift, C, V, G, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, s, partials, nblk, gamma, beta, mean, rstd, scale, shift, C, V, G, eps, bst_k);
     RU_CHECK_LAUNCH("gn_finalize_kernel");
     return RU_OK;
 }
@@ -398,7 +406,7 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
 // LPI lanes share one (sample, channel) item: 64 for long partial lists, 16 / 4 when a deep level has only a few partials per
 // item but many items (then a wave finishes 4 / 16 items per pass instead of one).
 template <int LPI>
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
+__global__ __launch_bounds__(512) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int C, size_t V, int G, int s2_sign) {
     extern __shared__ double S[];            // [N][cpg][2]
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int IPW = 64 / LPI;
     const int sub = lane / LPI, sl = lane % LPI;
-    for (int item0 = wave * IPW; item0 < N * cpg; item0 += 4 * IPW) {
+    const int nwave = blockDim.x >> 6;
+    for (int item0 = wave * IPW; item0 < N * cpg; item0 += nwave * IPW) {
         const int item = item0 + sub;
         const bool ok = item < N * cpg;
         const int it = ok ? item : 0;
@@ -415,6 +424,12 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
         const float2* p = reinterpret_cast<const float2*>(partials + ((size_t)n * C + g * cpg + j) * nblk * 2);
         double s1 = 0.0, s2 = 0.0;
         int i = sl;
+        for (; i + 7 * LPI < nblk; i += 8 * LPI) {        // eight loads in flight: the kernel is a latency chain
+            const float2 a = p[i], b = p[i + LPI], c = p[i + 2 * LPI], d = p[i + 3 * LPI];
+            const float2 e = p[i + 4 * LPI], f = p[i + 5 * LPI], g2 = p[i + 6 * LPI], h = p[i + 7 * LPI];
+            s1 += (((double)a.x + (double)b.x) + ((double)c.x + (double)d.x)) + (((double)e.x + (double)f.x) + ((double)g2.x + (double)h.x));
+            s2 += (((double)a.y + (double)b.y) + ((double)c.y + (double)d.y)) + (((double)e.y + (double)f.y) + ((double)g2.y + (double)h.y));
+        }
         for (; i + 3 * LPI < nblk; i += 4 * LPI) {
             const float2 a = p[i], b = p[i + LPI], c = p[i + 2 * LPI], d = p[i + 3 * LPI];
             s1 += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     }
     __syncthreads();
     const double m = (double)cpg * (double)V;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
         double m1 = 0.0, m2 = 0.0;
         for (int j = 0; j < cpg; ++j) {
             const double gm = (double)gamma[g * cpg + j];
@@ -445,7 +460,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
             q[2] = (float)(rs * rs * m2 * mu - rs * m1);
         }
     }
-    for (int j = threadIdx.x; j < cpg; j += 256) {
+    for (int j = threadIdx.x; j < cpg; j += blockDim.x) {
         double dg = 0.0, db = 0.0;
         for (int n = 0; n < N; ++n) { db += S[(n * cpg + j) * 2]; dg += S[(n * cpg + j) * 2 + 1]; }
         if (dgamma) dgamma[g * cpg + j] = (float)dg;
@@ -457,29 +472,10 @@ int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, 
     RU_REQUIRE(C % G == 0 && C / G <= 256, "groupnorm: C must be divisible by G (and C/G <= 256)");
     const size_t shm = (size_t)N * (C / G) * 2 * sizeof(double);
     RU_REQUIRE(shm <= 60000, "groupnorm backward: batch x channels-per-group too large for the finalize kernel");
-    if (nblk > 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
+    if (nblk > 32) hipLaunchKernelGGL(gn_bwd_finalize_kernel<64>, dim3(G), dim3(N * (C / G) > 4 ? 512 : 256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
     else if (nblk > 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
     else hipLaunchKernelGGL(gn_bwd_finalize_kernel<4>, dim3(G), dim3(256), shm, s, partials, nblk, gamma, mean, rstd, coef, dgamma, dbeta, N, C, V, G, s2_sign);
     RU_CHECK_LAUNCH("gn_bwd_finalize_kernel");
-    return RU_OK;
-}
-
-// constants of the fused GroupNorm-backward statistics (Conv3Args::bst_k): u = y*k1 + k2 = sign(gamma)*xhat, mask <=> u > thr
-__global__ void gn_bst_consts_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ k, int N, int C, int G) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C, g = c / (C / G);
-    const float gm = gamma[c], bt = beta[c], mu = mean[n * G + g], rs = rstd[n * G + g];
-    const float sg = gm < 0.f ? -1.f : 1.f;
-    float* kn = k + (size_t)n * 3 * C;
-    kn[c] = sg * rs;
-    kn[C + c] = -sg * mu * rs;
-    kn[2 * C + c] = gm == 0.f ? (bt > 0.f ? -INFINITY : INFINITY) : -bt / fabsf(gm);     // gamma*xhat + beta > 0  <=>  u > -beta/|gamma|
-}
-int gn_bst_consts_launch(const float* mean, const float* rstd, const float* gamma, const float* beta, float* k, int N, int C, int G, hipStream_t s) {
-    hipLaunchKernelGGL(gn_bst_consts_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, mean, rstd, gamma, beta, k, N, C, G);
-    RU_CHECK_LAUNCH("gn_bst_consts_kernel");
     return RU_OK;
 }
 

@@ -58,7 +58,7 @@ struct Conv3Args {
     // the gradient d w.r.t. the activation that followed a GroupNorm of `bst_y` (same shape as y).  The epilogue then writes, instead
     // of (sum, sumsq), the partial sums the GroupNorm backward needs -- S1 = sum dh, S2' = sum dh*u with u = y*k1 + k2 (= sign(gamma) *
     // xhat), dh = u > thr ? d : d*bst_slope -- to stat_partials, saving the separate reduce pass over (y, d).  bst_k: [N][3][Cout] =
-    // (k1, k2, thr) from gn_bst_consts_launch; gn_bwd_finalize_launch(..., s2_sign = 1) undoes the sign.
+    // (k1, k2, thr) written by gn_finalize_launch(..., bst_k); gn_bwd_finalize_launch(..., s2_sign = 1) undoes the sign.
     const float* bst_y;
     const float* bst_k;
     float bst_slope;
@@ -180,7 +180,7 @@ int gn_stats_tiles(size_t V);                                                   
 int gn_stats_launch(const float* x, float* partials, int N, int C, size_t V, hipStream_t s);   // [N][C][nblk][2]
 // partials -> mean,rstd [N][G]; scale,shift [N][C] (y = x*scale+shift)
 int gn_finalize_launch(const float* partials, int nblk, const float* gamma, const float* beta, float* mean, float* rstd,
-                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s);
+                       float* scale, float* shift, int N, int C, size_t V, int G, float eps, hipStream_t s, float* bst_k = nullptr);   // bst_k: optional [N][3][C] constants for Conv3Args::bst_k
 // y = (res ? res : 0) + lrelu(x*scale[n,c]+shift[n,c], slope)
 int gn_apply_launch(const float* x, const float* scale, const float* shift, const float* res, float* y,
                     int N, int C, size_t V, float slope, hipStream_t s);
@@ -191,8 +191,6 @@ int gn_bwd_reduce_launch(const float* x, const float* dy, const float* scale, co
 // partials -> coefficient triples coef[N][C][3] (dx = cA*dyh + cB*x + cC) and dgamma/dbeta (overwritten or accumulated)
 int gn_bwd_finalize_launch(const float* partials, int nblk, const float* gamma, const float* mean, const float* rstd,
                            float* coef, float* dgamma, float* dbeta, int N, int C, size_t V, int G, hipStream_t s, int s2_sign = 0);
-// k[N][3][C] = (k1, k2, thr) of Conv3Args::bst_k from the saved statistics and the affine parameters
-int gn_bst_consts_launch(const float* mean, const float* rstd, const float* gamma, const float* beta, float* k, int N, int C, int G, hipStream_t s);
 // the fused statistics need the persistent kernel: true when conv3_sb_launch will use it for this shape
 bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W);
 int gn_bwd_apply_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* coef,
