@@ -1095,8 +1095,19 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
         __syncthreads();                                // item 0 is staged
         for (int w = 0; w < nitems; ++w) {
             const u32x4* buf = lds + (w & 1) * BUF;
+            // output rows of this tile; the per-row operand of the epilogue (residual, or BST: the forward tensor) is requested now and
+            // lands under the MFMAs (it used to be loaded after them, with the stores waiting on it)
+            int n, z0, y0, x0;
+            tile_origin(w, n, z0, y0, x0);
+            const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
+            float4 radd[MT];
+            const float* src = BST ? a.bst_y : a.add;            // BST: the forward tensor of the GroupNorm this gradient enters (Conv3Args::bst_*)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MT; ++i) {
+                const int yy = y0 + my0 + i;
+                radd[i] = src ? *reinterpret_cast<const float4*>(src + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0))
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -1111,7 +1122,8 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
                 const int nofs = aoff[more ? ks + 1 : ks];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    acc[i] = mm(al[i], bh, acc[i]);
+                    if constexpr (ks == 0) acc[i] = mm(al[i], bh, f32x4{0.f, 0.f, 0.f, 0.f});      // starts from the zero operand
+                    else acc[i] = mm(al[i], bh, acc[i]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && i > 0) {
                         al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + HVOLP + (i - 1) * HX]);
@@ -1137,20 +1149,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
                     }
                 }
             });
-            int n, z0, y0, x0;
-            tile_origin(w, n, z0, y0, x0);
             if (n != n_acc) {
                 if (n_acc >= 0) flush_stats(n_acc);
                 n_acc = n;
-            }
-            const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
-            float4 radd[MT];
-            const float* src = BST ? a.bst_y : a.add;            // BST: the forward tensor of the GroupNorm this gradient enters (Conv3Args::bst_*)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int yy = y0 + my0 + i;
-                radd[i] = src ? *reinterpret_cast<const float4*>(src + ((out.ok && yy < H) ? sb_out_index<OUT16>(a, out, yy) : 0))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if constexpr (BST) {
                 f32x4 kc[3];
