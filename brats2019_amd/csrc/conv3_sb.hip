@@ -1093,12 +1093,26 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
         };
         f32x4 acc[MT];
         __syncthreads();                                // item 0 is staged
+        int cn, ctz, cty, ctx, gn, gz, gy, gx;           // (sample, tz, ty, tx) of the current tile and of the stride G
+        {
+            int b = swz;
+            cn = b / tiles_per_sample; b -= cn * tiles_per_sample;
+            ctx = b % ntx; b /= ntx;
+            cty = b % nty; ctz = b / nty;
+            b = G;
+            gx = b % ntx; b /= ntx;
+            gy = b % nty; b /= nty;
+            gz = b % ntz; gn = b / ntz;
+        }
         for (int w = 0; w < nitems; ++w) {
             const u32x4* buf = lds + (w & 1) * BUF;
             // output rows of this tile; the per-row operand of the epilogue (residual, or BST: the forward tensor) is requested now and
             // lands under the MFMAs (it used to be loaded after them, with the stores waiting on it)
-            int n, z0, y0, x0;
-            tile_origin(w, n, z0, y0, x0);
+            const int n = cn, z0 = ctz * TZ, y0 = cty * TY, x0 = ctx * 16;
+            ctx += gx; if (ctx >= ntx) { ctx -= ntx; ++cty; }      // digits of the next tile (+G): scalar adds with carries, no divisions
+            cty += gy; if (cty >= nty) { cty -= nty; ++ctz; }
+            ctz += gz; if (ctz >= ntz) { ctz -= ntz; ++cn; }
+            cn += gn;
             const SbOut out = sb_out_prepare<OUT16>(a, n, z0 + mz, x0, cog, lane);
             float4 radd[MT];
             const float* src = BST ? a.bst_y : a.add;            // BST: the forward tensor of the GroupNorm this gradient enters (Conv3Args::bst_*)
