@@ -257,6 +257,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # forward-only (BASELINE configs[1]: fp32 forward, batch 1)
         x1 = x[:1].contiguous()
+        backend.engine.freeze_params(True)       # inference legs: the weights no longer change, their packed copies are built once (as test.py would run)
         fwd = lambda: backend.forward(flat, x1, training=False)
         for _ in range(2):
             fwd()

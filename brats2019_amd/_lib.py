@@ -46,6 +46,7 @@ SIGNATURES = {
     "ru_unet_create": (_vp, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
     "ru_unet_destroy": (None, [_vp]),
     "ru_unet_set_precision": (_i, [_vp, _i]),
+    "ru_unet_freeze_params": (_i, [_vp, _i]),
     "ru_unet_get_precision": (_i, [_vp]),
     "ru_unet_param_count": (_i, [_vp]),
     "ru_unet_param_name": (C.c_char_p, [_vp, _i]),

@@ -139,6 +139,12 @@ struct ru_unet {
     float* pack = nullptr;
     const float* x_in = nullptr;
     const float* x_in4 = nullptr;   // 4-channel copy of the input made for the stem conv (C16 flow), reused by its weight gradient
+    // ru_unet_freeze_params: the weight packs at the head of the workspace are reused while (params, workspace, precision, layout) match
+    bool params_frozen = false;
+    const float* packed_params = nullptr;
+    const void* packed_base = nullptr;
+    int packed_prec = -1;
+    bool packed_c16 = false;
     float *y0 = nullptr, *t0 = nullptr, *probs = nullptr;
     GNSave g0;
     const float* head_in = nullptr;
@@ -267,6 +273,12 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
     return RU_OK;
 }
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
+extern "C" int ru_unet_freeze_params(ru_unet_t h, int frozen) {
+    RU_REQUIRE(h, "ru_unet_freeze_params: null handle");
+    h->params_frozen = frozen != 0;
+    h->packed_params = nullptr;                          // the next forward packs once, later ones reuse
+    return RU_OK;
+}
 extern "C" int ru_unet_param_count(ru_unet_t h) { return h ? (int)h->params.size() : 0; }
 extern "C" const char* ru_unet_param_name(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr; }
 extern "C" int ru_unet_param_ndim(ru_unet_t h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].ndim : 0; }
@@ -399,8 +411,14 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     for (int c : h->ch) h->c16 = h->c16 && (c % 16 == 0);
     h->pack = A.alloc(h->pk_total);
     h->fpack = reinterpret_cast<char*>(A.alloc(h->fk_total / sizeof(float) + 64));
-    int rc = pack_all(h, params, A, s);
-    if (rc) return rc;
+    float* wf4_in = A.alloc(conv3_sb4_frag_bytes(h->ch[0]) / sizeof(float) + 64);     // stem fragments: next to the packs, so they can be reused with them
+    const bool reuse_packs = h->params_frozen && !h->training && !A.dry && h->packed_params == params && h->packed_base == (const void*)h->pack &&
+                             h->packed_prec == h->precision && h->packed_c16 == h->c16;
+    int rc = RU_OK;
+    if (!reuse_packs) {
+        rc = pack_all(h, params, A, s);
+        if (rc) return rc;
+    }
 
     // stem: conv_input -> norm_input (no activation, model.py:412-413)
     const int C0 = h->ch[0];
@@ -410,10 +428,10 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
         // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
         float* x4 = A.alloc((size_t)N * 4 * Vl(0));
-        float* wf4 = A.alloc(conv3_sb4_frag_bytes(C0) / sizeof(float) + 64);
+        float* wf4 = wf4_in;
         h->x_in4 = x4;
         RU_RUN(pad_to_c4_launch(x, x4, N, kInCh, Vl(0), s));
-        RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_in), wf4, kInCh, C0, 0, s));
+        if (!reuse_packs) RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_in), wf4, kInCh, C0, 0, s));
         rc = conv3_gn(h, A, s, x4, nullptr, reinterpret_cast<const char*>(wf4), h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0,
                       N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, true);
     } else {
@@ -506,6 +524,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         hipError_t e = hipMemcpyAsync(probs_out, h->probs, (size_t)N * h->nout * Vl(0) * sizeof(float), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(probs)");
     }
+    if (!A.dry) { h->packed_params = h->training ? nullptr : params; h->packed_base = h->pack; h->packed_prec = h->precision; h->packed_c16 = h->c16; }   // a training forward is followed by an optimizer step
     return RU_OK;
 }
 

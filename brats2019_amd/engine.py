@@ -75,6 +75,15 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_precision(self.h, L.PRECISIONS[precision]), "ru_unet_set_precision")
         self.precision = precision
 
+    def freeze_params(self, frozen=True):
+        """Inference with constant weights: the packed weights in the workspace are built once and reused (ru_unet_freeze_params).
+        Leave off while training -- the optimizer rewrites the flat parameter buffer in place every step."""
+        frozen = bool(frozen)
+        if frozen and getattr(self, "_frozen", False):
+            return                                # already frozen: keep the cached packs
+        L.check(L.load().ru_unet_freeze_params(self.h, int(frozen)), "ru_unet_freeze_params")
+        self._frozen = frozen
+
     def _workspace(self, n, d, h, w, training, device):
         key = (n, d, h, w, bool(training), str(device), self.precision)      # the two precisions keep different scratch tensors
         if self._ws is None or self._ws_key != key:

@@ -72,6 +72,8 @@ def predict_tta(model, x, pad_left=(0, 0, 0), pad_right=(0, 0, 0), want_mean=Fal
     xt = torch.as_tensor(x, dtype=torch.float32).cuda()
     batch = torch.stack([torch.flip(xt, dims=list(ax)) if ax else xt for ax in TTA_FLIPS], dim=0).contiguous()
     model.eval()
+    if hasattr(model, "freeze_params"):
+        model.freeze_params(True)                       # constant weights: packed once, reused by every later forward (dropped by .train() / load_state_dict)
     with torch.no_grad():
         probs = model([batch])[0]                       # [4,3,D,H,W]
     mask, counts, mean = ops.tta_merge(probs, TTA_FLIPS, want_mean=want_mean)

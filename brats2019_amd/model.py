@@ -239,6 +239,26 @@ class UNet(nn.Module):
             eng.set_precision(precision)
         return self
 
+    def freeze_params(self, frozen=True):
+        """Inference with constant weights (test.py): the executor builds its packed weights once and reuses them until the flag is
+        cleared or the weights move.  Call again after load_state_dict / an optimizer step -- every call drops the cached packs."""
+        self._get_engine().freeze_params(frozen)
+        return self
+
+    def _unfreeze(self):
+        eng = self.__dict__.get("_engine_obj")
+        if eng is not None and getattr(eng, "_frozen", False):
+            eng.freeze_params(False)
+
+    def train(self, mode=True):                                   # weights are about to change: never reuse packed copies
+        if mode:
+            self._unfreeze()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):                   # writes through the aliased flat buffer in place
+        self._unfreeze()
+        return super().load_state_dict(*args, **kwargs)
+
     def _param_order(self):
         self._get_engine()
         return self.__dict__["_param_names"]

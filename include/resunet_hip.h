@@ -138,6 +138,11 @@ void ru_unet_destroy(ru_unet_t h);
 /* RU_PREC_* used by the 3x3x3 convolutions (forward, data gradient, weight gradient) of subsequent forward/backward calls;
  * default RU_PREC_F32.  Change it only between steps (not between a forward and its backward).  */
 int ru_unet_set_precision(ru_unet_t h, int precision);
+/* Inference with constant weights: frozen != 0 promises that the values behind `params` and the workspace `ws` are not modified between
+ * ru_unet_forward calls; the weight packs the forward builds at the head of `ws` are then built once and reused while the same
+ * (params pointer, ws pointer, precision) come back (they are rebuilt otherwise).  Training must leave it off (0, the default): the
+ * reference's optimizer changes the weights every step (train.py:220).  */
+int ru_unet_freeze_params(ru_unet_t h, int frozen);
 int ru_unet_get_precision(ru_unet_t h);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */

@@ -307,3 +307,33 @@ def test_full_size_batch4_equals_per_sample_runs():
     print("worst relative L2 difference batch vs sum of singles: %.2e (%s)" % worst)
     for k in gb:
         assert float((gb[k] - gsum[k]).norm()) < 2e-2 * float(gsum[k].norm()) + 1e-12, k
+
+
+def test_frozen_params_reuse_packs_bit_identical_and_drop_them_on_weight_change():
+    """ru_unet_freeze_params (inference with constant weights): forwards that reuse the packed weights give the bits of a forward
+    that packs them, and load_state_dict / train() drop the cached packs so that changed weights are never served stale."""
+    from brats2019_amd import model as M
+    torch.manual_seed(2)
+    net = M.UNet(4, [1, 2, 2, 4], [1, 1, 1, 1], [16, 32, 64, 128], 3).cuda()
+    net.set_precision("bf16x3")
+    net.eval()
+    x = torch.randn(1, 4, 32, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        p0 = net([x])[0].clone()
+        net.freeze_params(True)
+        p1 = net([x])[0].clone()                 # packs once
+        p2 = net([x])[0].clone()                 # reuses
+        assert torch.equal(p0, p1) and torch.equal(p1, p2)
+        net.load_state_dict({k: v * 1.01 for k, v in net.state_dict().items()})      # in place, same flat buffer: must unfreeze
+        p3 = net([x])[0].clone()
+        assert not torch.equal(p3, p2)
+        net.freeze_params(True)
+        p4 = net([x])[0].clone()
+        p5 = net([x])[0].clone()
+        assert torch.equal(p3, p4) and torch.equal(p4, p5)
+        net.train()                              # drops the freeze again
+        net.eval()
+        for q in net.parameters():
+            q.mul_(0.99)
+        p6 = net([x])[0].clone()
+        assert not torch.equal(p6, p5)
