@@ -532,7 +532,8 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
 // GroupNorm(+LeakyReLU) backward: d_act -> dy (gradient w.r.t. the raw conv output), dgamma/dbeta written
 // fused_part / fused_nblk: the partial sums were already taken by the conv that produced `dact` (Conv3Args::bst_*): no reduce pass
 static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
-                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const float* fused_part = nullptr, int fused_nblk = 0) {
+                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const float* fused_part = nullptr, int fused_nblk = 0,
+                  float** coef_out = nullptr /* non-null: stop after the finalize; the apply is fused into the weight gradient (Wgrad3Args::gb_*) */) {
     const bool fused = fused_nblk > 0;
     const int nblk = fused ? fused_nblk : (c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V));
     float* part = fused ? const_cast<float*>(fused_part) : A.alloc((size_t)N * C * nblk * 2);
@@ -542,13 +543,16 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
         else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
     }
     RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s, fused ? 1 : 0));
+    if (coef_out) { *coef_out = coef; return RU_OK; }
     if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, 1, s));   // split form: read by MFMA kernels only
     else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
     return RU_OK;
 }
 
+// GroupNorm-backward apply fused into the weight gradient's dy staging (Wgrad3Args::gb_*): dy is OUTPUT (split form) then
+struct GbApply { const float* y; const float* d; const GNSave* g; const float* coef; };
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
-                      bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr, bool dy_s16 = false) {
+                      bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr, bool dy_s16 = false, const GbApply* gb = nullptr) {
     if (x_c16 != dy_c16 && mode == RU_PREC_BF16X3 && Cin <= 16 && Cout <= 16) {
         // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side enters the transpose-read kernel as a
         // 16-channel block that is zero beyond its real channels -- from the 4-channel copy the conv of that tensor already made
@@ -576,6 +580,10 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
     w.N = N; w.Cin = Cin; w.Cout = Cout; w.D = D; w.H = H; w.W = W;
+    if (gb) {
+        w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = kSlope;
+        w.gb_out = const_cast<float*>(dy); w.dy_s16 = 0;
+    }
     RU_RUN(wgrad3_launch(w, s));
     return RU_OK;
 }
@@ -602,9 +610,16 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const size_t V = (size_t)D * H * W;
     float* dy2 = A.alloc((size_t)N * C * V);
     const bool c16 = h->c16;
-    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2);
+    // 16-channel level (its kernels are memory-bound): the GroupNorm-backward apply is computed by the weight gradient's dy staging
+    // from (y, d, coefficients) and published in split form for the data-gradient conv that follows -- no apply pass over (y, d)
+    static const bool no_gba = getenv("RU_NO_GBA") != nullptr;      // A/B switch
+    const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && !no_gba;
+    float *coef2 = nullptr, *coef1 = nullptr;
+    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2,
+                    fa ? &coef2 : nullptr);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16);
+    const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
+    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
@@ -622,9 +637,11 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     }
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
-    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, part1, nblk1);
+    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, part1, nblk1,
+                fa ? &coef1 : nullptr);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16);
+    const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
+    rc = wgrad3_run(A, s, h->precision, sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};

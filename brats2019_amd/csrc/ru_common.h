@@ -106,6 +106,18 @@ struct Wgrad3Args {
     int dw_cin, dw_cout;     // wgrad_tr only: real channel counts of dw when x / dy are zero-padded to 16 channels (0 = Cin / Cout)
     int dy_s16;              // wgrad_tr only: dy is C16 in split form: its staging is a plain copy
     int x_c4, dy_c4;         // wgrad_tr only: that operand is a [N][D][H][W][4] copy (pad_to_c4) standing for a 16-channel block whose channels 4..15 are zero
+    // wgrad_tr only, Cout == 16: the dy operand is the GroupNorm-backward APPLY computed on the fly (`dy` is ignored):
+    //     dy = cA * ((y*scale + shift) > 0 ? d : d*slope) + (cB*y + cC)
+    // from the forward tensor gb_y, the gradient w.r.t. the activation gb_d (both voxel-major fp32), the GroupNorm's (scale, shift)
+    // [N][Cout], the finalize coefficients gb_coef [N][Cout][3] and gb_slope -- the arithmetic of gn_bwd_apply16_launch -- and the
+    // kernel also writes it to gb_out in split form for the data-gradient conv: no separate apply pass over (y, d).
+    const float* gb_y;
+    const float* gb_d;
+    const float* gb_scale;
+    const float* gb_shift;
+    const float* gb_coef;
+    float gb_slope;
+    float* gb_out;
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);

@@ -179,6 +179,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         constexpr int NRX = (4 * PPOS + 127) / 128, NR2 = (2 * PPOS + 127) / 128, NRD = OT * ((DPOS + 127) / 128);     // first step of a column: 4 planes
         const int hsel = ptid & 1, pslot = ptid >> 1;
         float4 vx[NRX][2], vd[NRD][2];
+        float4 vg[DS == 3 ? NRD : 1][2], gc4[DS == 3 ? 10 : 1];       // DS == 3: the gradient stream and (scale, shift, coefficients) of this thread's 8 channels
+        int st_n = 0, st_y0 = 0, st_x0 = 0;
         float4 sc4[2], sh4[2];
         unsigned mx = 0, md = 0;
         int st_ring0 = 0, st_k = 0;                      // of the item whose loads are in the registers
@@ -226,7 +228,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = p < DPOS && gz < D && gy < H && gx < W;
                 const float* db = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + hsel * 8;
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                if constexpr (DS == 1) {                 // split form in HBM: hi and lo packets of this half, copied as they are
+                if constexpr (DS == 3) {                 // GroupNorm-backward apply on the fly: forward tensor y and gradient d
+                    md |= ok ? (1u << r) : 0u;
+                    const size_t cb = ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 8;
+                    vd[r][0] = *reinterpret_cast<const float4*>(a.gb_y + cb);
+                    vd[r][1] = *reinterpret_cast<const float4*>(a.gb_y + cb + 4);
+                    vg[r][0] = *reinterpret_cast<const float4*>(a.gb_d + cb);
+                    vg[r][1] = *reinterpret_cast<const float4*>(a.gb_d + cb + 4);
+                } else if constexpr (DS == 1) {                 // split form in HBM: hi and lo packets of this half, copied as they are
                     md |= ok ? (1u << r) : 0u;
                     const float* ds = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 4;
                     vd[r][0] = *reinterpret_cast<const float4*>(ds);
@@ -245,6 +254,14 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const int cofs = n * a.Cin + cgp * 16 + hsel * 8;
                 sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
                 sh4[0] = *reinterpret_cast<const float4*>(a.in_shift + cofs); sh4[1] = *reinterpret_cast<const float4*>(a.in_shift + cofs + 4);
+            }
+            if constexpr (DS == 3) {                     // OT == 1: one output block
+                const size_t go = (size_t)n * a.Cout + og * 16 + hsel * 8;
+                gc4[0] = *reinterpret_cast<const float4*>(a.gb_scale + go); gc4[1] = *reinterpret_cast<const float4*>(a.gb_scale + go + 4);
+                gc4[2] = *reinterpret_cast<const float4*>(a.gb_shift + go); gc4[3] = *reinterpret_cast<const float4*>(a.gb_shift + go + 4);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) gc4[4 + t] = *reinterpret_cast<const float4*>(a.gb_coef + go * 3 + 4 * t);
+                st_n = n; st_y0 = y0; st_x0 = x0;
             }
         };
         auto store = [&](char* dbuf) {
@@ -292,8 +309,21 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const bool ok = (md >> r) & 1u;
                 const float f[8] = {vd[r][0].x, vd[r][0].y, vd[r][0].z, vd[r][0].w, vd[r][1].x, vd[r][1].y, vd[r][1].z, vd[r][1].w};
                 float t[8];
+                if constexpr (DS == 3) {                 // the expression of gn_bwd_apply16_split_kernel, term for term
+                    const float g[8] = {vg[r][0].x, vg[r][0].y, vg[r][0].z, vg[r][0].w, vg[r][1].x, vg[r][1].y, vg[r][1].z, vg[r][1].w};
+                    const float ga[8] = {gc4[0].x, gc4[0].y, gc4[0].z, gc4[0].w, gc4[1].x, gc4[1].y, gc4[1].z, gc4[1].w};
+                    const float gb[8] = {gc4[2].x, gc4[2].y, gc4[2].z, gc4[2].w, gc4[3].x, gc4[3].y, gc4[3].z, gc4[3].w};
+                    const float cf[24] = {gc4[4].x, gc4[4].y, gc4[4].z, gc4[4].w, gc4[5].x, gc4[5].y, gc4[5].z, gc4[5].w, gc4[6].x, gc4[6].y, gc4[6].z, gc4[6].w,
+                                          gc4[7].x, gc4[7].y, gc4[7].z, gc4[7].w, gc4[8].x, gc4[8].y, gc4[8].z, gc4[8].w, gc4[9].x, gc4[9].y, gc4[9].z, gc4[9].w};
 #pragma unroll
-                for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
+                    for (int c = 0; c < 8; ++c) {
+                        const float dyv = cf[3 * c] * ((f[c] * ga[c] + gb[c]) > 0.f ? g[c] : g[c] * a.gb_slope) + (cf[3 * c + 1] * f[c] + cf[3 * c + 2]);
+                        t[c] = ok ? dyv : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
+                }
                 u32x4 hi, lo;
                 if constexpr (DS == 1) {
                     const u32x4 z = u32x4{0u, 0u, 0u, 0u};
@@ -304,6 +334,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 }
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + p * 32 + hsel * 16) = hi;
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
+                if constexpr (DS == 3) {                 // publish dy in split form (every position is staged once by input-channel group 0)
+                    if (ok && cgp == 0) {
+                        const int row = p >> 4, z = row / TY;
+                        const size_t vox = (size_t)((2 * st_k + z) * H + st_y0 + (row - z * TY)) * W + st_x0 + (p & 15);
+                        u32x4* op = reinterpret_cast<u32x4*>(a.gb_out) + ((size_t)(st_n * CBo + og * OT + q) * DHW + vox) * 4;
+                        op[hsel] = hi;
+                        op[2 + hsel] = lo;
+                    }
+                }
             }
         };
         if (nitems > 0) {
@@ -415,6 +454,11 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
     if (!a.ws || a.ws_bytes < wgrad3_tr_workspace_bytes(a.N, a.Cin, a.Cout, a.D, a.H, a.W)) {
         set_error("wgrad3_tr: workspace too small");
         return RU_ENOMEM;
+    }
+    if (a.gb_y) {
+        RU_REQUIRE(c.ot == 1 && !a.x_c4 && !a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && a.gb_out,
+                   "wgrad3_tr: the fused GroupNorm-backward apply needs Cout == 16, voxel-major x and all of its operands");
+        return wtz_cfg<1, 0, 3>(a, c, s);
     }
     const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
     if (c.ot == 2) {
