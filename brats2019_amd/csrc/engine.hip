@@ -613,7 +613,8 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     // 16-channel level (its kernels are memory-bound): the GroupNorm-backward apply is computed by the weight gradient's dy staging
     // from (y, d, coefficients) and published in split form for the data-gradient conv that follows -- no apply pass over (y, d)
     static const bool no_gba = getenv("RU_NO_GBA") != nullptr;      // A/B switch
-    const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && !no_gba;
+    static const bool gba_all = getenv("RU_GBA_ALL") != nullptr;    // experiment: every level
+    const bool fa = c16 && h->precision == RU_PREC_BF16X3 && (C == 16 || gba_all) && !no_gba;
     float *coef2 = nullptr, *coef1 = nullptr;
     int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2,
                     fa ? &coef2 : nullptr);

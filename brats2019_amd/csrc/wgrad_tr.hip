@@ -456,9 +456,16 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         return RU_ENOMEM;
     }
     if (a.gb_y) {
-        RU_REQUIRE(c.ot == 1 && !a.x_c4 && !a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && a.gb_out,
-                   "wgrad3_tr: the fused GroupNorm-backward apply needs Cout == 16, voxel-major x and all of its operands");
-        return wtz_cfg<1, 0, 3>(a, c, s);
+        RU_REQUIRE(!a.x_c4 && !a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && a.gb_out,
+                   "wgrad3_tr: the fused GroupNorm-backward apply needs voxel-major x and all of its operands");
+        WTRChoice c1 = c;                                // one output block per workgroup: the second block's constants and streams do not fit the registers
+        c1.ot = 1;
+        c1.ngroups = (a.Cout / 16) * c1.ncg;
+        long nbx = 256 / c1.ngroups;
+        if (nbx < 1) nbx = 1;
+        if (nbx > c.nbx) nbx = c.nbx;                    // the workspace was sized for c.nbx partials
+        c1.nbx = (int)nbx;
+        return wtz_cfg<1, 0, 3>(a, c1, s);
     }
     const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
     if (c.ot == 2) {
