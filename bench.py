@@ -13,8 +13,11 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  algorithmic bytes / average launch time vs the HBM peak (split-bf16: the memory side limits, see the comment in
                  roofline_probe), algorithmic FLOPs vs the f32 MFMA peak (f32); `traffic` = HBM bytes from the PMC passes
                  committed under profiles/,
-  cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample,
-  fwd          : forward-only volumes/s at batch 1 (BASELINE configs[1]).
+                 `whole_step_frac` = the per-layer roofline of the whole step (sum over the convolutions of max(executed FLOPs / MFMA
+                 peak, fp32 in+out bytes / HBM peak)) divided by the measured step time,
+  cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
+  fwd          : forward-only volumes/s at batch 1 in the precision of the run,
+  fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1).
 """
 import argparse
 import json
@@ -33,6 +36,37 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table: v_mfma_f32_1
 CPU_BASELINE_THREADS = 16         # tools/cpu_threads_probe.py on the MI355X host: 8-16 threads are fastest (256 hw threads: 20x slower)
 FWD_GFLOP_PER_VOL = 299.37        # algorithmic conv FLOPs per 128^3 volume, forward
 FWDBWD_GFLOP_PER_VOL = 890.87     # forward + backward
+
+
+def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False):
+    """Per-layer roofline of one step (SURVEY 8(d) / BASELINE.md section 4): sum over the convolutions of
+    max(executed FLOPs / MFMA peak, compulsory fp32 bytes / HBM peak), forward + data gradient + weight gradient.  3x3x3 convs:
+    split-bf16 executes 3 products per algorithmic one at the dense bf16 peak (f32 mode: exact-f32 MFMA peak); 1x1 / 2x2x2 convs run
+    on the f32 MFMA in both modes.  Bytes = input + output tensor (weight gradient: x + dy), fp32 -- the fused lower bound where
+    GroupNorm / LeakyReLU / residual / up-sampling ride on the convolutions' traffic."""
+    ch, enc = [16, 32, 64, 128], [1, 2, 2, 4]
+    peak3 = (BF16_MFMA_PEAK_TFLOPS / 3.0 if precision == "bf16x3" else F32_MFMA_PEAK_TFLOPS) * 1e12     # algorithmic FLOP/s of a 3^3 conv
+    peak1 = F32_MFMA_PEAK_TFLOPS * 1e12
+    bw = HBM_PEAK_GBPS * 1e9
+    v = [float(batch) * (size >> i) ** 3 for i in range(4)]
+    layers = []                                   # (taps, cin, cout, voxels_out, voxels_in, peak, has_dgrad)
+    layers.append((27, 4, ch[0], v[0], v[0], peak3, False))                      # conv_input: no data gradient (train.py: input has no grad)
+    layers += [(27, ch[0], ch[0], v[0], v[0], peak3, True)] * (2 * enc[0])       # conv_first
+    for i in range(3):
+        layers.append((8, ch[i], ch[i + 1], v[i + 1], v[i], peak1, True))        # 2^3 stride-2
+        layers += [(27, ch[i + 1], ch[i + 1], v[i + 1], v[i + 1], peak3, True)] * (2 * enc[i + 1])
+    for i in (2, 1, 0):
+        layers.append((1, ch[i + 1], ch[i], v[i], v[i], peak1, True))            # upsampling[i][1] (reference: at the fine resolution)
+        layers.append((1, 2 * ch[i], ch[i], v[i], v[i], peak1, True))            # decoder_convs1x1[i]
+        layers += [(27, ch[i], ch[i], v[i], v[i], peak3, True)] * 2              # decoder Residual
+    layers.append((27, ch[0], 3, v[0], v[0], peak3, True))                       # conv_output
+    t = 0.0
+    for taps, cin, cout, vo, vi, peak, dgrad in layers:
+        flops = 2.0 * taps * cin * cout * vo
+        byts = 4.0 * (cin * vi + cout * vo)
+        one = max(flops / peak, byts / bw)
+        t += one * (1 if forward_only else (3 if dgrad else 2))
+    return t * 1e3
 
 
 def synth(n, size, seed, device):
@@ -115,11 +149,12 @@ def roofline_probe(batch, size, precision, launches=20):
     ms = e0.elapsed_time(e1) / launches          # includes the ~2 us weight-pack kernel that precedes each conv launch
     flops = 2.0 * 27 * 16 * 16 * batch * size ** 3
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, "profiles", "pmc_conv3_l0.json")
     if os.path.exists(prof):
         try:
             traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/pmc_conv3_l0.json (rocprofv3 --pmc passes of this kernel at this shape, committed; not measured in this run)"
         except Exception:
             traffic = None
     abytes = 2 * 16 * batch * size ** 3 * 4
@@ -132,14 +167,14 @@ def roofline_probe(batch, size, precision, launches=20):
         # view is kept beside it (algorithmic flops, so <= 1/3.11 of the peak by construction, and the executed fraction).
         return {"bound": "hbm", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
                 "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(abytes),
+                "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(abytes),
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_algorithmic_tflops": round(achieved, 2),
                 "mfma_algorithmic_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                 "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
                 "executed_mfma_frac": round(achieved * 3 * 28 / 27 / BF16_MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "mfma", "kernel": "conv3_f32_kernel<4,8,8,1> (3x3x3 conv 16->16, %d x %d^3)" % (batch, size),
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+            "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
             "algorithmic_bytes_per_launch": int(abytes), "hbm_algorithmic_gbps": round(gbps, 1)}
 
 
@@ -179,19 +214,28 @@ def cpu_baseline(size, threads=0):
     params = O.make_params(1337, **O.DEFAULT_CFG)
     x, g = O.make_input(1, size, size, size), O.make_target(1, size, size, size)
     O.forward_backward(params, x, g, **O.DEFAULT_CFG)                   # warm-up (cold call is several x slower)
-    t0 = time.perf_counter()
-    O.forward_backward(params, x, g, **O.DEFAULT_CFG)
-    dt = time.perf_counter() - t0
+    reps = 3
+    dts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.forward_backward(params, x, g, **O.DEFAULT_CFG)
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
     p = O.to_torch(params)
+    dtfs = []
     with torch.no_grad():
         xt = torch.from_numpy(x)
         O.unet_forward(p, xt, **O.DEFAULT_CFG)
-        t1 = time.perf_counter()
-        O.unet_forward(p, xt, **O.DEFAULT_CFG)
-        dtf = time.perf_counter() - t1
-    return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": "1 timed fwd+loss+bwd step of one %d^3 x4ch volume (batch 1, fp32, torch CPU %s) after 1 warm-up step" % (size, torch.__version__),
-            "fwd_only_value": round(1.0 / dtf, 4)}
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            O.unet_forward(p, xt, **O.DEFAULT_CFG)
+            dtfs.append(time.perf_counter() - t1)
+    dtf = float(np.median(dtfs))
+    return {"value": round(1.0 / dt, 4), "unit": "volumes/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "median of %d timed fwd+loss+bwd steps of one %d^3 x4ch volume (batch 1, fp32, torch CPU %s) after 1 warm-up step; "
+                      "%d torch threads of %d host CPUs (tools/cpu_threads_probe.py: more threads are slower on this host)"
+                      % (reps, size, torch.__version__, cores, os.cpu_count() or 0),
+            "fwd_only_value": round(1.0 / dtf, 4), "step_s": [round(v, 3) for v in dts]}
 
 
 def main():
@@ -254,8 +298,11 @@ def main():
         "final_loss": round(loss, 6),
         "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
     }
+    roof_ms = step_roofline_ms(args.batch, args.size, args.precision)
+    out["whole_step_roofline_ms"] = round(roof_ms, 3)
+    out["whole_step_frac"] = round(roof_ms / (1e3 * dt / args.steps), 4)
     if rank == 0 and world == 1 and not args.no_extras:
-        # forward-only (BASELINE configs[1]: fp32 forward, batch 1)
+        # forward-only, batch 1, in the precision of the run
         x1 = x[:1].contiguous()
         backend.engine.freeze_params(True)       # inference legs: the weights no longer change, their packed copies are built once (as test.py would run)
         fwd = lambda: backend.forward(flat, x1, training=False)
@@ -263,9 +310,23 @@ def main():
             fwd()
         it = max(5, args.steps)
         dtf = time_region(fwd, it, False)
-        out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3),
-                      "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2)}
+        out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3), "precision": args.precision,
+                      "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
+                      "roofline_frac": round(step_roofline_ms(1, args.size, args.precision, forward_only=True) / (1e3 * dtf / it), 4)}
+        if args.precision != "f32":
+            # BASELINE configs[1]: fp32 forward, batch 1 -- exact-f32 MFMA arithmetic, its own engine and workspace
+            be32 = P.HipBackend(device=dev, precision="f32")
+            be32.engine.freeze_params(True)
+            fwd32 = lambda: be32.forward(flat, x1, training=False)
+            for _ in range(2):
+                fwd32()
+            dt32 = time_region(fwd32, it, False)
+            out["fwd_f32"] = {"value": round(it / dt32, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dt32 / it, 3), "precision": "f32",
+                              "algorithmic_tflops": round(it / dt32 * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
+                              "roofline_frac": round(step_roofline_ms(1, args.size, "f32", forward_only=True) / (1e3 * dt32 / it), 4)}
+            del be32
         out["roofline"] = roofline_probe(args.batch, args.size, args.precision)
+        out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
         if args.size == 128:
             out["sliding_window"] = sliding_window_probe(backend, flat, args.precision)
         if not args.no_cpu_baseline:

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RU_LIB_PATH") or os.path.join(_PKG, "lib", "libresune
 
 _lib = None
 PRECISIONS = {"f32": 0, "bf16x3": 1}      # RU_PREC_F32 / RU_PREC_BF16X3
+FUSE_GN_BWD_STATS, FUSE_GN_BWD_APPLY = 1, 2   # RU_FUSE_*
 
 _vp, _f, _d, _i, _sz = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_size_t
 
@@ -42,12 +43,14 @@ SIGNATURES = {
     "ru_criterion_sums": (_i, [_vp, _vp, _vp, _i, _i, _sz, _f, _vp, _sz, _vp]),
     "ru_criterion_grad": (_i, [_vp, _vp, _vp, _d, _f, _f, _f, _f, _vp, _i, _i, _sz, _vp]),
     "ru_criterion_value": (_i, [C.POINTER(_d), _i, _d, _d, C.POINTER(_d), C.POINTER(_d)]),
+    "ru_criterion_value_device": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp]),
     "ru_adam_amsgrad_step": (_i, [_vp] * 5 + [_sz] + [_f] * 5 + [_i, _vp]),
     "ru_unet_create": (_vp, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
     "ru_unet_destroy": (None, [_vp]),
     "ru_unet_set_precision": (_i, [_vp, _i]),
     "ru_unet_freeze_params": (_i, [_vp, _i]),
     "ru_unet_get_precision": (_i, [_vp]),
+    "ru_unet_set_fusion": (_i, [_vp, C.c_uint]),
     "ru_unet_param_count": (_i, [_vp]),
     "ru_unet_param_name": (C.c_char_p, [_vp, _i]),
     "ru_unet_param_ndim": (_i, [_vp, _i]),

@@ -1,4 +1,7 @@
-"""Build libresunet_hip.so (gfx950) in-tree with hipcc.  `python -m brats2019_amd.build [--force]`.
+"""Build libresunet_hip.so (gfx950) in-tree with hipcc.  `python -m brats2019_amd.build [--force] [--devtools]`.
+
+`--devtools` builds a SECOND library, lib/libresunet_hip_dev.so, with -DRU_DEVTOOLS: the ablation / section-counter switches of
+tools/*.sh (RU_SB2_DEBUG, ru_dbg_sb2_prof) exist only there; select it with RU_LIB_PATH.  The product library has none of them.
 
 One `hipcc -c` per translation unit (run in parallel), then one link.  The shared library lands in
 brats2019_amd/lib/ (git-ignored, but it travels to the GPU box with the gpurun snapshot).  Objects are
@@ -36,37 +39,38 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+def _compile(src, force, devtools=False):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + (".dev.o" if devtools else ".o"))
     path = os.path.join(CSRC, src)
     if not force and not _stale(obj, [path] + HEADERS):
         return obj, ""
-    cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + (["-DRU_DEVTOOLS"] if devtools else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     return obj, r.stderr
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, devtools=False):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    lib = os.path.join(LIBDIR, "libresunet_hip_dev.so") if devtools else LIB
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, devtools), srcs))
     objs = [o for o, _ in results]
     for _, warn in results:
         if warn.strip() and verbose:
             sys.stderr.write(warn)
-    if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024))
-    return LIB
+        print("built %s (%d KB)" % (lib, os.path.getsize(lib) // 1024))
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)

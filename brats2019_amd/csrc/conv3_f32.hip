@@ -227,13 +227,13 @@ size_t conv3_packed_floats(int Cin_conv, int Cout_conv) {
 template <int TZ, int TY, int KC, int NT>
 static int launch_cfg(const Conv3Args& a, hipStream_t s) {
     using P = C3<TZ, TY, KC, NT>;
-    static bool attr_done = false;
+    static PerDevice attr_done;
     const size_t lds = (size_t)P::LDS_FLOATS * sizeof(float);
-    if (!attr_done) {
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f32_kernel<TZ, TY, KC, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3)");
-        attr_done = true;
+        attr_done.set();
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.CoutP, NT * 16));

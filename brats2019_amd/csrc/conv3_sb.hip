@@ -409,9 +409,17 @@ __device__ unsigned long long sb2_prof[8];
 // the first (that exposed L2 latency was ~20 % of the kernel at 32..128 channels).
 // BST: fused GroupNorm-backward statistics in the epilogue (Conv3Args::bst_*), C16 output only.
 template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST>
-__global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg) {
+__global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg_arg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
-    // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue
+    // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue.
+    // Only a -DRU_DEVTOOLS build (python -m brats2019_amd.build --devtools -> lib/libresunet_hip_dev.so, for tools/) reads it; the
+    // product library compiles every switch out.
+#ifdef RU_DEVTOOLS
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     using P = SB<TZ, TY>;
     constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NROW = P::NROW;
     constexpr int BUF = 4 * HVOLP;                      // packets per LDS buffer
@@ -1308,14 +1316,15 @@ static SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
 // v2 (persistent producer/consumer) handles the large-tile case
 static bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
 
-static int sb_ncu() {
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+static int sb_ncu() {                                  // CUs of the CURRENT device (cached per device id)
+    static int ncu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (ncu[dev] == 0) {
+        int v = 0;
+        ncu[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return ncu;
+    return ncu[dev];
 }
 // workgroups along x of the persistent kernel: one resident workgroup per CU in total
 static long sb2_grid_x(int N, int Cout, int D, int H, int W) {
@@ -1334,7 +1343,8 @@ int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
 }
 
-// tools only (not in include/resunet_hip.h): read and clear the RU_SB2_DEBUG=64 section counters
+#ifdef RU_DEVTOOLS
+// tools only (not in include/resunet_hip.h, -DRU_DEVTOOLS builds): read and clear the RU_SB2_DEBUG=64 section counters
 extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(sb2_prof), 8 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol(sb2_prof)");
@@ -1342,23 +1352,28 @@ extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
     e = hipMemcpyToSymbol(HIP_SYMBOL(sb2_prof), z, sizeof(z));
     return e == hipSuccess ? RU_OK : hip_fail(e, "hipMemcpyToSymbol(sb2_prof)");
 }
+#endif
 
 template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false>
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
-    static bool attr_done = false;
+    static PerDevice attr_done;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
-    if (!attr_done) {
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
-        attr_done = true;
+        attr_done.set();
     }
     static_assert(TZ == 4 && TY == 8, "sb2_grid_x assumes the (4,8,16) tile");
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2: at most 32 samples per call when statistics are requested");
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
+#ifdef RU_DEVTOOLS
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
+#else
+    constexpr int dbg = 0;
+#endif
     hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
@@ -1375,11 +1390,11 @@ bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W) { return sb_use_v
 template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDevice attr_done;
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb)");
-        attr_done = true;
+        attr_done.set();
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.Cout, 16));
@@ -1395,12 +1410,12 @@ bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W) {
 template <bool OUT16, bool BST = false>
 static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<4, 8>;
-    static bool attr_done = false;
+    static PerDevice attr_done;
     constexpr int LDS = 2 * 2 * P::HVOLP * 16;
-    if (!attr_done) {
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2c4_kernel<OUT16, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2c4)");
-        attr_done = true;
+        attr_done.set();
     }
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2c4: at most 32 samples per call when statistics are requested");
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));

@@ -128,6 +128,7 @@ struct ru_unet {
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
+    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY;
     bool c16 = false;           // this forward/backward pair keeps its activations voxel-major (split-bf16, channels % 16 == 0)
     char* fpack = nullptr;
 
@@ -273,6 +274,12 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
     return RU_OK;
 }
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
+extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
+    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY)) == 0, "ru_unet_set_fusion: bad argument");
+    h->fusion = mask;
+    h->have_fwd = false;            // the workspace layout of the backward depends on it
+    return RU_OK;
+}
 extern "C" int ru_unet_freeze_params(ru_unet_t h, int frozen) {
     RU_REQUIRE(h, "ru_unet_freeze_params: null handle");
     h->params_frozen = frozen != 0;
@@ -513,17 +520,14 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     }
     // head: conv_output + bias + sigmoid (model.py:429-431)
     h->head_in = cur;
+    // training: the sigmoid backward reads the probabilities from the CALLER's buffer (kept valid until ru_unet_backward, see the header)
     float* pdst = probs_out;
-    if (h->training) { h->probs = A.alloc((size_t)N * h->nout * Vl(0)); pdst = h->probs; }
+    h->probs = probs_out;
     Conv3Args a{};
     a.x = cur; a.wp = h->pack + h->pk_out; a.bias = P(h, params, h->conv_out_b); a.y = pdst; a.sigmoid = 1;
     a.mode = h->precision; a.wfrag = h->fpack + h->fk_out; a.in_c16 = h->c16;
     a.N = N; a.Cin = C0; a.Cout = h->nout; a.D = Dl[0]; a.H = Hl[0]; a.W = Wl[0];
     RU_RUN(conv3_launch(a, s));
-    if (h->training && !A.dry) {
-        hipError_t e = hipMemcpyAsync(probs_out, h->probs, (size_t)N * h->nout * Vl(0) * sizeof(float), hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(probs)");
-    }
     if (!A.dry) { h->packed_params = h->training ? nullptr : params; h->packed_base = h->pack; h->packed_prec = h->precision; h->packed_c16 = h->c16; }   // a training forward is followed by an optimizer step
     return RU_OK;
 }
@@ -612,9 +616,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const bool c16 = h->c16;
     // 16-channel level (its kernels are memory-bound): the GroupNorm-backward apply is computed by the weight gradient's dy staging
     // from (y, d, coefficients) and published in split form for the data-gradient conv that follows -- no apply pass over (y, d)
-    static const bool no_gba = getenv("RU_NO_GBA") != nullptr;      // A/B switch
-    static const bool gba_all = getenv("RU_GBA_ALL") != nullptr;    // experiment: every level
-    const bool fa = c16 && h->precision == RU_PREC_BF16X3 && (C == 16 || gba_all) && !no_gba;
+    const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && (h->fusion & RU_FUSE_GN_BWD_APPLY);
     float *coef2 = nullptr, *coef1 = nullptr;
     int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2,
                     fa ? &coef2 : nullptr);
@@ -627,8 +629,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
     // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
-    static const bool no_bst = getenv("RU_NO_BST") != nullptr;      // A/B switch: separate reduce pass
-    const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && !no_bst;
+    const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
     float* part1 = nullptr;
     int nblk1 = 0;
     if (fuse1) {
@@ -712,7 +713,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         dh.x = d4; dh.wfrag = wf4; dh.in_c4 = 1;
     }
     // the head's data gradient is the gradient entering norm2 of the last decoder block: its GroupNorm-backward sums are taken here
-    static const bool no_bst = getenv("RU_NO_BST") != nullptr;
+    const bool no_bst = !(h->fusion & RU_FUSE_GN_BWD_STATS);
     const BlockSave* hb = (depth >= 2 && !h->dec_s[0].empty()) ? &h->dec_s[0].back() : nullptr;
     float* hpart = nullptr;
     int hnblk = 0;
@@ -1152,6 +1153,11 @@ extern "C" int ru_criterion_value(const double* sums_host, int C, double count, 
     if (dice) *dice = priority * (1.0 - acc / C);                                                  // loss.py:122
     if (bce) *bce = -sums_host[2 * C] / count;                                                     // loss.py:79
     return RU_OK;
+}
+extern "C" int ru_criterion_value_device(const double* sums, int C, double count, double priority, double w_dice, double w_bce, double* out3,
+                                         ru_stream_t stream) {
+    RU_REQUIRE(sums && out3 && C > 0 && C <= 64 && count > 0, "ru_criterion_value_device: bad argument");
+    return crit_value_launch(sums, C, count, priority, w_dice, w_bce, out3, (hipStream_t)stream);
 }
 extern "C" int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vmax, size_t n, float lr, float beta1, float beta2,
                                     float eps, float weight_decay, int step, ru_stream_t stream) {

@@ -851,6 +851,21 @@ int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C,
     RU_CHECK_LAUNCH("crit_final_kernel");
     return RU_OK;
 }
+// loss scalars on the device (one wave): out = (w_dice*dice + w_bce*bce, dice, bce), loss.py:114-122,79
+__global__ void crit_value_kernel(const double* __restrict__ sums, int C, double count, double priority, double w_dice, double w_bce,
+                                  double* __restrict__ out) {
+    double q = threadIdx.x < (unsigned)C ? 2.0 * (sums[threadIdx.x] + 1e-6) / (sums[C + threadIdx.x] + 2e-6) : 0.0;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (threadIdx.x == 0) {
+        const double dice = priority * (1.0 - q / C), bce = -sums[2 * C] / count;
+        out[0] = w_dice * dice + w_bce * bce; out[1] = dice; out[2] = bce;
+    }
+}
+int crit_value_launch(const double* sums, int C, double count, double priority, double w_dice, double w_bce, double* out3, hipStream_t s) {
+    hipLaunchKernelGGL(crit_value_kernel, dim3(1), dim3(64), 0, s, sums, C, count, priority, w_dice, w_bce, out3);
+    RU_CHECK_LAUNCH("crit_value_kernel");
+    return RU_OK;
+}
 __global__ __launch_bounds__(256) void crit_grad_kernel(const float* __restrict__ p, const float* __restrict__ g, const double* __restrict__ sums,
                                                         double count, float w_dice, float w_bce, float bgw, float priority,
                                                         float* __restrict__ dp, int C, size_t V) {

@@ -28,6 +28,15 @@ int hip_fail(hipError_t e, const char* what);
         }                                \
     } while (0)
 
+// a flag per HIP device: hipFuncSetAttribute (dynamic LDS above 64 KB) is a per-device setting, so a second device used by the same
+// process must not inherit the first one's "done"
+struct PerDevice {
+    bool done[64] = {};
+    static int cur() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : -1; }
+    bool get() const { const int d = cur(); return d >= 0 && done[d]; }
+    void set() { const int d = cur(); if (d >= 0) done[d] = true; }
+};
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
@@ -242,6 +251,7 @@ int crit_tiles(size_t total);
 int crit_sums_launch(const float* p, const float* g, double* sums, int N, int C, size_t V, float bgw, void* ws, size_t ws_bytes, hipStream_t s);
 int crit_grad_launch(const float* p, const float* g, const double* sums, double count, float w_dice, float w_bce,
                      float bgw, float priority, float* dp, int N, int C, size_t V, hipStream_t s);
+int crit_value_launch(const double* sums, int C, double count, double priority, double w_dice, double w_bce, double* out3, hipStream_t s);
 int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s);
 int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s);
 int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s);

@@ -360,13 +360,13 @@ size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) {
 template <int TZ, int TY, int OT, int CT>
 static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
     using P = W3<TZ, TY, OT, CT>;
-    static bool attr_done = false;
+    static PerDevice attr_done;
     const size_t lds = (size_t)P::LDS_FLOATS * sizeof(float);
-    if (!attr_done) {
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_f32_kernel<TZ, TY, OT, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3)");
-        attr_done = true;
+        attr_done.set();
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     dim3 grid(c.nbx, c.ngroups);
@@ -711,13 +711,13 @@ size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V) {
 
 template <int OT, int CT>
 static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
-    static bool attr_done = false;
+    static PerDevice attr_done;
     const size_t lds = (size_t)(OT + CT) * 16 * W1_RS * sizeof(float);
-    if (!attr_done) {
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1_f32_kernel<OT, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1)");
-        attr_done = true;
+        attr_done.set();
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     hipLaunchKernelGGL((wgrad1_f32_kernel<OT, CT>), dim3(c.nbx, c.ngroups), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, c.ncg, CoP, CiP);
@@ -736,12 +736,12 @@ int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
         return RU_ENOMEM;
     }
     if (a.s2d && wgrad1_s2d_usable(a.Cin, a.Cout)) {
-        static bool attr_done = false;
+        static PerDevice attr_done;
         const size_t lds = (size_t)4 * 16 * W1_RS * sizeof(float);
-        if (!attr_done) {
+        if (!attr_done.get()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1_s2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad1_s2d)");
-            attr_done = true;
+            attr_done.set();
         }
         const int nbx = wgrad1_s2d_nbx(a.N, a.Cin, a.Cout, a.V), ncgb = a.Cin / (W1S_NG * 32);
         hipLaunchKernelGGL(wgrad1_s2d_kernel, dim3(nbx, (a.Cout / 32) * ncgb), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, ncgb, a.Cout, a.Cin);

@@ -383,11 +383,11 @@ template <int OT, bool X16, bool DY16>
 static int wsb_cfg(const Wgrad3Args& a, const WSBChoice& c, hipStream_t s) {
     constexpr int TZ = OT == 1 ? 4 : 2;
     using P = WSB<TZ, 4, OT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDevice attr_done;
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_sb)");
-        attr_done = true;
+        attr_done.set();
     }
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,

@@ -432,11 +432,11 @@ size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) 
 template <int OT, int XS, int DS>
 static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     using P = WTZ<OT>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDevice attr_done;
+    if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_tz_kernel<OT, XS, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_tz)");
-        attr_done = true;
+        attr_done.set();
     }
     const int ntz = cdiv(a.D, 2), nty = cdiv(a.H, 8), ntx = cdiv(a.W, 16);
     const long ncol = (long)a.N * nty * ntx;

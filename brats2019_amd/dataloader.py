@@ -54,13 +54,29 @@ def zscore_stats(image):
     return mean, std
 
 
+def remap_labels(label):
+    """Label contract of the pipeline: {0, 1, 2, 3} with 3 = enhancing tumour.  The reference gets there in its reader
+    (loader_helper.read_multimodal: `annotation[annotation == 4] = 3`, loader_helper.py:30) and `np.eye(4)[label]` fails loudly on a raw
+    4 if that step is skipped; the device kernel only recognises 1, 2, 3, so raw BraTS labels {0, 1, 2, 4} are remapped HERE (4 -> 3)
+    and anything else is refused instead of silently dropping every ET voxel from the WT / TC / ET targets."""
+    lab = np.ascontiguousarray(label)
+    bad = ~np.isin(lab, (0, 1, 2, 3, 4))
+    if bad.any():
+        raise ValueError("label volume holds values outside {0,1,2,3,4}: %s" % np.unique(lab[bad])[:8])
+    lab = lab.astype(np.uint8)
+    lab[lab == 4] = 3
+    return lab
+
+
 class DeviceCase(object):
-    """One multimodal case resident in HBM: raw modalities [C,D,H,W] float32, label [D,H,W] uint8, z-score constants, centre box."""
+    """One multimodal case resident in HBM: raw modalities [C,D,H,W] float32, label [D,H,W] uint8 in {0,1,2,3} (raw BraTS 4 is
+    remapped to 3, see remap_labels), z-score constants, centre box."""
 
     def __init__(self, image, label, patch_size, device="cuda"):
         L.require_gpu()
+        label = remap_labels(label)
         self.image = torch.as_tensor(np.ascontiguousarray(image, dtype=np.float32)).to(device)
-        self.label = torch.as_tensor(np.ascontiguousarray(label).astype(np.uint8)).to(device)
+        self.label = torch.as_tensor(label).to(device)
         self.patch_size = tuple(int(p) for p in patch_size)
         self.mean, self.std = zscore_stats(self.image)
         self.bbox = label_bbox(label, self.patch_size)

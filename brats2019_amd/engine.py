@@ -75,6 +75,13 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_precision(self.h, L.PRECISIONS[precision]), "ru_unet_set_precision")
         self.precision = precision
 
+    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True):
+        """Backward-pass fusions of the voxel-major engine (ru_unet_set_fusion; both on by default, tests switch them off to hold the
+        fused kernels to the separate passes)."""
+        mask = (L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0)
+        L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
+        self._ws_key = None                    # the backward's workspace layout depends on it
+
     def freeze_params(self, frozen=True):
         """Inference with constant weights: the packed weights in the workspace are built once and reused (ru_unet_freeze_params).
         Leave off while training -- the optimizer rewrites the flat parameter buffer in place every step."""
@@ -110,6 +117,7 @@ class UNetEngine:
                                          L.ptr(ws), ws.numel(), L.stream()), "ru_unet_forward")
         self.generation += 1
         self._x = x                               # keep the input alive until backward (wgrad of conv_input reads it)
+        self._probs = probs if training else None  # ... and the probabilities (the sigmoid backward reads the caller's buffer)
         return probs
 
     def backward(self, flat_params, dprobs, flat_grads=None, want_dx=False):

@@ -32,10 +32,10 @@ class _CriterionFn(torch.autograd.Function):
         sums = ops.criterion_sums(pred, gt, bg_weight)
         world = _all_reduce_sums(sums, group)
         count = float(pred.numel()) * world
-        dice, bce = ops.criterion_value(sums, count, priority)
+        out = ops.criterion_losses(sums, count, priority, w_dice, w_bce)
         ctx.save_for_backward(pred, gt, sums)
         ctx.cfg = (count, w_dice, w_bce, bg_weight, priority)
-        return (w_dice * dice + w_bce * bce).to(torch.float32)
+        return out[0].to(torch.float32)
 
     @staticmethod
     def backward(ctx, gout):

@@ -25,6 +25,12 @@ from .engine import UNetEngine
 LEAKY_SLOPE = 1e-2
 
 
+def default_precision(number_of_channels):
+    """The benchmarked split-bf16 engine needs channel counts divisible by 16 (voxel-major C16 layout); it is what a drop-in user
+    gets for main.py:56-59.  Other configurations run the exact-f32 NCDHW kernels."""
+    return "bf16x3" if all(int(c) % 16 == 0 for c in number_of_channels) else "f32"
+
+
 # ---------------------------------------------------------------------- per-op autograd (building blocks used stand-alone)
 class _ConvFn(torch.autograd.Function):
     @staticmethod
@@ -154,7 +160,9 @@ class _UNetFn(torch.autograd.Function):
         probs = eng.forward(flat, x, training=training)
         ctx.net, ctx.generation, ctx.training = net, eng.generation, training
         ctx.x_needs_grad = x.requires_grad
-        return probs
+        if training:
+            ctx.save_for_backward(probs)          # the executor reads this buffer again in backward: autograd's version check then
+        return probs                              # catches an in-place edit of the returned probabilities
 
     @staticmethod
     def backward(ctx, dprobs):
@@ -164,9 +172,11 @@ class _UNetFn(torch.autograd.Function):
             raise RuntimeError("UNet forward ran in inference mode; no activations were kept for backward")
         if eng.generation != ctx.generation:
             raise RuntimeError("UNet.forward was called again before backward(): the executor keeps ONE forward state")
+        _ = ctx.saved_tensors                     # raises if the probabilities were modified in place since the forward
         flat = net._flat_params()
         res = eng.backward(flat, dprobs, want_dx=ctx.x_needs_grad)
         grads, dx = res if ctx.x_needs_grad else (res, None)
+        net.__dict__["_last_flat_grads"] = grads      # parallel.all_reduce_gradients reduces this bucket in place when p.grad alias it
         views = eng.layout.views(grads)
         out = []
         for name in net._param_order():
@@ -220,7 +230,7 @@ class UNet(nn.Module):
         eng = self.__dict__.get("_engine_obj")
         if eng is None:
             eng = UNetEngine(self.depth, list(self.encoder_layers), list(self.decoder_layers), list(self.number_of_channels),
-                             self.number_of_outputs, precision=self.__dict__.get("precision", "f32"))
+                             self.number_of_outputs, precision=self.__dict__.get("precision") or default_precision(self.number_of_channels))
             names = [n for n, _ in self.named_parameters()]
             if names != list(eng.layout.entries.keys()):
                 raise RuntimeError("parameter names/order differ from the executor's layout")
@@ -232,7 +242,11 @@ class UNet(nn.Module):
         return eng
 
     def set_precision(self, precision):
-        """Arithmetic of the 3x3x3 convolutions: "f32" (default, exact) or "bf16x3" (split-bf16, ~5x the MFMA rate)."""
+        """Arithmetic of the 3x3x3 convolutions: "bf16x3" (split-bf16 operands, 3 MFMA products, |dp| ~ 5e-5; the default when every
+        channel count is a multiple of 16, i.e. for the shipped configuration) or "f32" (exact-f32 MFMA, ~3x slower; opt-in, and
+        the default for other channel counts)."""
+        if precision not in L.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(L.PRECISIONS))
         self.__dict__["precision"] = precision
         eng = self.__dict__.get("_engine_obj")
         if eng is not None:
@@ -291,7 +305,7 @@ class UNet(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_engine_obj", "_flat_buf", "_param_names"):     # never pickle the ctypes handle / the alias buffer
+        for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads"):     # never pickle the ctypes handle / the alias buffer
             state.pop(k, None)
         return state
 

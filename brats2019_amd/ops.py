@@ -168,12 +168,19 @@ def criterion_grad(p, g, sums, count, w_dice=0.5, w_bce=0.5, bg_weight=1e-2, pri
     return dp
 
 
+def criterion_losses(sums, count, priority=1.0, w_dice=0.5, w_bce=0.5):
+    """float64 DEVICE tensor [3] = (w_dice*dice + w_bce*bce, dice, bce) from (global) sums -- one launch, no host sync."""
+    c = (sums.numel() - 1) // 2
+    out = torch.empty(3, dtype=torch.float64, device=sums.device)
+    L.check(L.load().ru_criterion_value_device(L.ptr(sums), c, float(count), float(priority), float(w_dice), float(w_bce), L.ptr(out), L.stream()),
+            "ru_criterion_value_device")
+    return out
+
+
 def criterion_value(sums, count, priority=1.0):
     """(dice, bce) as float64 0-dim DEVICE tensors from (global) sums -- no host sync."""
-    c = (sums.numel() - 1) // 2
-    inter, union, bce = sums[:c], sums[c:2 * c], sums[2 * c]
-    dice = priority * (1.0 - torch.mean(2.0 * (inter + 1e-6) / (union + 2e-6)))    # loss.py:114-122
-    return dice, -bce / count                                                        # loss.py:79
+    out = criterion_losses(sums, count, priority)
+    return out[1], out[2]                                                            # loss.py:114-122, loss.py:79
 
 
 def adam_amsgrad_step(w, g, m, v, vmax, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):

@@ -24,12 +24,13 @@ import torch.distributed as dist
 class HipBackend:
     """Arithmetic of the step on the local GPU through the C-ABI (no CPU fallback)."""
 
-    def __init__(self, cfg=None, device=None, precision="f32"):
+    def __init__(self, cfg=None, device=None, precision=None):
         from . import _lib as L
         from .engine import UNetEngine, DEFAULT_CFG
+        from .model import default_precision
         L.require_gpu()
         self.cfg = dict(cfg or DEFAULT_CFG)
-        self.engine = UNetEngine(precision=precision, **self.cfg)
+        self.engine = UNetEngine(precision=precision or default_precision(self.cfg["number_of_channels"]), **self.cfg)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.total = self.engine.layout.total
         # contiguous runs of LIVE parameters: the reference's Adam skips tensors whose grad is None (the never-executed
@@ -55,6 +56,12 @@ class HipBackend:
     def criterion_sums(self, probs, target, bg_weight):
         from . import ops
         return ops.criterion_sums(probs, target, bg_weight)
+
+    def criterion_losses(self, sums, count, priority):
+        """(loss, dice, bce) 0-dim float64 device tensors, loss = (dice + bce) / 2 (train.py:203-205)."""
+        from . import ops
+        out = ops.criterion_losses(sums, count, priority, 0.5, 0.5)
+        return out[0], out[1], out[2]
 
     def criterion_grad(self, probs, target, sums, count, bg_weight, priority):
         from . import ops
@@ -110,9 +117,7 @@ class DataParallelStep:
         if self.distributed:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         count = float(probs.numel()) * self.world
-        c = (sums.numel() - 1) // 2
-        dice = self.priority * (1.0 - torch.mean(2.0 * (sums[:c] + 1e-6) / (sums[c:2 * c] + 2e-6)))
-        bce = -sums[2 * c] / count
+        loss, dice, bce = b.criterion_losses(sums, count, self.priority)
         dprobs = b.criterion_grad(probs, target_shard, sums, count, self.bg_weight, self.priority)
         b.backward(self.flat, dprobs, self.grads)
         if self.distributed:
@@ -125,7 +130,7 @@ class DataParallelStep:
             else:
                 dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
         self.last_probs = probs
-        return 0.5 * (dice + bce), dice, bce
+        return loss, dice, bce
 
     def step(self, x_shard, target_shard):
         loss, dice, bce = self.loss_and_grads(x_shard, target_shard)
@@ -141,6 +146,55 @@ class DataParallelStep:
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.vmax.copy_(sd["vmax"])
         self.global_step = int(sd["global_step"])
+
+
+def world_info(group=None):
+    """(rank, world) of the initialised process group, (0, 1) otherwise."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def all_reduce_gradients(model, group=None):
+    """What nn.DataParallel's reduce_add does for the reference loop (main.py:61, train.py:210): after `loss.backward()` on this
+    rank's shard, SUM the parameter gradients over the ranks (SUM, not mean -- the criterion with `data_parallel` set already
+    carries the global 1/count).  Parameters whose grad is None (the never-executed deepest decoder stage) stay None
+    on every rank.  When the gradients still alias the flat bucket the HIP executor wrote (`_UNetFn.backward`), the live runs of
+    that bucket are reduced in place; otherwise (an accumulation copied them) they are packed into one bucket, reduced, unpacked."""
+    rank, world = world_info(group)
+    if world <= 1:
+        return 0
+    net = model.module if hasattr(model, "module") else model
+    params = [p for p in net.parameters() if p.grad is not None]
+    if not params:
+        return 0
+    flat = getattr(net, "__dict__", {}).get("_last_flat_grads")
+    if flat is not None:
+        lo, hi = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        runs = []
+        for p in params:
+            g = p.grad
+            a = g.data_ptr()
+            if not (g.dtype == torch.float32 and g.is_contiguous() and lo <= a and a + 4 * g.numel() <= hi):
+                runs = None
+                break
+            a = (a - lo) // 4
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = a + g.numel()
+            else:
+                runs.append([a, a + g.numel()])
+        if runs:
+            for a, e in runs:
+                dist.all_reduce(flat[a:e], op=dist.ReduceOp.SUM, group=group)
+            return sum(e - a for a, e in runs)
+    bucket = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(bucket[off:off + n].view_as(p.grad))
+        off += n
+    return off
 
 
 def init_process_group_from_env(backend=None):

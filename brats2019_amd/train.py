@@ -9,7 +9,13 @@ Differences that are deliberate:
   * the scheduler assert accepts `LRScheduler` (StepLR is no longer an `_LRScheduler` subclass instance);
   * tensorboardX is optional (absent in this image): scalars go to a no-op writer when it cannot be imported;
   * `eval_cpu=True` is refused: this path is HIP-only;
-  * tile geometry of `predict_tiled` is a parameter (defaults = the reference's literals 192/48/72).
+  * tile geometry of `predict_tiled` is a parameter (defaults = the reference's literals 192/48/72);
+  * data parallelism (main.py:61 wraps the model in nn.DataParallel so that this loop is data-parallel without knowing it): here the
+    loop itself is rank-aware.  Launched as one process per GPU (`torch.distributed.run`, process group initialised before
+    `Trainer.train`), every rank takes its slice of each batch the loader yields (what DataParallel's scatter does), the criteria
+    form the GLOBAL-batch loss (`data_parallel`, loss.py:114-115 sums over the whole batch), the parameter gradients are summed
+    over the ranks after `loss.backward()` (DataParallel's reduce_add) and every replica takes the same optimizer step; rank 0
+    alone writes checkpoints and scalars.  `shard_batches = False` if the loader already yields per-rank shards.
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import numpy as np
 import torch
 
 from . import tiling
+from .parallel import all_reduce_gradients, world_info
 
 
 class TrainingState(object):
@@ -54,7 +61,8 @@ def _log_metric(writer, metric, prefix, epoch):
     val = np.atleast_1d(np.asarray(metric.get(), dtype=np.float64))
     for i, v in enumerate(val):
         writer.add_scalar("%s%s-%d" % (prefix, metric.name, i), float(v), epoch)
-    print("%s%s: %s" % (prefix, metric.name, np.array2string(val, precision=4)))
+    if world_info()[0] == 0:
+        print("%s%s: %s" % (prefix, metric.name, np.array2string(val, precision=4)))
 
 
 class Trainer(object):
@@ -67,14 +75,22 @@ class Trainer(object):
         self.logs_path = os.path.join(self.model_path, "logs")
         self.state = TrainingState()
         self.resume_training = False
-        if os.path.exists(self.model_path):
-            if rewrite:
-                shutil.rmtree(self.model_path)
-            else:
-                self.resume_training = True
-        if not os.path.exists(self.model_path):
-            os.makedirs(self.logs_path)
-        self.tb_writer = _make_writer(self.logs_path) if connect_tb else _NullWriter()
+        self.shard_batches = True          # data parallel: slice each loader batch per rank (nn.DataParallel's scatter)
+        rank, world = world_info()
+        if rank == 0:
+            if os.path.exists(self.model_path):
+                if rewrite:
+                    shutil.rmtree(self.model_path)
+                else:
+                    self.resume_training = True
+            if not os.path.exists(self.model_path):
+                os.makedirs(self.logs_path)
+        if world > 1:                      # every rank follows rank 0's view of the directory
+            import torch.distributed as dist
+            flag = [self.resume_training]
+            dist.broadcast_object_list(flag, src=0)
+            self.resume_training = bool(flag[0])
+        self.tb_writer = _make_writer(self.logs_path) if (connect_tb and rank == 0) else _NullWriter()
         self.tile_shape, self.center_shape, self.border = (192, 192, 192), (48, 48, 48), (72, 72, 72)   # train.py:154-156
 
     def cuda(self):
@@ -90,6 +106,15 @@ class Trainer(object):
             raise NotImplementedError("eval_cpu=True needs a CPU model; this engine is HIP-only")
         self.eval_cpu = eval_cpu
         assert isinstance(criterion, (tuple, list, torch.nn.Module))
+        rank, world = world_info()
+        if world > 1:
+            # one process per GPU: each rank sees its shard only, so the criteria must reduce their partial sums over the ranks to
+            # form the loss nn.DataParallel computes on GPU 0 over the gathered global batch (main.py:61, train.py:201-208)
+            for c in (criterion if isinstance(criterion, (tuple, list)) else [criterion]):
+                if not hasattr(c, "data_parallel"):
+                    raise RuntimeError("data-parallel training needs criteria that reduce over the global batch "
+                                       "(brats2019_amd.loss modules); got %s" % type(c).__name__)
+                c.data_parallel = True
         if self.resume_training:
             self.load_latest()
         elif pretrained_weights is not None:
@@ -128,6 +153,33 @@ class Trainer(object):
     def _to_device(self, tensors):
         return [t.cuda(non_blocking=True) for t in tensors] if self.state.cuda else list(tensors)
 
+    def _shard(self, tensors):
+        """This rank's slice of every tensor of a loader batch: samples [r*B/W, (r+1)*B/W)."""
+        rank, world = world_info()
+        if world <= 1 or not self.shard_batches:
+            return list(tensors)
+        out = []
+        for t in tensors:
+            b = int(t.shape[0])
+            if b % world != 0:
+                raise ValueError("global batch %d is not divisible by the %d data-parallel ranks" % (b, world))
+            out.append(t[rank * (b // world):(rank + 1) * (b // world)])
+        return out
+
+    @staticmethod
+    def _reduce_metric(m):
+        """Equal shards: the global-batch mean a metric accumulates per update is the mean of the ranks' shard means."""
+        rank, world = world_info()
+        if world <= 1 or not hasattr(m, "accumulator"):
+            return
+        import torch.distributed as dist
+        acc = torch.as_tensor(np.asarray(m.accumulator, dtype=np.float64))
+        if torch.cuda.is_available() and dist.get_backend() == "nccl":
+            acc = acc.cuda()
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        acc = (acc / world).cpu().numpy()
+        m.accumulator = acc if acc.ndim else float(acc)
+
     def _train_one_epoch(self, criterion, optimizer, loader, train_metrics, results, epoch, global_step, scheduler):
         for m in train_metrics:
             m.reset()
@@ -137,7 +189,7 @@ class Trainer(object):
         optimizer.zero_grad()
         for batch in loader:
             assert isinstance(batch[0], list) and isinstance(batch[1], list)
-            data, target = self._to_device(batch[0]), self._to_device(batch[1])
+            data, target = self._to_device(self._shard(batch[0])), self._to_device(self._shard(batch[1]))
             output = self.model(data)                                        # train.py:201
             if isinstance(criterion, (tuple, list)):
                 loss_val = [c(output, target) for c in criterion]            # train.py:203-205
@@ -146,6 +198,7 @@ class Trainer(object):
                 loss_val = [criterion(output, target)]
                 loss = loss_val[0]
             loss.backward()                                                  # train.py:210
+            all_reduce_gradients(self.model)                                 # nn.DataParallel's reduce_add (main.py:61); no-op on one rank
             optimizer.step()
             optimizer.zero_grad()
             if scheduler is not None:
@@ -158,6 +211,7 @@ class Trainer(object):
                 self.tb_writer.add_scalar("misc/lr-%d" % i, group["lr"], global_step)
             global_step += 1
         for m in train_metrics:
+            self._reduce_metric(m)
             results[m.name].append(m.get())
             _log_metric(self.tb_writer, m, "train/", epoch)
         self.state.optimizer_state = optimizer.state_dict()
@@ -172,11 +226,26 @@ class Trainer(object):
             assert isinstance(batch[0], list)
             return self.model(self._to_device(batch[0]))
 
-    def predict_tiled(self, batch, output_shape, tile_shape=None, center_shape=None, border=None, batch_tiles=8):
+    def _auto_batch_tiles(self, tile_shape, nvol, cap=8):
+        """Tiles per forward: as many as fit in a third of the free device memory (the inference arena keeps every activation of a
+        forward: ~5.7 GiB per 192^3 tile in bf16x3, 7.6 GiB in f32), at most `cap`."""
+        net = self.model.module if hasattr(self.model, "module") else self.model
+        if not (torch.cuda.is_available() and hasattr(net, "_get_engine")):
+            return 1
+        from . import _lib as L
+        eng = net._get_engine()
+        per = L.load().ru_unet_workspace_bytes(eng.h, int(nvol), int(tile_shape[0]), int(tile_shape[1]), int(tile_shape[2]), 0)
+        if per == 0:
+            return 1
+        free, _total = torch.cuda.mem_get_info()
+        return int(max(1, min(cap, (free // 3) // per)))
+
+    def predict_tiled(self, batch, output_shape, tile_shape=None, center_shape=None, border=None, batch_tiles=None):
         """train.py:145-176: per centre block, run the model on the zero-padded tile and paste the centre back.
         The volume goes to the device once, tiles are cut there and `batch_tiles` of them share one forward (every op of
         the network is per-sample, so batching tiles does not change a single value); the pasted result stays on the
-        device until the end (the reference does .cuda()/.cpu() per tile)."""
+        device until the end (the reference does .cuda()/.cpu() per tile).  `batch_tiles=None`: sized from the free device
+        memory (at most 8)."""
         tile_shape = tuple(tile_shape or self.tile_shape)
         center_shape = tuple(center_shape or self.center_shape)
         border = tuple(border or self.border)
@@ -185,6 +254,8 @@ class Trainer(object):
             self.model.cuda()
             inp = inp.cuda(non_blocking=True)
         self.model.eval()
+        if batch_tiles is None:
+            batch_tiles = self._auto_batch_tiles(tile_shape, int(inp.shape[0]))
         output = torch.zeros(output_shape, dtype=torch.float32, device=inp.device)
         grid = tiling.grid_for(inp.shape[2:], center_shape)
         positions = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
@@ -229,7 +300,12 @@ class Trainer(object):
         return os.path.join(self.model_path, self.name + suffix + ".pth")    # no separator, like the reference
 
     def _save(self, suffix):
-        torch.save({"state": self.state, "model": self.model}, self._ckpt(suffix))
+        rank, world = world_info()
+        if rank == 0:                          # replicas are identical: one writer
+            torch.save({"state": self.state, "model": self.model}, self._ckpt(suffix))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()                     # nobody reads (load_latest on resume) a file that is still being written
 
     def _load(self, suffix):
         from .compat import install_aliases

@@ -119,6 +119,10 @@ int ru_criterion_grad(const float* p, const float* g, const double* sums, double
                       float* dp, int N, int C, size_t V, ru_stream_t stream);
 /* host helper: (dice, bce) from global sums (host pointer) */
 int ru_criterion_value(const double* sums_host, int C, double count, double priority, double* dice, double* bce);
+/* the same on the device, one launch, no host sync: out[0] = w_dice*dice + w_bce*bce (train.py:203-205 with w = 1/2), out[1] = dice
+ * (loss.py:114-122), out[2] = bce (loss.py:79) as float64, from the (all-reduced) device sums */
+int ru_criterion_value_device(const double* sums, int C, double count, double priority, double w_dice, double w_bce,
+                              double* out3, ru_stream_t stream);
 
 /* ---------------------------------------------------------------- optimizer (main.py:133-142)
  * torch.optim.Adam(amsgrad=True) with L2 weight decay added to the gradient; `step` is 1-based.  */
@@ -144,6 +148,14 @@ int ru_unet_set_precision(ru_unet_t h, int precision);
  * reference's optimizer changes the weights every step (train.py:220).  */
 int ru_unet_freeze_params(ru_unet_t h, int frozen);
 int ru_unet_get_precision(ru_unet_t h);
+/* Backward-pass fusions of the voxel-major split-bf16 engine (both on by default; same arithmetic either way up to summation order --
+ * the separate passes stay available so that tests can hold the fused kernels to them):
+ *   RU_FUSE_GN_BWD_STATS  the GroupNorm-backward sums are taken in the epilogue of the data-gradient conv that produces the incoming
+ *                         gradient (no reduce pass over (y, d));
+ *   RU_FUSE_GN_BWD_APPLY  16-channel level: the GroupNorm-backward apply is computed in the weight gradient's dy staging (no apply pass). */
+#define RU_FUSE_GN_BWD_STATS 1
+#define RU_FUSE_GN_BWD_APPLY 2
+int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
 int ru_unet_param_ndim(ru_unet_t h, int i);
@@ -153,7 +165,8 @@ size_t ru_unet_param_total(ru_unet_t h);                     /* floats */
 int ru_unet_param_is_dead(ru_unet_t h, int i);
 size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int W, int training);
 /* UNet.forward (model.py:407-433): x [N,4,D,H,W] -> probs [N,n_out,D,H,W] (sigmoid).  D,H,W divisible by
- * 2^(depth-1).  training != 0 keeps activations in `ws` for ru_unet_backward.  */
+ * 2^(depth-1).  training != 0 keeps activations in `ws` for ru_unet_backward; `x` and `probs` are then read again by
+ * ru_unet_backward (weight gradient of conv_input; sigmoid backward) and must stay valid and unmodified until it has run.  */
 int ru_unet_forward(ru_unet_t h, const float* params, const float* x, float* probs,
                     int N, int D, int H, int W, int training,
                     void* ws, size_t ws_bytes, ru_stream_t stream);

@@ -248,7 +248,7 @@ def gn_stats_hooks(net, store):
     return hooks
 
 
-def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward):
+def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16):
     out = {"seed": np.int64(seed), "shape": np.asarray((n,) + dhw, np.int64)}
     net, params = load_ref_unet(cfg, seed)
     x = O.make_input(n, *dhw, seed=seed)
@@ -271,7 +271,7 @@ def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward):
                 continue
             gflat = p.grad.numpy().ravel()
             out["gnorm_" + k] = np.float64(np.sqrt((gflat.astype(np.float64) ** 2).sum()))
-            out["gsamp_" + k] = gflat[:: max(1, gflat.size // 16)][:16].copy()
+            out["gsamp_" + k] = gflat[:: max(1, gflat.size // nsamp)][:nsamp].copy()
             if gflat.size <= 4096:
                 out["gfull_" + k] = p.grad.numpy().copy()
         out["dead_params"] = np.asarray(dead)
@@ -299,6 +299,37 @@ def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward):
     for k, v in stats.items():
         out["gnstat_" + k] = v
     save(tag + ".npz", **out)
+
+
+# ------------------------------------------------------------------ (5b) BASELINE configs[4]: sliding window over a BraTS-native volume
+def gen_sliding240():
+    """The loop body of Trainer.predict_tiled (train.py:158-174) around the reference's own get_indices / copy / copy_back
+    (loader_helper.py:34-97) and the reference UNet, with the tile geometry of BASELINE configs[4] (tile 128, centre 64, border 32;
+    the reference hard-codes 192/48/72 at train.py:154-156) on one seeded 240x240x155x4 volume: 4 x 4 x 3 = 48 forwards."""
+    shape, seed = (240, 240, 155), 4242
+    tile, center, border = (128, 128, 128), (64, 64, 64), (32, 32, 32)
+    net, _ = load_ref_unet(O.DEFAULT_CFG, 1337)
+    net.eval()
+    inp = t(O.make_input(1, *shape, seed=seed))
+    output = torch.zeros((1, 3) + shape)
+    grid = [int(np.ceil(j / i)) for i, j in zip(center, inp.shape[2:])]                       # train.py:158
+    with torch.no_grad():
+        for i in range(grid[0]):
+            for j in range(grid[1]):
+                for k in range(grid[2]):
+                    a, b = ref_lh.get_indices(position=(i, j, k), center_shape=center, border=border)
+                    tl = ref_lh.copy(data=inp, tile_shape=tile, index_min=a, index_max=b)
+                    o = net([tl])[0].detach().cpu()                                         # train.py:171
+                    ref_lh.copy_back(data=output, tile=o, center_shape=center, index_min=a, index_max=b, border=border)
+    pn = output.numpy()
+    mask = pn > 0.5
+    flat = pn.ravel()
+    stride = max(1, flat.size // 4096)
+    save("sliding240.npz", seed=np.int64(seed), shape=np.asarray(shape), tile=np.asarray(tile), center=np.asarray(center),
+         border=np.asarray(border), grid=np.asarray(grid), mask_packed=np.packbits(mask.ravel()), mask_count=np.int64(mask.sum()),
+         near_half_1e_5=np.int64((np.abs(pn - 0.5) < 1e-5).sum()), near_half_1e_3=np.int64((np.abs(pn - 0.5) < 1e-3).sum()),
+         sample_stride=np.int64(stride), samples=flat[::stride][:4096].copy(),
+         plane=pn[0, :, 120, ::2, ::2].copy())                # one sub-sampled plane through every tile seam in y/z
 
 
 # ------------------------------------------------------------------ (7) Adam(amsgrad) + StepLR
@@ -478,6 +509,12 @@ if __name__ == "__main__":
         gen_unet("unet_small", small, 2, (16, 24, 16), 7, full_output=True, with_backward=True)
     if want("unet128"):
         gen_unet("unet128", full, 1, (128, 128, 128), 1337, full_output=False, with_backward=False)
+    if want("unet128_train"):
+        # a TRAINING step at a size where every persistent kernel path of the HIP engine is taken (batch 2 x 128^3; the reference needs
+        # ~15 s and ~10 GB for it): train.py:201-210 around the imported model / loss modules
+        gen_unet("unet128_train", full, 2, (128, 128, 128), 2024, full_output=False, with_backward=True, nsamp=64)
+    if want("sliding240"):
+        gen_sliding240()
     if want("adam"):
         gen_adam()
     if want("tiling"):

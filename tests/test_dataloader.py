@@ -122,3 +122,33 @@ def test_simple_reader_protocol(golden):
     d, t = fr[0]
     np.testing.assert_allclose(d[0].cpu().numpy()[:, ::2, ::2, ::2], g["full_data_sub"], rtol=0, atol=2e-5)
     np.testing.assert_array_equal(np.packbits(t[0].cpu().numpy().astype(np.uint8)), g["full_target_bits"])
+
+
+def test_remap_labels_contract():
+    """raw BraTS labels {0,1,2,4} -> {0,1,2,3} (loader_helper.py:30); anything else is refused, not silently dropped"""
+    from brats2019_amd import dataloader as DL
+    raw = np.array([[0, 1], [2, 4]], np.int16)
+    np.testing.assert_array_equal(DL.remap_labels(raw), np.array([[0, 1], [2, 3]], np.uint8))
+    np.testing.assert_array_equal(DL.remap_labels(np.array([0.0, 3.0, 4.0], np.float32)), np.array([0, 3, 3], np.uint8))
+    with pytest.raises(ValueError):
+        DL.remap_labels(np.array([0, 5]))
+    with pytest.raises(ValueError):
+        DL.remap_labels(np.array([0.5]))
+
+
+@pytest.mark.gpu
+def test_hip_raw_brats_labels_give_the_reference_targets(golden):
+    """a case handed over with RAW labels {0,1,2,4} must produce the targets the reference builds after its reader's 4 -> 3 step"""
+    from brats2019_amd import dataloader as DL
+    g = golden("dataloader")
+    image, label = _case()
+    raw = label.copy()
+    raw[label == 3] = 4
+    assert (raw == 4).any()
+    patch = tuple(int(v) for v in g["patch"])
+    vol = DL.DeviceCase(image, raw, patch)
+    random.seed(int(g["seed0"]))
+    np.random.seed(int(g["seed0"]))
+    p = DL.draw_augment_params(vol.bbox, patch)
+    _data, tgt = DL.augment_patch(vol, p)
+    np.testing.assert_allclose(tgt.cpu().numpy(), g["target0"], rtol=0, atol=2e-6)

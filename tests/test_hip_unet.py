@@ -18,17 +18,21 @@ T = torch.from_numpy
 SMALL = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[8, 16, 32], number_of_outputs=3)
 
 
-def build_model(cfg, seed):
+def build_model(cfg, seed, precision="f32"):
+    """exact-f32 arithmetic unless a test asks for the split-bf16 engine (the drop-in default for the shipped configuration)"""
     from brats2019_amd import model as M
     net = M.UNet(**cfg)
+    net.set_precision(precision)
     params = O.make_params(seed, **cfg)
     net.load_state_dict({k: T(v) for k, v in params.items()})
     return net.cuda(), params
 
 
-def run_train_step(cfg, n, dhw, seed):
+def run_train_step(cfg, n, dhw, seed, precision="f32", fusion=None):
     from brats2019_amd import loss as L
-    net, params = build_model(cfg, seed)
+    net, params = build_model(cfg, seed, precision)
+    if fusion is not None:
+        net._get_engine().set_fusion(*fusion)
     x = T(O.make_input(n, *dhw, seed=seed)).cuda()
     g = T(O.make_target(n, *dhw, seed=seed)).cuda()
     net.train()
@@ -40,12 +44,20 @@ def run_train_step(cfg, n, dhw, seed):
     return net, out[0].detach(), loss, vals
 
 
-def check_against_fixture(g, net, probs, loss, vals, grad_rel):
+def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, loss_tol=5e-6, flip_band=1e-5):
     p = probs.cpu().numpy()
-    err = np.abs(p - g["probs"]).max()
-    assert err <= 2e-5, "max |dp| = %.3e" % err
-    assert abs(float(loss) - float(g["loss"])) < 5e-6
-    assert abs(float(vals[0]) - float(g["loss_dice"])) < 5e-6 and abs(float(vals[1]) - float(g["loss_bce"])) < 5e-6
+    if "probs" in g:
+        err = np.abs(p - g["probs"]).max()
+    else:                                                    # large fixtures: strided samples + the packed > 0.5 mask
+        err = np.abs(p.ravel()[:: int(g["sample_stride"])][:4096] - g["samples"]).max()
+        mask = p > 0.5
+        ref_mask = np.unpackbits(g["mask_packed"])[: mask.size].astype(bool).reshape(mask.shape)
+        diff = mask != ref_mask
+        assert (np.abs(p[diff] - 0.5) < flip_band).all(), "%d mask voxels differ outside the %.0e band" % (int(diff.sum()), flip_band)
+        assert int(diff.sum()) <= int(g["near_half_1e-4"]) * (1 if flip_band <= 1e-4 else 20) + 8
+    assert err <= prob_tol, "max |dp| = %.3e" % err
+    assert abs(float(loss) - float(g["loss"])) < loss_tol
+    assert abs(float(vals[0]) - float(g["loss_dice"])) < loss_tol and abs(float(vals[1]) - float(g["loss_bce"])) < loss_tol
     dead = set(g["dead_params"].tolist())
     for k, prm in net.named_parameters():
         if k in dead:
@@ -61,7 +73,8 @@ def check_against_fixture(g, net, probs, loss, vals, grad_rel):
             # magnitude: the fp32 CPU reference itself carries ~1e-3 relative noise there, hence 4x the norm tolerance
             np.testing.assert_allclose(gr, g["gfull_" + k].ravel().astype(np.float64), rtol=0, atol=4 * grad_rel * np.abs(g["gfull_" + k]).max() + 1e-9,
                                        err_msg=k)
-        samp = gr[:: max(1, gr.size // 16)][:16]
+        ns = int(g["gsamp_" + k].size)
+        samp = gr[:: max(1, gr.size // ns)][:ns]
         np.testing.assert_allclose(samp, g["gsamp_" + k].astype(np.float64), rtol=0, atol=10 * grad_rel * ref / np.sqrt(gr.size) + 1e-9, err_msg=k)
 
 
@@ -337,3 +350,81 @@ def test_frozen_params_reuse_packs_bit_identical_and_drop_them_on_weight_change(
             q.mul_(0.99)
         p6 = net([x])[0].clone()
         assert not torch.equal(p6, p5)
+
+
+# ---------------------------------------------------------------- full-size TRAINING step pinned by the reference (tests/golden/unet128_train.npz)
+# batch 2 x 128^3, shipped configuration: every level takes the persistent kernels (conv3_sb2 single- and multi-chunk, z-walk tile
+# order, statistics partials across a sample boundary, BST epilogues, wgrad3_tz with the fused GroupNorm-backward apply) -- the
+# paths the 32^3 fixtures cannot reach.  Reference: train.py:201-210 around model.py / loss.py, run by make_golden.py.
+def _grad_report(g, net):
+    worst = (0.0, "")
+    for k, prm in net.named_parameters():
+        if prm.grad is None:
+            continue
+        ref = float(g["gnorm_" + k])
+        got = float(torch.linalg.vector_norm(prm.grad.double()))
+        worst = max(worst, (abs(got - ref) / ref, k))
+    return worst
+
+
+def test_unet128_train_step_f32_matches_reference_fixture(golden):
+    g = golden("unet128_train")
+    net, probs, loss, vals = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "f32")
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-4)
+    print("f32 unet128_train: worst relative gradient-norm error %.2e (%s)" % _grad_report(g, net))
+
+
+@pytest.mark.parametrize("fusion", [(True, True), (False, True), (True, False), (False, False)],
+                         ids=["fused", "no-bst", "no-gba", "unfused"])
+def test_unet128_train_step_bf16x3_matches_reference_fixture(golden, fusion):
+    """BASELINE configs[2] arithmetic at a full-size shape against the REFERENCE (not the HIP path against itself): probabilities to 2e-4
+    (bar 1e-3), mask flips only within 1e-3 of the threshold, loss to 5e-5, every parameter-gradient norm to 5e-3 with elementwise
+    samples -- with the backward fusions on (the benchmarked path) and with each of them switched off (ru_unet_set_fusion)."""
+    g = golden("unet128_train")
+    net, probs, loss, vals = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "bf16x3", fusion)
+    assert net._get_engine().precision == "bf16x3"
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-3, prob_tol=2e-4, loss_tol=5e-5, flip_band=1e-3)
+    print("bf16x3 unet128_train %s: worst relative gradient-norm error %.2e (%s)" % ((fusion,) + _grad_report(g, net)))
+
+
+def test_fused_and_unfused_backward_agree_tightly():
+    """A/B of the fused GroupNorm-backward kernels against the separate passes on the SAME forward (batch 2 x 128^3, bf16x3): the
+    fusions only move where sums are taken, so every gradient tensor agrees to 2e-4 in relative L2 (a dropped term in a fused epilogue
+    would show at the 1e-2 level)."""
+    net, _ = build_model(O.DEFAULT_CFG, 2024, "bf16x3")
+    x = T(O.make_input(2, 128, 128, 128, seed=2024)).cuda()
+    w = torch.randn(2, 3, 128, 128, 128, generator=torch.Generator().manual_seed(1)).cuda() * 1e-3
+    res = {}
+    for fusion in ((True, True), (False, False)):
+        net._get_engine().set_fusion(*fusion)
+        net.zero_grad()
+        p = net([x])[0]
+        (p * w).sum().backward()
+        res[fusion] = (p.detach().clone(), {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None})
+    pa, ga = res[(True, True)]
+    pb, gb = res[(False, False)]
+    assert torch.equal(pa, pb)                               # the forward does not depend on the switch
+    worst = max((float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-30)), k) for k in ga)
+    print("fused vs unfused backward: worst relative L2 %.2e (%s)" % worst)
+    assert worst[0] < 2e-4, worst
+
+
+def test_default_precision_is_bf16x3_for_the_shipped_configuration():
+    from brats2019_amd import model as M
+    assert M.UNet(**O.DEFAULT_CFG)._get_engine().precision == "bf16x3"          # what a drop-in Trainer user gets (main.py:56-59)
+    assert M.UNet(**SMALL)._get_engine().precision == "f32"                      # channels not divisible by 16: exact-f32 NCDHW kernels
+    with pytest.raises(ValueError):
+        M.UNet(**SMALL).set_precision("fp8")
+
+
+def test_inplace_edit_of_probabilities_before_backward_is_caught():
+    """the executor reads the returned probabilities again in backward (sigmoid backward): autograd's version check must refuse an
+    in-place edit instead of silently using the edited values"""
+    net, _ = build_model(SMALL, 3)
+    x = T(O.make_input(1, 16, 16, 16, seed=3)).cuda()
+    p = net([x])[0]
+    loss = p.sum()
+    with torch.no_grad():
+        p.mul_(0.5)
+    with pytest.raises(RuntimeError):
+        loss.backward()

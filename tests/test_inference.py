@@ -166,3 +166,38 @@ def test_entry_point_loads_reference_checkpoint_and_segments(tmp_path):
     full = np.zeros(img.shape[1:], np.uint8)
     full[bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]] = want
     assert (seg != full).mean() < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,batch_tiles,tol,band", [("bf16x3", 8, 1e-3, 1e-3), ("f32", 3, 2e-5, 1e-5)])
+def test_sliding_window_240x240x155_matches_reference_fixture(golden, tmp_path, precision, batch_tiles, tol, band):
+    """BASELINE configs[4] at its full size: one BraTS-native 240x240x155x4 volume, 128^3 tiles (centre 64, border 32 -> 48 tiles)
+    through Trainer.predict_tiled with batched tiles and frozen (packed-once) weights, against the REFERENCE's own tiling loop and
+    UNet (tests/golden/sliding240.npz: train.py:158-174 + loader_helper.py:34-97 run by make_golden.py).  bf16x3: probabilities
+    within 1e-3 (the bar of BASELINE.json), labels may only flip where the probability is within 1e-3 of the threshold; f32: 2e-5 /
+    1e-5 like the other exact-f32 tests (3 tiles per forward: a ragged last batch)."""
+    from brats2019_amd import model as M, train as TR
+    g = golden("sliding240")
+    shape = tuple(int(v) for v in g["shape"])
+    params = O.make_params(1337, **O.DEFAULT_CFG)
+    net = M.UNet(**O.DEFAULT_CFG)
+    net.set_precision(precision)
+    net.load_state_dict({k: T(v) for k, v in params.items()})
+    net.cuda().eval()
+    net.freeze_params(True)
+    vol = T(O.make_input(1, *shape, seed=int(g["seed"])))
+    tr = TR.Trainer(name="sw", models_root=str(tmp_path), model=net, rewrite=True, connect_tb=False)
+    tile, centre, border = (tuple(int(v) for v in g[k]) for k in ("tile", "center", "border"))
+    got = tr.predict_tiled([[vol]], (1, 3) + shape, tile, centre, border, batch_tiles=batch_tiles)[0].numpy()
+    samp = got.ravel()[:: int(g["sample_stride"])][:4096]
+    err = float(np.abs(samp - g["samples"]).max())
+    perr = float(np.abs(got[0, :, 120, ::2, ::2] - g["plane"]).max())          # a plane through every y/z tile seam
+    mask = got > 0.5
+    ref_mask = np.unpackbits(g["mask_packed"])[: mask.size].astype(bool).reshape(mask.shape)
+    diff = mask != ref_mask
+    print("sliding 240x240x155 %s: max |dp| samples %.2e, seam plane %.2e; %d / %d labels differ" % (precision, err, perr, int(diff.sum()), mask.size))
+    assert err <= tol and perr <= tol
+    assert (np.abs(got[diff] - 0.5) < band).all()
+    assert int(diff.sum()) <= (int(g["near_half_1e_3"]) if band >= 1e-3 else int(g["near_half_1e_5"]) + 8)
+    d = O.dice_metric(mask.astype(np.float32), ref_mask.astype(np.float32))    # metrics.Dice yardstick (BASELINE.json "Dice vs reference")
+    assert (d > 1.0 - 1e-4).all()

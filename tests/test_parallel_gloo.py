@@ -63,6 +63,12 @@ class OracleBackend:
         i, u, b = O.np_dice_bce_sums(probs.numpy(), target.numpy(), bg_weight)
         return torch.from_numpy(np.concatenate([i, u, [b]]))
 
+    def criterion_losses(self, sums, count, priority):
+        c = (sums.numel() - 1) // 2
+        dice = priority * (1.0 - torch.mean(2.0 * (sums[:c] + 1e-6) / (sums[c:2 * c] + 2e-6)))     # loss.py:114-122
+        bce = -sums[2 * c] / count                                                                # loss.py:79
+        return 0.5 * (dice + bce), dice, bce
+
     def criterion_grad(self, probs, target, sums, count, bg_weight, priority):
         s = sums.numpy()
         c = (s.size - 1) // 2
@@ -164,3 +170,132 @@ def test_two_rank_sharded_step_equals_global_batch_step(tmp_path):
     w1, _m, _v, _vm = O.np_adam_amsgrad_step(w, r0["grads"].astype(np.float64), np.zeros_like(w), np.zeros_like(w), np.zeros_like(w), 1, 1e-3)
     assert np.abs(w1 - r0["w1"])[~dead_mask].max() < 1e-7
     assert abs(float(r0["l1"]) - ref_loss) < 2e-6 and np.isfinite(r0["l2"])
+
+
+# ---------------------------------------------------------------------- the reference-surface loop: train.Trainer under a process group
+class _OracleUNet(torch.nn.Module):
+    """CPU stand-in with the product model's call convention (list in, list out) over the oracle forward: test infrastructure for
+    the HOST logic of Trainer (sharding, gradient all-reduce, rank-0 checkpoints); the product model is HIP-only."""
+
+    def __init__(self, cfg, params):
+        super().__init__()
+        self.cfg = cfg
+        self.names = list(params.keys())
+        self.plist = torch.nn.ParameterList([torch.nn.Parameter(torch.from_numpy(params[k]).clone()) for k in self.names])
+
+    def cuda(self, *a, **k):
+        return self
+
+    def forward(self, x):
+        return [O.unet_forward(dict(zip(self.names, self.plist)), x[0], **self.cfg)]
+
+
+class _OracleCritFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, g, w_dice, w_bce, bg_weight, data_parallel):
+        i, u, b = O.np_dice_bce_sums(p.detach().numpy(), g.numpy(), bg_weight)
+        sums = torch.from_numpy(np.concatenate([i, u, [b]]))
+        world = 1
+        if data_parallel and dist.is_initialized():
+            dist.all_reduce(sums)
+            world = dist.get_world_size()
+        c = p.shape[1]
+        count = float(p.numel()) * world
+        s = sums.numpy()
+        _half, dice, bce = O.np_criterion_from_sums(s[:c], s[c:2 * c], s[2 * c], count)
+        ctx.save_for_backward(p.detach(), g)
+        ctx.cfg = (s, count, w_dice, w_bce, bg_weight)
+        return torch.tensor(w_dice * dice + w_bce * bce, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, g = ctx.saved_tensors
+        s, count, w_dice, w_bce, bgw = ctx.cfg
+        c = p.shape[1]
+        both = O.np_criterion_grad(p.numpy(), g.numpy(), s[:c], s[c:2 * c], count, bgw, 1.0)                 # = (dDice + dBCE) / 2
+        only_b = O.np_criterion_grad(p.numpy(), g.numpy(), s[:c], np.full(c, 1e150), count, bgw, 1.0)         # Dice term vanishes
+        d_bce, d_dice = 2.0 * only_b, 2.0 * (both - only_b)
+        return torch.from_numpy((w_dice * d_dice + w_bce * d_bce).astype(np.float32)) * gout, None, None, None, None, None
+
+
+class _OracleCrit(torch.nn.Module):
+    def __init__(self, w_dice, w_bce, bg_weight):
+        super().__init__()
+        self.w, self.data_parallel = (w_dice, w_bce, bg_weight), False
+
+    def forward(self, x, y):
+        return _OracleCritFn.apply(x[0], y[0], self.w[0], self.w[1], self.w[2], self.data_parallel)
+
+
+class _CountMetric:
+    name = "frac"
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.accumulator, self.samples = 0.0, 0.0
+
+    def update(self, out, tgt):
+        self.accumulator += float((out[0] > 0.5).float().mean())
+        self.samples += 1
+
+    def get(self):
+        return self.accumulator / self.samples
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from brats2019_amd import train as TR
+    params = O.make_params(SEED, **CFG)
+    net = _OracleUNet(CFG, params)
+    tr = TR.Trainer(name="dp", models_root=os.path.join(out_dir, "m%d" % world), model=net, rewrite=True, connect_tb=False)
+    tr.state.cuda = False
+    batches = []
+    for i in range(2):
+        batches.append(([torch.from_numpy(O.make_input(2, *DHW, seed=SEED + i))], [torch.from_numpy(O.make_target(2, *DHW, seed=SEED + i))]))
+    crit = [_OracleCrit(1.0, 0.0, 1.0), _OracleCrit(0.0, 1.0, 1e-2)]                       # Dice_loss_joint + BCE_Loss(bg 1e-2), main.py:126-128
+    m = _CountMetric()
+    tr.state.cuda = False
+    orig_train = tr.train
+
+    def no_cuda_train(**kw):                      # Trainer.train starts from self.state.cuda, which load/fresh state sets True
+        tr.state.cuda = False
+        return orig_train(**kw)
+    no_cuda_train(criterion=crit, optimizer=torch.optim.Adam, optimizer_params=dict(lr=1e-3, weight_decay=1e-6, amsgrad=True),
+                  scheduler=torch.optim.lr_scheduler.StepLR, scheduler_params=dict(step_size=1, gamma=0.5),
+                  training_data_loader=batches, evaluation_data_loader=[], split_into_tiles=False, pretrained_weights=None,
+                  train_metrics=[m], val_metrics=[], track_metric="none", epoches=1, default_val=0.0,
+                  comparator=lambda a, b: False, eval_cpu=False, continue_form_pretraining=False)
+    w = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    np.savez(os.path.join(out_dir, "tr_w%d_r%d.npz" % (world, rank)), w=w, metric=np.float64(tr.state.train_metric["frac"][0]),
+             ckpt=int(os.path.exists(os.path.join(tr.model_path, "dplast_model.pth"))), steps=tr.state.global_step,
+             dp_flags=np.asarray([c.data_parallel for c in crit]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trainer_loop_shards_batches_and_sums_gradients(tmp_path):
+    """Trainer.train (the reference's loop, train.py:59-127,178-241) under a 2-rank gloo group == the single-process run on the
+    global batches: the criteria get `data_parallel`, each rank trains on its slice, gradients are summed before optimizer.step()
+    (what nn.DataParallel's reduce_add does, main.py:61), replicas stay identical, metrics are the global-batch values and only
+    rank 0 writes the checkpoints."""
+    _trainer_worker(0, 1, 0, str(tmp_path))
+    ref = dict(np.load(tmp_path / "tr_w1_r0.npz"))
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (dict(np.load(tmp_path / ("tr_w2_r%d.npz" % r))) for r in range(2))
+    assert np.array_equal(r0["w"], r1["w"])
+    assert r0["dp_flags"].all() and not ref["dp_flags"].any()
+    assert int(r0["steps"]) == int(ref["steps"]) == 2
+    # Adam normalises the step: compare against the reference run elementwise (two steps, lr 1e-3 then 5e-4)
+    dw = np.abs(r0["w"] - ref["w"])
+    assert dw.max() < 2e-5 and dw.mean() < 2e-7, (dw.max(), dw.mean())
+    moved = np.abs(ref["w"] - np.concatenate([v.ravel() for v in O.make_params(SEED, **CFG).values()]))
+    assert moved.max() > 1e-3                                 # the run really trained
+    assert abs(float(r0["metric"]) - float(ref["metric"])) < 1e-6 and float(r0["metric"]) == float(r1["metric"])
+    assert int(r0["ckpt"]) == 1 and int(r1["ckpt"]) == 1 and os.path.exists(tmp_path / "m2" / "dp" / "dplast_model.pth")
