@@ -1,7 +1,8 @@
-"""Build libresunet_hip.so (gfx950) in-tree with hipcc.  `python -m brats2019_amd.build [--force] [--devtools]`.
+"""Build libresunet_hip.so (gfx950) in-tree with hipcc.  `python -m brats2019_amd.build [--force] [--dbg BITS]`.
 
-`--devtools` builds a SECOND library, lib/libresunet_hip_dev.so, with -DRU_DEVTOOLS: the ablation / section-counter switches of
-tools/*.sh (RU_SB2_DEBUG, ru_dbg_sb2_prof) exist only there; select it with RU_LIB_PATH.  The product library has none of them.
+`--dbg BITS` builds ANOTHER library, lib/libresunet_hip_dbg<BITS>.so, with -DRU_SB2_DBG=<BITS>: the ablation / section-counter
+switches of conv3_sb2 (tools/sb2_*.sh, ru_dbg_sb2_prof) are compile-time and exist only there; select it with RU_LIB_PATH.  The
+product library has none of them.
 
 One `hipcc -c` per translation unit (run in parallel), then one link.  The shared library lands in
 brats2019_amd/lib/ (git-ignored, but it travels to the GPU box with the gpurun snapshot).  Objects are
@@ -39,22 +40,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src, force, devtools=False):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + (".dev.o" if devtools else ".o"))
+def _compile(src, force, devtools=None):
+    if src != "conv3_sb.hip":
+        devtools = None                        # only this unit has RU_SB2_DBG switches: the others are shared with the product build
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + (".dbg%d.o" % devtools if devtools is not None else ".o"))
     path = os.path.join(CSRC, src)
     if not force and not _stale(obj, [path] + HEADERS):
         return obj, ""
-    cmd = [_hipcc()] + FLAGS + (["-DRU_DEVTOOLS"] if devtools else []) + ["-c", path, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + (["-DRU_SB2_DBG=%d" % devtools] if devtools is not None else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     return obj, r.stderr
 
 
-def build(force=False, verbose=True, devtools=False):
+def build(force=False, verbose=True, devtools=None):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    lib = os.path.join(LIBDIR, "libresunet_hip_dev.so") if devtools else LIB
+    lib = os.path.join(LIBDIR, "libresunet_hip_dbg%d.so" % devtools) if devtools is not None else LIB
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force, devtools), srcs))
@@ -73,4 +76,4 @@ def build(force=False, verbose=True, devtools=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, devtools="--devtools" in sys.argv)
+    build(force="--force" in sys.argv, devtools=int(sys.argv[sys.argv.index("--dbg") + 1]) if "--dbg" in sys.argv else None)

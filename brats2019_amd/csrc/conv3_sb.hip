@@ -28,6 +28,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SB_KSTEPS = 14;       // ceil(27 taps / 2)
 
+// Tap (dz*9 + dy*3 + dx, or -1 = phantom with zero weights) in K-slot `slot` (k-groups 0-1 / 2-3 of the A fragment) of K-step ks.
+// The 27 taps are 9 chains (dz, dx) of three dy taps each.  K-step 3f + dy (f < 4) pairs the dy-th taps of chains 2f and 2f+1, so the
+// A fragment of (K-step 3f + dy, output row i) is the fragment of (K-step 3f + dy', output row i + dy - dy'): one LDS read serves the
+// three output rows that share a halo row (conv3_sb2_kernel's consumer).  The ninth chain fills K-steps 12 (dy 0, 1) and 13 (dy 2, -).
+__host__ __device__ constexpr int sb_tap(int ks, int slot) {
+    if (ks < 12) {
+        const int ch = 2 * (ks / 3) + slot, dy = ks % 3;
+        return (ch / 3) * 9 + dy * 3 + ch % 3;
+    }
+    const int dy = (ks - 12) * 2 + slot;
+    return dy < 3 ? 2 * 9 + dy * 3 + 2 : -1;
+}
+
 template <int TZ, int TY>
 struct SB {
     static constexpr int HZ = TZ + 2, HY = TY + 2, HX = 18;
@@ -202,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
     int aoff[SB_KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < SB_KSTEPS; ++ks) {
-        int tap = 2 * ks + (kg >> 1);
-        if (tap > 26) tap = 26;                  // phantom 28th tap: its weights are zero, any valid address will do
+        int tap = sb_tap(ks, kg >> 1);
+        if (tap < 0) tap = 26;                   // phantom 28th tap: its weights are zero, any valid address will do
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
         aoff[ks] = (kg & 1) * HVOLP + ((mz + dz) * HY + my0 + dy) * HX + dx + (lane & 15);
     }
@@ -412,14 +425,15 @@ template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg_arg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue.
-    // Only a -DRU_DEVTOOLS build (python -m brats2019_amd.build --devtools -> lib/libresunet_hip_dev.so, for tools/) reads it; the
-    // product library compiles every switch out.
-#ifdef RU_DEVTOOLS
-    const int dbg = dbg_arg;
+    // COMPILE-TIME only: a -DRU_SB2_DBG=<bits> build (python -m brats2019_amd.build --dbg <bits> -> lib/libresunet_hip_dbg<bits>.so,
+    // for tools/) has them; the product library compiles every switch out.  (A runtime switch put a branch around every unrolled step
+    // of the consumer and the ablation then timed different code.)
+#ifdef RU_SB2_DBG
+    constexpr int dbg = RU_SB2_DBG;
 #else
     constexpr int dbg = 0;
-    (void)dbg_arg;
 #endif
+    (void)dbg_arg;
     using P = SB<TZ, TY>;
     constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NROW = P::NROW;
     constexpr int BUF = 4 * HVOLP;                      // packets per LDS buffer
@@ -718,16 +732,25 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         }
     } else {
         // ---------------------------------------------------------------- consumers
-        const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
+        // Wave rw owns output plane z0 + rw: its 8 M-tiles are the 8 rows of that plane (tile i = row y0 + i), and the A fragment of
+        // (tile i, tap (dz, dy, dx)) sits at halo row i + dy of halo plane rw + dz.  The K-steps pair taps so that the SAME fragment
+        // serves three tiles (sb_tap): K-step 3f + dy holds tap dy of two dy-chains, so the fragment F(f, r) read at halo row r is the
+        // operand of tile r (K-step 3f), tile r-1 (K-step 3f+1) and tile r-2 (K-step 3f+2).  The item is walked ROW-MAJOR: for each
+        // halo row r = 0..9, four family fragments + one fragment of the ninth chain (K-steps 12 / 13) -- 50 fragment pairs (hi, lo) per
+        // item instead of 8 tiles x 14 K-steps = 112: the LDS read traffic of the consumers was what held the matrix pipe at ~55 %
+        // (917 KB of ds_read_b128 per item and CU next to 139 KB of producer writes, on a 256 B/clk array).  Same MFMAs (336), same
+        // weights in registers.  Tile i is complete after row i + 2 and stored while the next rows compute (one store per row).
+        static_assert(MT == TY && MT == 8 && TZ == 4, "one output plane per consumer wave");
+        const int mz = rw, my0 = 0;
         const int kg = lane >> 4;
-        int aoff[SB_KSTEPS];
+        int fbase[6];                                   // packet offset of each fragment form at halo row 0 (hi plane; lo plane = + 2*HVOLP)
 #pragma unroll
-        for (int ks = 0; ks < SB_KSTEPS; ++ks) {
-            int tap = 2 * ks + (kg >> 1);
-            if (tap > 26) tap = 26;
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            aoff[ks] = (kg & 1) * HVOLP + ((mz + dz) * HY + my0 + dy) * HX + dx + (lane & 15);
+        for (int f = 0; f < 4; ++f) {
+            const int t = sb_tap(3 * f, kg >> 1);       // dy = 0 tap of this lane's chain
+            fbase[f] = (kg & 1) * HVOLP + ((mz + t / 9) * HY + my0) * HX + t % 3 + (lane & 15);
         }
+        fbase[4] = (kg & 1) * HVOLP + ((mz + 2) * HY + my0 + (kg >> 1)) * HX + 2 + (lane & 15);   // ninth chain (dz 2, dx 2): slot 0 = row r, slot 1 = row r+1
+        fbase[5] = (kg & 1) * HVOLP + ((mz + 2) * HY + my0) * HX + 2 + (lane & 15);               // rows 8, 9: both slots row r (slot 1 meets zero weights)
         u32x4 wreg[SB_KSTEPS][2];
         auto wptr = [&](int chunk) { return wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane; };
         auto load_w = [&](int chunk) {
@@ -746,17 +769,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
         };
         constexpr int NS = OUT16 ? 4 : 1;
-        constexpr int HM = MT / 2;
         f32x4 s1, s2;                                   // whole vectors: the per-row update is 2 v_pk_add + 2 v_pk_fma, no packing moves
 #pragma unroll
         for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-        // The M-tiles of a wave form two groups (0..HM-1, HM..MT-1).  A group runs all 14 K-steps on its own accumulators while
-        // the OTHER group's finished tile rows are stored, one store every third K-step: group 0 of a tile is stored under
-        // group 1's MFMAs, group 1 under group 0 of the NEXT item (after the barrier).  A store burst at the end of every item
-        // (32 KB per CU from all CUs at once) is HBM-write bound and used to stall the matrix pipe for ~25 % of the kernel.
-        // Inside a group, the A fragment of K-step ks+1 is read right after the last MFMA that uses the register: one LDS
-        // instruction between two MFMAs instead of a burst (sched_barrier pins the written order).
-        bf16x8 ah[HM], al[HM];                          // A fragments (hi / lo) of the group's M-tiles; live from group 0 into group 1
         f32x4 kc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // BST: (k1, k2, thr) of this lane's 4 channels for sample kc_n
         int kc_n = -1;
         auto need_kc = [&](int n) __attribute__((always_inline)) {      // wave-uniform, reloads only when the sample changes
@@ -772,93 +787,17 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 }
             }
         };
-        auto run_group = [&](auto GSEL, const u32x4* buf, bool do_store, const SbOut& so, int ybase, const u32x4* wnext) {
-            constexpr int gsel = decltype(GSEL)::value, cb = gsel * HM, sb = (1 - gsel) * HM;
-            float4 radd[HM];
-#pragma unroll
-            for (int j = 0; j < HM; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (do_store && (BST || a.add)) {           // residual (or, BST, the forward tensor y): unconditional loads from clamped addresses
-                const float* src = BST ? a.bst_y : a.add;
-#pragma unroll
-                for (int j = 0; j < HM; ++j) {
-                    const int yy = ybase + sb + j;
-                    radd[j] = *reinterpret_cast<const float4*>(src + ((so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
-                }
-            }
-            auto store_row = [&](int yy, const f32x4& v, const float4& r) __attribute__((always_inline)) {
-                if constexpr (BST) sb_out_tile_bst(a, so, yy, v, r, kc, a.bst_slope, s1, s2);
-                else sb_out_tile<OUT16, NS>(a, so, yy, v, r, s1, s2);
-            };
-            if (dbg & 4) {
-                if (do_store) {
-#pragma unroll
-                    for (int j = 0; j < HM; ++j) store_row(ybase + sb + j, acc[sb + j], radd[j]);
-                }
-                return;
-            }
-            if constexpr (gsel == 0) {                  // group 1's first fragments are read under group 0's last K-step
-#pragma unroll
-                for (int i = 0; i < HM; ++i) {
-                    ah[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + (cb + i) * HX]);
-                    al[i] = __builtin_bit_cast(bf16x8, buf[aoff[0] + 2 * HVOLP + (cb + i) * HX]);
-                }
-            }
-            static_for<SB_KSTEPS>([&](auto KS) {
-                constexpr int ks = decltype(KS)::value;
-                constexpr bool within = ks + 1 < SB_KSTEPS;
-                constexpr bool more = within || gsel == 0;         // fragments to fetch: this group's next K-step, or group 1's first
-                constexpr int nb = within ? cb : HM;                // first M-tile of the group they belong to
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                const int nofs = aoff[within ? ks + 1 : 0];
-#pragma unroll
-                for (int i = 0; i < HM; ++i) {            // lo * hi ; al[i] is free after its MFMA
-                    if constexpr (!MULTI && ks == 0) acc[cb + i] = mm(al[i], bh, f32x4{0.f, 0.f, 0.f, 0.f});    // one chunk: starts from the zero operand, no v_mov per accumulator
-                    else acc[cb + i] = mm(al[i], bh, acc[cb + i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more && i > 0) {
-                        al[i - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (nb + i - 1) * HX]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < HM; ++i) {            // hi * lo
-                    acc[cb + i] = mm(ah[i], bl, acc[cb + i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more && i == 0) {
-                        al[HM - 1] = __builtin_bit_cast(bf16x8, buf[nofs + 2 * HVOLP + (nb + HM - 1) * HX]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < HM; ++i) {            // hi * hi ; ah[i] is free after its MFMA
-                    acc[cb + i] = mm(ah[i], bh, acc[cb + i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) {
-                        ah[i] = __builtin_bit_cast(bf16x8, buf[nofs + (nb + i) * HX]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if constexpr (MULTI && gsel == 1) {       // this K-step's fragments are dead for this item: fetch the next chunk's
-                    wreg[ks][0] = wnext[(ks * 2 + 0) * 64];
-                    wreg[ks][1] = wnext[(ks * 2 + 1) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (ks % 3 == 2 && ks / 3 < HM) {
-                    if (do_store) store_row(ybase + sb + ks / 3, acc[sb + ks / 3], radd[ks / 3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-            static_assert(HM <= SB_KSTEPS / 3, "one store slot per M-tile of the other group");
-        };
-        SbOut out_prev{}, out_cur{};
-        int yb_prev = 0, yb_cur = 0, n_prev = 0;
-        bool pend = false;                              // group 1 of the previous tile still has to be stored
+        // per-row operand of the epilogue (residual `add`, or BST: the forward tensor y): loaded three rows ahead of the store from a
+        // clamped address; without such an operand every lane reads one dummy line and the value is dropped by a select (no branch
+        // in the MFMA stream)
+        const float* rsrc = BST ? a.bst_y : (a.add ? a.add : a.y);
+        const bool has_r = BST || a.add != nullptr;
         // GroupNorm statistics: ONE partial per (workgroup, consumer wave, sample) -- the tiles of a workgroup come in increasing
         // order, so a sample's tiles are consecutive; the partial is flushed when the sample changes and the samples this
         // workgroup never sees get zeros (the finalize kernel then reads gridDim.x*4 partials per channel instead of 4 per tile)
         const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
         unsigned flushed = 0;                           // bit n: sample n has been written
+        int n_acc = -1;                                 // sample whose statistics are being accumulated
         auto flush_stats = [&](int n) {
             sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
             flushed |= 1u << (n & 31);
@@ -885,39 +824,133 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             gy = b % nty; b /= nty;
             gz = b % ntz; gn = b / ntz;
         }
+        constexpr int NSTEP = 50;                       // (halo row r = 0..9) x (4 families + ninth chain)
         int chunk = 0;
         for (int w = 0; w < nitems; ++w) {
             if (prof) t0 = __builtin_readcyclecounter();
-            const bool last = chunk == nchunk - 1 && !(dbg & 8);
+            const bool last = chunk == nchunk - 1 && !(dbg & 8);      // this item completes its tile: the rows are stored as they finish
             const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
             const u32x4* buf = lds + (w & 1) * BUF;
-            const int n = cn, n_item = cn;               // sample of this item's tile
+            const int n = cn;                            // sample of this item's tile
+            SbOut so{};
+            int ybase = 0;
             if (last) {
-                out_cur = sb_out_prepare<OUT16>(a, cn, ctz * TZ + mz, ctx * 16, cog, lane);
-                yb_cur = cty * TY + my0;
+                so = sb_out_prepare<OUT16>(a, cn, ctz * TZ + mz, ctx * 16, cog, lane);
+                ybase = cty * TY + my0;
+                if (n != n_acc) {                        // first tile of a new sample here: the previous sample's partial is complete
+                    if (n_acc >= 0) flush_stats(n_acc);
+                    n_acc = n;
+                }
+                need_kc(n);
             }
-            // ---- group 0 computes; group 1 of the previous tile is stored underneath, then that tile's statistics are flushed
             if (MULTI && chunk == 0) {
 #pragma unroll
-                for (int i = 0; i < HM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (prof) { t1 = __builtin_readcyclecounter(); pt[0] += t1 - t0; t0 = t1; }
-            if (pend) need_kc(n_prev);
-            run_group(std::integral_constant<int, 0>{}, buf, pend, out_prev, yb_prev, wnext);
-            if (prof) { t1 = __builtin_readcyclecounter(); pt[1] += t1 - t0; t0 = t1; }
-            if (pend) {
-                if (n_item != n_prev) flush_stats(n_prev);   // the previous tile was the last one of its sample here
-                pend = false;
-            }
-            // ---- group 1 computes; group 0 of this tile is stored underneath
-            if (MULTI && chunk == 0) {
+            auto frag_ofs = [&](auto S) __attribute__((always_inline)) {
+                constexpr int r = decltype(S)::value / 5, f = decltype(S)::value % 5;
+                return fbase[f < 4 ? f : (r < 8 ? 4 : 5)] + r * HX;
+            };
+            bf16x8 fh[3], fl[3];                         // fragment ring: step s lives in slot s % 3, fetched two steps ahead
+            fh[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{})]);
+            fl[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{}) + 2 * HVOLP]);
+            fh[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{})]);
+            fl[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{}) + 2 * HVOLP]);
+            float4 radd[4];                              // tile i uses slot i % 4: loaded at row i, consumed at row i + 3
 #pragma unroll
-                for (int i = HM; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (prof) { t1 = __builtin_readcyclecounter(); pt[2] += t1 - t0; t0 = t1; }
-            if (last) need_kc(n);
-            run_group(std::integral_constant<int, 1>{}, buf, last, out_cur, yb_cur, wnext);
-            if (last) { pend = true; out_prev = out_cur; yb_prev = yb_cur; n_prev = n; }
+            for (int j = 0; j < 4; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto store_tile = [&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const float4 q = radd[i & 3];
+                const float4 rr = has_r ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], rr, kc, a.bst_slope, s1, s2);
+                else sb_out_tile<OUT16, NS>(a, so, ybase + i, acc[i], rr, s1, s2);
+            };
+            static_for<NSTEP>([&](auto S) {
+                constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % 3, nxt = (s + 2) % 3;
+                const bf16x8 ah = fh[cur], al = fl[cur];
+                bool fetched = (s + 2 >= NSTEP);
+                auto fetch = [&]() __attribute__((always_inline)) {            // the slot of step s-1 is free once its MFMAs are issued
+                    if constexpr (s + 2 < NSTEP) {
+                        const int o = frag_ofs(std::integral_constant<int, (s + 2 < NSTEP ? s + 2 : 0)>{});
+                        fh[nxt] = __builtin_bit_cast(bf16x8, buf[o]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fl[nxt] = __builtin_bit_cast(bf16x8, buf[o + 2 * HVOLP]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    fetched = true;
+                };
+                if (!(dbg & 4)) {
+                    if constexpr (f < 4) {
+                        // tiles r-2 (dy 2), r-1 (dy 1), r (dy 0); products lo*hi, hi*lo, hi*hi -- product-major, so MFMAs on one accumulator
+                        // are three apart
+                        static_for<3>([&](auto PR) {
+                            constexpr int pr = decltype(PR)::value;
+                            static_for<3>([&](auto E) {
+                                constexpr int dy = 2 - decltype(E)::value, i = r - dy;
+                                if constexpr (i >= 0 && i < MT) {
+                                    constexpr int ks = 3 * f + dy;
+                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                                    if constexpr (pr == 0) {
+                                        if constexpr (!MULTI && f == 0 && dy == 0) acc[i] = mm(al, bh, f32x4{0.f, 0.f, 0.f, 0.f});   // first touch of tile i (one chunk): zero operand
+                                        else acc[i] = mm(al, bh, acc[i]);
+                                    } else if constexpr (pr == 1) {
+                                        acc[i] = mm(ah, bl, acc[i]);
+                                    } else {
+                                        acc[i] = mm(ah, bh, acc[i]);
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (!fetched) fetch();
+                                }
+                            });
+                        });
+                    } else {
+                        // ninth chain: K-step 12 = (dy 0, dy 1) feeds tile r, K-step 13 = (dy 2, phantom) feeds tile r-2 from the same fragment
+                        static_for<3>([&](auto PR) {
+                            constexpr int pr = decltype(PR)::value;
+                            static_for<2>([&](auto E) {
+                                constexpr int ks = decltype(E)::value == 0 ? 13 : 12, i = decltype(E)::value == 0 ? r - 2 : r;
+                                if constexpr (i >= 0 && i < MT) {
+                                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
+                                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+                                    if constexpr (pr == 0) acc[i] = mm(al, bh, acc[i]);
+                                    else if constexpr (pr == 1) acc[i] = mm(ah, bl, acc[i]);
+                                    else acc[i] = mm(ah, bh, acc[i]);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (!fetched) fetch();
+                                }
+                            });
+                        });
+                    }
+                }
+                if (!fetched) fetch();
+                // ---- row bookkeeping between the MFMAs
+                if constexpr (f == 0 && r < MT) {           // epilogue operand of tile r, three rows ahead of its store
+                    const int yy = ybase + r;
+                    radd[r & 3] = *reinterpret_cast<const float4*>(rsrc + ((last && has_r && so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (f == 1 && r >= 3) {           // tile r-3 was completed by row r-1: its MFMAs have drained by now
+                    if (last) store_tile(std::integral_constant<int, r - 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (MULTI) {
+                    // a K-step's weights are dead for this item after their last tile: fetch the next chunk's into the same registers
+                    // (dy 0 after row 7, dy 1 after row 8, dy 2 after row 9)
+                    constexpr int ksd = f < 4 ? (r >= 7 ? 3 * f + (r - 7) : -1) : (r == 7 ? 12 : (r == 9 ? 13 : -1));
+                    if constexpr (ksd >= 0) {
+                        wreg[ksd][0] = wnext[(ksd * 2 + 0) * 64];
+                        wreg[ksd][1] = wnext[(ksd * 2 + 1) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (s == 24) {
+                    if (prof) { t1 = __builtin_readcyclecounter(); pt[1] += t1 - t0; t0 = t1; }
+                }
+            });
+            if (last) store_tile(std::integral_constant<int, MT - 1>{});      // completed by the last row (tile 6 went out in row 9)
             if (++chunk == nchunk) {                    // next tile
                 chunk = 0;
                 ++cstep;
@@ -935,23 +968,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (prof) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; pt[5] += 1; }
         }
         if (prof) t0 = __builtin_readcyclecounter();
-        if (pend) {                                     // drain: group 1 of the last tile
-            float4 radd[HM];
-            const float* src = BST ? a.bst_y : a.add;
-#pragma unroll
-            for (int j = 0; j < HM; ++j) {
-                const int yy = yb_prev + HM + j;
-                radd[j] = src ? *reinterpret_cast<const float4*>(src + ((out_prev.ok && yy < H) ? sb_out_index<OUT16>(a, out_prev, yy) : 0))
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            need_kc(n_prev);
-#pragma unroll
-            for (int j = 0; j < HM; ++j) {
-                if constexpr (BST) sb_out_tile_bst(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], kc, a.bst_slope, s1, s2);
-                else sb_out_tile<OUT16, NS>(a, out_prev, yb_prev + HM + j, acc[HM + j], radd[j], s1, s2);
-            }
-            flush_stats(n_prev);
-        }
+        if (n_acc >= 0) flush_stats(n_acc);
         if (prof && rw == 0 && lane == 0) {
             pt[6] = __builtin_readcyclecounter() - t0;
 #pragma unroll
@@ -1235,7 +1252,7 @@ int conv3_sb4_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, i
 
 // ------------------------------------------------------------------ weight fragments
 // unit u = ((cog*nchunk + chunk)*14 + ks)*2 + hl, 64 lanes x 16 bytes each: lane l (col = l&15, k-group g = l>>4) holds,
-// for e = 0..7, W[cout = cog*16 + col][cin = chunk*16 + (g&1)*8 + e][tap = 2*ks + (g>>1)].
+// for e = 0..7, W[cout = cog*16 + col][cin = chunk*16 + (g&1)*8 + e][tap = sb_tap(ks, g>>1)] (zeros for the phantom tap).
 __device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int i) {
     const int total = ncog * nchunk * SB_KSTEPS * 64;
     if (i >= total) return;
@@ -1244,7 +1261,7 @@ __device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* 
     const int chunk = ((i >> 6) / SB_KSTEPS) % nchunk;
     const int cog = (i >> 6) / (SB_KSTEPS * nchunk);
     const int col = lane & 15, g = lane >> 4;
-    const int tap = 2 * ks + (g >> 1);
+    const int tap = sb_tap(ks, g >> 1);
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     const int co = cog * 16 + col;
     float t[8];
@@ -1252,7 +1269,7 @@ __device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* 
     for (int e = 0; e < 8; ++e) {
         const int ci = chunk * 16 + (g & 1) * 8 + e;
         float v = 0.f;
-        if (tap < 27 && ci < cin_conv && co < cout_conv)
+        if (tap >= 0 && ci < cin_conv && co < cout_conv)
             v = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
         t[e] = v;
     }
@@ -1343,8 +1360,8 @@ int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
 }
 
-#ifdef RU_DEVTOOLS
-// tools only (not in include/resunet_hip.h, -DRU_DEVTOOLS builds): read and clear the RU_SB2_DEBUG=64 section counters
+#ifdef RU_SB2_DBG
+// tools only (not in include/resunet_hip.h, -DRU_SB2_DBG builds): read and clear the RU_SB2_DEBUG=64 section counters
 extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(sb2_prof), 8 * sizeof(unsigned long long));
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyFromSymbol(sb2_prof)");
@@ -1368,12 +1385,7 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2: at most 32 samples per call when statistics are requested");
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
-#ifdef RU_DEVTOOLS
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("RU_SB2_DEBUG"); dbg = e ? atoi(e) : 0; }
-#else
-    constexpr int dbg = 0;
-#endif
+    constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Per-section cycle breakdown of the conv3_sb2 consumer loop (RU_SB2_DEBUG=64): usage sb2_sections.py [C] [size] [N]
+"""Per-section cycle breakdown of the conv3_sb2 consumer loop (-DRU_SB2_DBG=64 build): usage sb2_sections.py [C] [size] [N]
 Prints the average cycles per item that consumer wave 0 of a workgroup spends in each section."""
 import ctypes, os, sys
-os.environ["RU_SB2_DEBUG"] = str(64 | int(os.environ.get("RU_SB2_EXTRA", "0")))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DBG = 64 | int(os.environ.get("RU_SB2_EXTRA", "0"))
+os.environ.setdefault("RU_LIB_PATH", os.path.join(ROOT, "brats2019_amd", "lib", "libresunet_hip_dbg%d.so" % DBG))   # python -m brats2019_amd.build --dbg <64|extra>
+sys.path.insert(0, ROOT)
 import torch
 from brats2019_amd import _lib as L
 
@@ -26,7 +28,7 @@ for rep in range(3):
     fn(ctypes.addressof(buf))
 v = list(buf)
 items, wgs = max(v[5], 1), max(v[7], 1)
-names = ["index math", "group 0", "between", "group 1", "barrier"]
+names = ["item setup", "rows 0-4", "(unused)", "rows 5-9", "barrier"]
 tot = sum(v[:5])
 print("C=%d size=%d N=%d: %d workgroups, %.1f items each; cycles per item (consumer wave 0):" % (c, size, n, wgs, items / wgs))
 for i, nm in enumerate(names):
