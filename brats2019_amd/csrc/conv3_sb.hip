@@ -137,6 +137,27 @@ __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, 
     }
     *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// The same for the persistent kernel, with what a row needs decided at COMPILE time: every VALU instruction of the epilogue sits in the
+// consumer's stream between its MFMAs (~25 cycles each there), so a voxel-major row without residual is statistics + store and
+// nothing else.  The bias exists for NCDHW output only (the head conv; voxel-major output with a bias takes the one-stage kernel).
+template <bool OUT16, bool HAS_R>
+__device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, f32x4& s1, f32x4& s2) {
+    if (!(o.ok && yy < a.H)) return;
+    if constexpr (!OUT16) v += f32x4{o.bias.x, o.bias.y, o.bias.z, o.bias.w};
+    if constexpr (HAS_R) v += f32x4{radd.x, radd.y, radd.z, radd.w};
+    if constexpr (OUT16) {
+        s1 += v;
+        s2 += v * v;
+    } else {
+        s1[0] += (v[0] + v[1]) + (v[2] + v[3]);
+        s2[0] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (a.sigmoid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]));
+        }
+    }
+    *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
+}
 // Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
 // GroupNorm-backward sums are taken on the way: u = y*k1 + k2 (= sign(gamma)*xhat), dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
 __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& yv, const f32x4 (&kc)[3], float slope,
@@ -421,7 +442,9 @@ __device__ unsigned long long sb2_prof[8];
 // the registers group 1 has just finished with, instead of 28 loads at the start of every item with the matrix pipe waiting on
 // the first (that exposed L2 latency was ~20 % of the kernel at 32..128 channels).
 // BST: fused GroupNorm-backward statistics in the epilogue (Conv3Args::bst_*), C16 output only.
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST>
+// ADD: a residual tensor is added in the epilogue (Conv3Args::add).  Compile-time, like BST: without a per-row operand the consumer's
+// stream holds NO loads, so its s_waitcnt vmcnt never has to wait for older row stores to be acknowledged (vmcnt counts in order).
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST, bool ADD>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg_arg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue.
@@ -790,8 +813,8 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // per-row operand of the epilogue (residual `add`, or BST: the forward tensor y): loaded three rows ahead of the store from a
         // clamped address; without such an operand every lane reads one dummy line and the value is dropped by a select (no branch
         // in the MFMA stream)
-        const float* rsrc = BST ? a.bst_y : (a.add ? a.add : a.y);
-        const bool has_r = BST || a.add != nullptr;
+        const float* rsrc = BST ? a.bst_y : a.add;
+        constexpr bool has_r = BST || ADD;
         // GroupNorm statistics: ONE partial per (workgroup, consumer wave, sample) -- the tiles of a workgroup come in increasing
         // order, so a sample's tiles are consecutive; the partial is flushed when the sample changes and the samples this
         // workgroup never sees get zeros (the finalize kernel then reads gridDim.x*4 partials per channel instead of 4 per tile)
@@ -825,10 +848,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             gz = b % ntz; gn = b / ntz;
         }
         constexpr int NSTEP = 50;                       // (halo row r = 0..9) x (4 families + ninth chain)
+        float dbg_sink = 0.f;
         int chunk = 0;
         for (int w = 0; w < nitems; ++w) {
             if (prof) t0 = __builtin_readcyclecounter();
-            const bool last = chunk == nchunk - 1 && !(dbg & 8);      // this item completes its tile: the rows are stored as they finish
+            const bool last = chunk == nchunk - 1;      // this item completes its tile: the rows are stored as they finish
             const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
             const u32x4* buf = lds + (w & 1) * BUF;
             const int n = cn;                            // sample of this item's tile
@@ -862,10 +886,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             for (int j = 0; j < 4; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             auto store_tile = [&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                const float4 q = radd[i & 3];
-                const float4 rr = has_r ? q : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], rr, kc, a.bst_slope, s1, s2);
-                else sb_out_tile<OUT16, NS>(a, so, ybase + i, acc[i], rr, s1, s2);
+                if constexpr ((dbg & 8) != 0) { dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; return; }   // ablation: the MFMAs stay, the row is dropped
+                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], radd[i & 3], kc, a.bst_slope, s1, s2);
+                else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i & 3], s1, s2);
             };
             static_for<NSTEP>([&](auto S) {
                 constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % 3, nxt = (s + 2) % 3;
@@ -927,16 +950,16 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 }
                 if (!fetched) fetch();
                 // ---- row bookkeeping between the MFMAs
-                if constexpr (f == 0 && r < MT) {           // epilogue operand of tile r, three rows ahead of its store
+                if constexpr (has_r && f == 0 && r < MT) {  // epilogue operand of tile r, three rows ahead of its store (unconditional, clamped address)
                     const int yy = ybase + r;
-                    radd[r & 3] = *reinterpret_cast<const float4*>(rsrc + ((last && has_r && so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
+                    radd[r & 3] = *reinterpret_cast<const float4*>(rsrc + ((last && so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (f == 1 && r >= 3) {           // tile r-3 was completed by row r-1: its MFMAs have drained by now
                     if (last) store_tile(std::integral_constant<int, r - 3>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (MULTI) {
+                if constexpr (MULTI && !(dbg & 128)) {      // (ablation bit 128: the weights are never refilled)
                     // a K-step's weights are dead for this item after their last tile: fetch the next chunk's into the same registers
                     // (dy 0 after row 7, dy 1 after row 8, dy 2 after row 9)
                     constexpr int ksd = f < 4 ? (r >= 7 ? 3 * f + (r - 7) : -1) : (r == 7 ? 12 : (r == 9 ? 13 : -1));
@@ -968,6 +991,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (prof) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; pt[5] += 1; }
         }
         if (prof) t0 = __builtin_readcyclecounter();
+        if ((dbg & 8) && dbg_sink == 12345.678f) a.y[0] = dbg_sink;
         if (n_acc >= 0) flush_stats(n_acc);
         if (prof && rw == 0 && lane == 0) {
             pt[6] = __builtin_readcyclecounter() - t0;
@@ -1371,13 +1395,13 @@ extern "C" int ru_dbg_sb2_prof(unsigned long long* out8) {
 }
 #endif
 
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false>
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, bool ADD = false>
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static PerDevice attr_done;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         attr_done.set();
     }
@@ -1386,7 +1410,8 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
 }
@@ -1395,6 +1420,7 @@ static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     if constexpr (IN16 && OUT16) {
         if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true>(a, s);
     }
+    if (a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, true>(a, s);
     return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false>(a, s);
 }
 bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W) { return sb_use_v2(sb_choose(N, Cout, D, H, W)); }
@@ -1453,7 +1479,9 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_sb: C16 input needs Cin %% 16 == 0");
     RU_REQUIRE(!a.in_s16 || (a.in_c16 && !a.in_scale), "conv3_sb: a split-form input is voxel-major and has no fused transform");
     RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
-    const SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
+    SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
+    RU_REQUIRE(!(a.bias && a.out_c16 && a.stat_partials), "conv3_sb: bias + voxel-major output + statistics is not a path of the network");
+    if (sb_use_v2(c) && a.bias && a.out_c16) c = SBChoice{2, 8};      // (no engine path: the persistent kernel has the bias for NCDHW output only)
     if (sb_use_v2(c)) {
         if (a.in_c16) return a.out_c16 ? sb2_cfg<4, 8, true, true>(a, s) : sb2_cfg<4, 8, true, false>(a, s);
         return a.out_c16 ? sb2_cfg<4, 8, false, true>(a, s) : sb2_cfg<4, 8, false, false>(a, s);

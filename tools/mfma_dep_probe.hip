@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512) void probe_steps(float* out, int iters) {
     for (int i = threadIdx.x; i < 5120; i += blockDim.x) buf[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     __syncthreads();
     constexpr int NS = AHEAD + 1;
+    const unsigned long long t_start = __builtin_readcyclecounter();
     bf16x8 fh[NS], fl[NS], w[6];
     for (int i = 0; i < NS; ++i) { fh[i] = __builtin_bit_cast(bf16x8, buf[lane + i * 64]); fl[i] = __builtin_bit_cast(bf16x8, buf[lane + 2176 + i * 64]); }
     for (int i = 0; i < 6; ++i) w[i] = __builtin_bit_cast(bf16x8, buf[lane + 512 + i * 64]);
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512) void probe_steps(float* out, int iters) {
     float sum = 0.f;
     for (int i = 0; i < 3; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (sum == 12345.678f) out[threadIdx.x] = sum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(out)[512] = __builtin_readcyclecounter() - t_start;   // s_memtime ticks of this wave
 }
 template <int NM, int AHEAD>
 static void run_steps(int threads, float* out) {
@@ -96,7 +98,10 @@ static void run_steps(int threads, float* out) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double wps = threads / 256.0, mf = 12.0 * NM * iters * wps;
-    printf("steps of %d MFMAs, fragment pair read %d steps ahead, waves/SIMD %.0f: %6.2f ns per MFMA per SIMD\n", NM, AHEAD, wps, ms * 1e6 / mf);
+    unsigned long long ticks = 0;
+    (void)hipMemcpy(&ticks, reinterpret_cast<unsigned long long*>(out) + 512, 8, hipMemcpyDeviceToHost);
+    printf("steps of %d MFMAs, fragment pair read %d steps ahead, waves/SIMD %.0f: %6.2f ns per MFMA per SIMD; s_memtime: %.1f ticks per MFMA of one wave, %.3f ticks per ns\n",
+           NM, AHEAD, wps, ms * 1e6 / mf, (double)ticks / (12.0 * NM * iters), (double)ticks / (ms * 1e6));
 }
 
 template <int NACC, int BIG, int READS>
