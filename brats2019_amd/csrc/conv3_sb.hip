@@ -161,8 +161,9 @@ __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, 
 // Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
 // GroupNorm-backward sums are taken on the way: u = y*k1 + k2 (= sign(gamma)*xhat), dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
 __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& yv, const f32x4 (&kc)[3], float slope,
-                                                f32x4& s1, f32x4& s2) {
+                                                f32x4& s1, f32x4& s2, const float4* radd = nullptr) {
     if (!(o.ok && yy < a.H)) return;
+    if (radd) v += f32x4{radd->x, radd->y, radd->z, radd->w};          // residual first: the sums are those of the STORED gradient
     const f32x4 u = f32x4{yv.x, yv.y, yv.z, yv.w} * kc[0] + kc[1];
     const f32x4 vs = v * slope;
     f32x4 dh;
@@ -813,7 +814,6 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // per-row operand of the epilogue (residual `add`, or BST: the forward tensor y): loaded three rows ahead of the store from a
         // clamped address; without such an operand every lane reads one dummy line and the value is dropped by a select (no branch
         // in the MFMA stream)
-        const float* rsrc = BST ? a.bst_y : a.add;
         constexpr bool has_r = BST || ADD;
         // GroupNorm statistics: ONE partial per (workgroup, consumer wave, sample) -- the tiles of a workgroup come in increasing
         // order, so a sample's tiles are consecutive; the partial is flushed when the sample changes and the samples this
@@ -881,14 +881,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             fl[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{}) + 2 * HVOLP]);
             fh[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{})]);
             fl[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{}) + 2 * HVOLP]);
-            float4 radd[4];                              // tile i uses slot i % 4: loaded at row i, consumed at row i + 3
-#pragma unroll
-            for (int j = 0; j < 4; ++j) radd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 radd[3], rbst[3];                     // per-row operands (residual / BST forward tensor): tile i uses slot i % 3, loaded at row i + 1,
+#pragma unroll                                           // consumed at row i + 3
+            for (int j = 0; j < 3; ++j) { radd[j] = make_float4(0.f, 0.f, 0.f, 0.f); rbst[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
             auto store_tile = [&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 if constexpr ((dbg & 8) != 0) { dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; return; }   // ablation: the MFMAs stay, the row is dropped
-                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], radd[i & 3], kc, a.bst_slope, s1, s2);
-                else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i & 3], s1, s2);
+                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
+                else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
             };
             static_for<NSTEP>([&](auto S) {
                 constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % 3, nxt = (s + 2) % 3;
@@ -950,9 +950,11 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 }
                 if (!fetched) fetch();
                 // ---- row bookkeeping between the MFMAs
-                if constexpr (has_r && f == 0 && r < MT) {  // epilogue operand of tile r, three rows ahead of its store (unconditional, clamped address)
-                    const int yy = ybase + r;
-                    radd[r & 3] = *reinterpret_cast<const float4*>(rsrc + ((last && so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0));
+                if constexpr (has_r && f == 0 && r >= 1 && r <= MT) {   // epilogue operands of tile r-1, two rows ahead of its store (unconditional, clamped address)
+                    const int yy = ybase + r - 1;
+                    const size_t ri = (last && so.ok && yy < H) ? sb_out_index<OUT16>(a, so, yy) : 0;
+                    if constexpr (ADD) radd[(r - 1) % 3] = *reinterpret_cast<const float4*>(a.add + ri);
+                    if constexpr (BST) rbst[(r - 1) % 3] = *reinterpret_cast<const float4*>(a.bst_y + ri);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (f == 1 && r >= 3) {           // tile r-3 was completed by row r-1: its MFMAs have drained by now
@@ -1418,6 +1420,7 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
 template <int TZ, int TY, bool IN16, bool OUT16>
 static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     if constexpr (IN16 && OUT16) {
+        if (a.bst_y && a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true, true>(a, s);
         if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true>(a, s);
     }
     if (a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, true>(a, s);
@@ -1464,9 +1467,9 @@ static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
 
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!(a.sigmoid && a.out_c16), "conv3_sb: the fused sigmoid exists for NCDHW output only");
-    RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && (a.in_c16 || a.in_c4) && a.out_c16 && !a.add && !a.bias && !a.sigmoid &&
+    RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && (a.in_c16 || a.in_c4) && a.out_c16 && !a.bias && !a.sigmoid && (!a.add || !a.in_c4) &&
                             conv3_sb_bst_usable(a.N, a.Cout, a.D, a.H, a.W)),
-               "conv3_sb: fused GroupNorm-backward statistics need the persistent voxel-major kernel, a partial buffer and no bias / residual / activation");
+               "conv3_sb: fused GroupNorm-backward statistics need the persistent voxel-major kernel, a partial buffer and no bias / activation");
     if (a.in_c4) {
         RU_REQUIRE(a.Cin <= 4 && !a.in_scale, "conv3_sb: the 4-channel kernel takes Cin <= 4 and no fused input transform");
         RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");

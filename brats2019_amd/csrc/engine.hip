@@ -606,8 +606,13 @@ static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, 
 // Residual backward: dout -> d(xprev); parameter gradients into `grads`
 // `join`: a second gradient arriving at the block input (the skip connection of a down block); *joined tells whether it was added here
 // part2 / nblk2: the GroupNorm-backward sums of norm2 were taken by the kernel that produced `dout` (Conv3Args::bst_*)
+// nx: the GroupNorm(+activation) the gradient this block produces (dx, for a block without down-sampling conv) enters NEXT -- norm2 of the
+//     previous block of the level, or norm_input: its backward sums are then taken in the epilogue of the data-gradient conv of conv1
+//     (which also adds the skip gradient) and handed back through nx->part / nx->nblk
+struct GNNext { const float* y; const float* k; float slope; float* part; int nblk; };
 static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hipStream_t s, const BlockSave& sv, const float* dout,
-                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr, const float* part2 = nullptr, int nblk2 = 0) {
+                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr, const float* part2 = nullptr, int nblk2 = 0,
+                     GNNext* nx = nullptr) {
     if (joined) *joined = false;
     const BlockP& bp = *sv.bp;
     const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
@@ -650,6 +655,12 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
     d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = c16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
+    if (nx) { nx->part = nullptr; nx->nblk = 0; }
+    if (nx && fuse1 && bp.down < 0) {                   // same shape and kernel choice as d2: dx = dout + dgrad(conv1) IS the gradient entering nx
+        nx->nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
+        nx->part = A.alloc((size_t)N * C * nx->nblk * 2);
+        d1.bst_y = nx->y; d1.bst_k = nx->k; d1.bst_slope = nx->slope; d1.stat_partials = nx->part;
+    }
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
     // down-sampling conv backward (Appendix A2): 1x1 over the space-to-depth view
@@ -800,9 +811,15 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // encoder levels, deepest first; the skip gradient joins at each level's input
     for (int i = depth - 2; i >= 0; --i) {
         bool joined = false;
+        float* pnext = nullptr;                                  // sums of the NEXT block's norm2, taken by this block's last conv
+        int nnext = 0;
         for (int j = (int)h->enc_s[i].size() - 1; j >= 0; --j) {
-            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr);
+            GNNext nx{nullptr, nullptr, kSlope, nullptr, 0};
+            if (j >= 1 && h->enc_s[i][j - 1].g2.k) { nx.y = h->enc_s[i][j - 1].y2; nx.k = h->enc_s[i][j - 1].g2.k; }
+            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr, pnext, nnext,
+                           (nx.y || A.dry) && j >= 1 ? &nx : nullptr);
             if (rc) return rc;
+            pnext = nx.part; nnext = nx.nblk;
         }
         if (!joined) {
             float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
@@ -810,13 +827,20 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             dcur = sum;
         }
     }
+    float* pfirst = nullptr;
+    int nfirst = 0;
     for (int j = (int)h->first_s.size() - 1; j >= 0; --j) {
-        rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur);
+        // the gradient a first-level block produces enters norm2 of the block before it, or (j = 0) norm_input (no activation: slope 1)
+        GNNext nx{nullptr, nullptr, j >= 1 ? kSlope : 1.0f, nullptr, 0};
+        if (j >= 1) { nx.y = h->first_s[j - 1].y2; nx.k = h->first_s[j - 1].g2.k; }
+        else { nx.y = h->y0; nx.k = h->g0.k; }
+        rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur, nullptr, nullptr, pfirst, nfirst, (nx.k || A.dry) ? &nx : nullptr);
         if (rc) return rc;
+        pfirst = nx.part; nfirst = nx.nblk;
     }
     // norm_input (no activation: slope 1) and conv_input
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0));
+    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst);
     if (rc) return rc;
     rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16);
     if (rc) return rc;

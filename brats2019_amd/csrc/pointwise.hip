@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const Conv1Args a, int 
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_pw{0.f, 0.f, 0.f, 0.f};
     const float* x0 = a.x0 + (size_t)n * a.C0 * V;
     const float* x1 = a.x1 ? a.x1 + (size_t)n * a.C1 * V : a.x0;
-#pragma unroll 4
-    for (int c0 = 0; c0 < Ct; c0 += 4) {
+    auto cstep = [&](int c0) __attribute__((always_inline)) {
         const int c = c0 + k;
         const bool cok = c < Ct;
         const int cc = cok ? c : Ct - 1;
@@ -116,7 +115,10 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const Conv1Args a, int 
         for (int t = 0; t < 4; ++t) bv[t] = xp[vb[t]];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
-    }
+    };
+    int c0 = 0;                                           // four K-groups per trip, written out (the runtime-bound loop refused `#pragma unroll 4`)
+    for (; c0 + 12 < Ct; c0 += 16) { cstep(c0); cstep(c0 + 4); cstep(c0 + 8); cstep(c0 + 12); }
+    for (; c0 < Ct; c0 += 4) cstep(c0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const size_t v = v0 + 16 * t + r;

@@ -397,8 +397,9 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb) acc[t][cb] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
     const int CBf_in = nkb0 >> 3;                        // gather: channel blocks of the fine input tensor
-#pragma unroll 2
-    for (int kb = 0; kb < nkb; ++kb) {
+    // two K-blocks per trip (written out: `#pragma unroll 2` on the runtime-bound loop was refused by the optimizer): the loads of the second
+    // block are in flight under the first block's MFMAs
+    auto kstep = [&](int kb) __attribute__((always_inline)) {
         float4 xb[4];
         if constexpr (S2D == 1) {
             const int tap = kb / CBf_in, cbf = kb - tap * CBf_in;
@@ -422,7 +423,10 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
                 acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xb[t].w, acc[t][cb], 0, 0, 0);
             }
         }
-    }
+    };
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) { kstep(kb); kstep(kb + 1); }
+    if (kb < nkb) kstep(kb);
     const int CBf_out = CBo >> 3;                        // scatter: channel blocks of the fine output tensor
 #pragma unroll
     for (int t = 0; t < 4; ++t) {

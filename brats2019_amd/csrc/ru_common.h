@@ -63,7 +63,8 @@ struct Conv3Args {
     int in_c16, out_c16;
     int in_s16;              // x is C16 in SPLIT form (see gn_bwd_apply16_launch): the staging copies hi/lo packets, no conversion, no transform
     int in_c4;               // x is a [N][D][H][W][4] copy (pad_to_c4) of a tensor with Cin <= 4: conv3_sb2c4_kernel, wfrag from conv3_sb4_pack_weights
-    // Fused GroupNorm-BACKWARD statistics (persistent split-bf16 kernel, C16 in and out, no bias / add / sigmoid): this conv's output is
+    // Fused GroupNorm-BACKWARD statistics (persistent split-bf16 kernel, C16 in and out, no bias / sigmoid; a residual `add` is part of the
+    // output and therefore of the sums): this conv's output is
     // the gradient d w.r.t. the activation that followed a GroupNorm of `bst_y` (same shape as y).  The epilogue then writes, instead
     // of (sum, sumsq), the partial sums the GroupNorm backward needs -- S1 = sum dh, S2' = sum dh*u with u = y*k1 + k2 (= sign(gamma) *
     // xhat), dh = u > thr ? d : d*bst_slope -- to stat_partials, saving the separate reduce pass over (y, d).  bst_k: [N][3][Cout] =
