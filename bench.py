@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl == RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--transport", default="torch", choices=["torch", "rccl"],
+                    help="collectives of the step: torch.distributed (nccl == RCCL; default) or the library's own ru_allreduce on the kernels' stream")
     ap.add_argument("--shared-gpu", action="store_true", help="plumbing test: let every rank use cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
@@ -268,7 +270,8 @@ def main():
 
     backend = P.HipBackend(device=dev, precision=args.precision)
     flat = init_params(backend)                      # same seed on every rank: identical replicas
-    stepper = P.DataParallelStep(backend, flat)
+    comm = P.RcclComm(rank, world) if (args.transport == "rccl" and world > 1) else None
+    stepper = P.DataParallelStep(backend, flat, comm=comm)
     x, g = synth(args.batch, args.size, 1000 + rank, dev)
 
     last = {}

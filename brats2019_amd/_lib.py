@@ -62,6 +62,12 @@ SIGNATURES = {
     "ru_unet_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "ru_unet_backward": (_i, [_vp] * 6),
     "ru_unet_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ru_comm_unique_id": (_i, [_vp]),
+    "ru_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "ru_comm_destroy": (_i, [_vp]),
+    "ru_comm_rank": (_i, [_vp]),
+    "ru_comm_world": (_i, [_vp]),
+    "ru_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),

@@ -20,7 +20,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libresunet_hip.so")
-SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "wgrad_sb.hip", "wgrad_tr.hip", "pointwise.hip", "pointwise_c16.hip", "engine.hip"]
+SOURCES = ["conv3_f32.hip", "conv3_sb.hip", "wgrad_f32.hip", "wgrad_sb.hip", "wgrad_tr.hip", "pointwise.hip", "pointwise_c16.hip", "engine.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(CSRC, "conv3_epilogue.hpp"), os.path.join(CSRC, "pw_helpers.hpp"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -66,7 +66,7 @@ def build(force=False, verbose=True, devtools=None):
         if warn.strip() and verbose:
             sys.stderr.write(warn)
     if force or _stale(lib, objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

@@ -76,12 +76,60 @@ class HipBackend:
             ops.adam_amsgrad_step(flat[a:b], grads[a:b], m[a:b], v[a:b], vmax[a:b], step, lr, betas, eps, weight_decay)
 
 
+class RcclComm:
+    """The two collectives of a step through the C-ABI (`ru_comm_*`, `ru_allreduce`): RCCL all-reduce enqueued on torch's current HIP
+    stream, in place -- no torch.distributed call in the data path.  The 128-byte RCCL unique id travels once, at set-up: rank 0 makes
+    it, `torch.distributed` (any backend, e.g. the gloo group torchrun's environment gives) or the caller broadcasts it."""
+
+    def __init__(self, rank, world, unique_id=None, group=None):
+        import ctypes as C
+        from . import _lib as L
+        L.require_gpu()
+        lib = L.load()
+        self.rank, self.world = int(rank), int(world)
+        if unique_id is None:
+            buf = (C.c_char * 128)()
+            if self.rank == 0:
+                L.check(lib.ru_comm_unique_id(C.cast(buf, C.c_void_p)), "ru_comm_unique_id")
+            box = [bytes(buf)]
+            if self.world > 1:
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise RuntimeError("RcclComm: pass unique_id, or initialise torch.distributed so that rank 0 can broadcast it")
+                dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        self.unique_id = bytes(unique_id)
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(self.unique_id, 128)
+        L.check(lib.ru_comm_init(C.byref(h), C.cast(idbuf, C.c_void_p), self.rank, self.world), "ru_comm_init")
+        self.h = h
+
+    def all_reduce(self, t):
+        """in-place SUM over the ranks of a contiguous float32 / float64 device tensor, on the current stream"""
+        from . import _lib as L
+        if t.dtype not in (torch.float32, torch.float64):
+            raise TypeError("RcclComm.all_reduce: float32 or float64, got %s" % t.dtype)
+        L.check(L.load().ru_allreduce(self.h, L.ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, L.stream()), "ru_allreduce")
+        return t
+
+    def close(self):
+        from . import _lib as L
+        if getattr(self, "h", None):
+            L.load().ru_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DataParallelStep:
     """forward + criterion + backward + gradient all-reduce + Adam(amsgrad) + StepLR, hyper-parameters of
     main.py:126-142 (lr 2e-5, wd 1e-6, amsgrad, StepLR(16000, 0.5) stepped per iteration, train.py:220-223)."""
 
     def __init__(self, backend, flat_params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6,
-                 step_size=16000, gamma=0.5, bg_weight=1e-2, priority=1.0, process_group=None):
+                 step_size=16000, gamma=0.5, bg_weight=1e-2, priority=1.0, process_group=None, comm=None):
         self.backend = backend
         self.flat = flat_params
         self.grads = torch.zeros_like(flat_params)
@@ -93,9 +141,13 @@ class DataParallelStep:
         self.bg_weight, self.priority = bg_weight, priority
         self.group = process_group
         self.global_step = 0
-        self.distributed = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(self.group) if self.distributed else 1
-        self.rank = dist.get_rank(self.group) if self.distributed else 0
+        self.comm = comm                       # RcclComm: the collectives go through ru_allreduce on the kernels' stream
+        if comm is not None:
+            self.distributed, self.world, self.rank = True, comm.world, comm.rank
+        else:
+            self.distributed = dist.is_available() and dist.is_initialized()
+            self.world = dist.get_world_size(self.group) if self.distributed else 1
+            self.rank = dist.get_rank(self.group) if self.distributed else 0
 
     @staticmethod
     def shard(batch_size, rank, world):
@@ -115,7 +167,7 @@ class DataParallelStep:
         probs = b.forward(self.flat, x_shard, training=True)
         sums = b.criterion_sums(probs, target_shard, self.bg_weight)
         if self.distributed:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(sums)
         count = float(probs.numel()) * self.world
         loss, dice, bce = b.criterion_losses(sums, count, self.priority)
         dprobs = b.criterion_grad(probs, target_shard, sums, count, self.bg_weight, self.priority)
@@ -126,11 +178,17 @@ class DataParallelStep:
             segs = getattr(b, "live_segments", None)
             if segs and sum(e - a for a, e in segs) < 0.9 * self.grads.numel():
                 for a, e in segs:
-                    dist.all_reduce(self.grads[a:e], op=dist.ReduceOp.SUM, group=self.group)
+                    self._all_reduce(self.grads[a:e])
             else:
-                dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(self.grads)
         self.last_probs = probs
         return loss, dice, bce
+
+    def _all_reduce(self, t):
+        if self.comm is not None:
+            self.comm.all_reduce(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, x_shard, target_shard):
         loss, dice, bce = self.loss_and_grads(x_shard, target_shard)

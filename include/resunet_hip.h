@@ -178,6 +178,25 @@ int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, floa
  * idx-th executed GroupNorm (execution order) into DEVICE buffers.  Returns number of GN layers if idx<0. */
 int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream);
 
+/* ---------------------------------------------------------------- data-parallel collectives (replaces nn.DataParallel, main.py:61)
+ * One process per GPU, full replica each, minibatch sharded over the ranks.  Per step two SUM all-reduces keep the result
+ * identical to the reference's global-batch step: the [2C+1] float64 criterion sums between ru_criterion_sums and ru_criterion_grad
+ * (Dice_loss_joint sums over the GLOBAL batch, loss.py:114-115), and the live runs of the flat float32 gradient buffer after
+ * ru_unet_backward (SUM, not mean).  ru_allreduce enqueues ncclAllReduce (RCCL over xGMI) on `stream` -- the stream of the kernels --
+ * in place; no host synchronisation.  librccl is bound at run time: the library loads without it, these calls then fail with RU_EHIP.
+ * Set-up: rank 0 calls ru_comm_unique_id and hands the RU_COMM_ID_BYTES bytes to every rank out of band (the host mirror broadcasts
+ * them through torch.distributed or a file); every rank then calls ru_comm_init with its HIP device current.  */
+typedef struct ru_comm* ru_comm_t;
+#define RU_COMM_ID_BYTES 128
+#define RU_DT_F32 0
+#define RU_DT_F64 1
+int ru_comm_unique_id(void* id_out /* RU_COMM_ID_BYTES host bytes */);
+int ru_comm_init(ru_comm_t* out, const void* id, int rank, int world);
+int ru_comm_destroy(ru_comm_t c);
+int ru_comm_rank(ru_comm_t c);
+int ru_comm_world(ru_comm_t c);
+int ru_allreduce(ru_comm_t c, void* buf, size_t count, int dtype, ru_stream_t stream);
+
 /* ---------------------------------------------------------------- inference post-processing (test.py:115-159)
  * ru_tta_merge: `probs` holds K predictions [K][C][D][H][W] of flipped copies of one volume; bits 3k..3k+2 of `flips` say
  * which axes (bit0 D, bit1 H, bit2 W) copy k was reversed along (test.py:117-120 uses {none, D, H, D+H}).  Each prediction

@@ -34,7 +34,7 @@ def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(0)
     if world > 1 or backend == "nccl":
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo" if backend == "rccl-direct" else backend, rank=rank, world_size=world)
     from brats2019_amd import parallel as P
     x = torch.from_numpy(O.make_input(GLOBAL_BATCH, *DHW, seed=SEED))
     g = torch.from_numpy(O.make_target(GLOBAL_BATCH, *DHW, seed=SEED))
@@ -46,15 +46,22 @@ def main():
         flat = be.new_flat()
         for k, v in be.engine.layout.views(flat).items():
             v.copy_(torch.from_numpy(params[k]))
-        st = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5)
+        comm = P.RcclComm(rank, world) if backend == "rccl-direct" else None      # ru_comm_* / ru_allreduce instead of torch.distributed
+        st = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm)
         sl = P.DataParallelStep.shard(GLOBAL_BATCH, rank, world)
         xs, gs = x[sl].cuda(), g[sl].cuda()
         l1, d1, b1 = st.loss_and_grads(xs, gs)
         res.update(loss=float(l1), dice=float(d1), bce=float(b1), grads=st.grads.cpu().numpy())
-        st2 = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5)
+        st2 = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm)
         la = float(st2.step(xs, gs)[0])
         lb = float(st2.step(xs, gs)[0])
         res.update(l_step1=la, l_step2=lb, weights=flat.cpu().numpy())
+        if comm is not None:
+            probe32 = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+            probe64 = torch.arange(7, dtype=torch.float64, device="cuda") + 0.25
+            comm.all_reduce(probe32); comm.all_reduce(probe64)
+            res.update(probe32=probe32.cpu().numpy(), probe64=probe64.cpu().numpy(), comm_world=comm.world)
+            comm.close()
     elif mode == "trainer":
         from brats2019_amd import model as M, loss as L, train as TR, metrics as MT
         net = M.UNet(**CFG)

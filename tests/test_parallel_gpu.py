@@ -94,3 +94,17 @@ def test_rccl_transport_executes_with_one_rank(tmp_path):
     ref = {k: v.copy() for k, v in ref.items()}
     (got,) = _launch("step", tmp_path, 1, backend="nccl")
     assert float(got["loss"]) == float(ref["loss"]) and np.array_equal(got["grads"], ref["grads"]) and np.array_equal(got["weights"], ref["weights"])
+
+
+@pytest.mark.timeout(900)
+def test_library_rccl_entry_points_execute_with_one_rank(tmp_path):
+    """ru_comm_unique_id / ru_comm_init / ru_allreduce (include/resunet_hip.h): the step's collectives through the library's own RCCL
+    binding on the kernels' stream, no torch.distributed call in the data path.  One rank (RCCL refuses two ranks on one device):
+    the all-reduce is the identity and the step must equal the run without any communicator."""
+    (ref,) = _launch("step", tmp_path, 1)
+    ref = {k: v.copy() for k, v in ref.items()}
+    (got,) = _launch("step", tmp_path, 1, backend="rccl-direct")
+    assert int(got["comm_world"]) == 1
+    np.testing.assert_array_equal(got["probe32"], np.arange(1000, dtype=np.float32) * 0.5)
+    np.testing.assert_array_equal(got["probe64"], np.arange(7, dtype=np.float64) + 0.25)
+    assert float(got["loss"]) == float(ref["loss"]) and np.array_equal(got["grads"], ref["grads"]) and np.array_equal(got["weights"], ref["weights"])
