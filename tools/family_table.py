@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Derived per-kernel-family table for profiles/: for the 3x3x3 conv (forward kernel) and its weight gradient at the four level shapes of
+the training step (batch 4): average launch time, algorithmic HBM GB/s, counter HBM traffic, MFMA-busy %, roofline fractions.
+
+Runs ON THE GPU BOX (tools/family_table.py > gpurun_out/<tag>_family_table.txt).  Every number comes from rocprofv3 on tools/conv_probe.py:
+one --kernel-trace pass for the time, separate --pmc passes (never combined with tracing) for SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE,
+FETCH_SIZE and WRITE_SIZE.  Counter conventions (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE counts a
+128-byte request of a wide streaming read as 64 bytes, so it is doubled; GRBM_GUI_ACTIVE is summed over the 8 XCDs (divide by 8 for the
+kernel's cycles); MFMA-busy % = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)."""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROBE = os.path.join(ROOT, "tools", "conv_probe.py")
+SHAPES = [(16, 128), (32, 64), (64, 32), (128, 16)]
+N = 4
+BF16_PEAK, HBM_PEAK = 2.5e15, 8.0e12
+
+
+def run(tag, extra, args):
+    out = "/tmp/ft_%s" % tag
+    subprocess.run(["rm", "-rf", out])
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(["rocprofv3"] + extra + ["--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, PROBE] + args,
+                   cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    return out
+
+
+def kernel_rows(out, pattern, want):
+    rows = []
+    for f in glob.glob(out + "/**/*%s.csv" % pattern, recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if want(r)]
+    return rows
+
+
+def main():
+    lines = ["# kernel family table (tools/family_table.py): batch %d, voxel-major tensors, split-bf16 x3; peaks: %.1f PF dense bf16, %.1f TB/s HBM" % (N, BF16_PEAK / 1e15, HBM_PEAK / 1e12),
+             "# kind   shape        kernel                          avg_us  alg_GB  alg_GB/s  hbm_frac  counter_GB (fetch x2 + write)  MFMA_busy%%  exec_MFMA_TF  exec_frac"]
+    for kind, kpat, flags in (("conv fwd", "conv3_sb2_kernel", "3"), ("wgrad", "wgrad3_tz_kernel", "3")):
+        for c, size in SHAPES:
+            args = ["fwd" if kind == "conv fwd" else "wgrad", "bf16x3", str(N), str(c), str(size), "6", flags]
+            want = lambda r, kpat=kpat: kpat in r.get("Kernel_Name", r.get("Name", ""))
+            tr = kernel_rows(run("t", ["--kernel-trace"], args), "kernel_trace", want)
+            if not tr:
+                continue
+            durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr)
+            us = sum(durs[1:]) / max(1, len(durs) - 1) if len(durs) > 1 else durs[0]
+            name = tr[0]["Kernel_Name"].replace("void ", "").split("(")[0]
+            cnt = {}
+            for cs in (["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]):
+                for r in kernel_rows(run("c", ["--pmc"] + cs, args), "counter_collection", want):
+                    cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            mean = lambda k: sum(cnt[k]) / len(cnt[k]) if cnt.get(k) else float("nan")
+            vox = N * size ** 3
+            alg_bytes = 2.0 * c * vox * 4 if kind == "conv fwd" else 2.0 * c * vox * 4      # conv: x + y; weight gradient: x + dy (fp32)
+            flops = 2.0 * 27 * c * c * vox
+            exec_tf = flops * 3 * 28 / 27 / (us * 1e-6) / 1e12
+            counter_gb = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024 / 1e9
+            busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
+            lines.append("%-8s %3dch %3d^3  %-30s %7.1f  %6.3f  %8.0f  %8.3f  %10.3f  %27.1f  %12.0f  %9.3f" % (
+                kind, c, size, name[:30], us, alg_bytes / 1e9, alg_bytes / (us * 1e-6) / 1e9, alg_bytes / (us * 1e-6) / HBM_PEAK, counter_gb, busy,
+                exec_tf, exec_tf * 1e12 / BF16_PEAK))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
