@@ -140,12 +140,19 @@ __device__ __forceinline__ void sb_out_tile(const Conv3Args& a, const SbOut& o, 
 // The same for the persistent kernel, with what a row needs decided at COMPILE time: every VALU instruction of the epilogue sits in the
 // consumer's stream between its MFMAs (~25 cycles each there), so a voxel-major row without residual is statistics + store and
 // nothing else.  The bias exists for NCDHW output only (the head conv; voxel-major output with a bias takes the one-stage kernel).
+#ifdef RU_SB2_DBG
+constexpr int kSb2RowDbg = RU_SB2_DBG;      // ablation builds only: 256 = no statistics math, 512 = no store instruction
+#else
+constexpr int kSb2RowDbg = 0;
+#endif
 template <bool OUT16, bool HAS_R>
 __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, f32x4& s1, f32x4& s2) {
     if (!(o.ok && yy < a.H)) return;
     if constexpr (!OUT16) v += f32x4{o.bias.x, o.bias.y, o.bias.z, o.bias.w};
     if constexpr (HAS_R) v += f32x4{radd.x, radd.y, radd.z, radd.w};
-    if constexpr (OUT16) {
+    if constexpr (OUT16 && (kSb2RowDbg & 256)) {
+        s1[0] += v[0];                            // keeps the accumulator alive with one VALU instruction
+    } else if constexpr (OUT16) {
         s1 += v;
         s2 += v * v;
     } else {
@@ -156,6 +163,7 @@ __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, 
             for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v[r]));
         }
     }
+    if constexpr ((kSb2RowDbg & 512) != 0) { s2[0] += v[1] + v[2] + v[3]; return; }
     *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
