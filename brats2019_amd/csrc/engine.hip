@@ -621,6 +621,9 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const bool c16 = h->c16;
     // 16-channel level (its kernels are memory-bound): the GroupNorm-backward apply is computed by the weight gradient's dy staging
     // from (y, d, coefficients) and published in split form for the data-gradient conv that follows -- no apply pass over (y, d)
+    // (16 channels only.  The two-block kernel wgrad3_tz<2,0,3> exists and fits its registers since the constants of a block are fetched when
+    // the block is converted, but at 32 channels it costs what it saves: 203 us against 131 us + a 70 us apply pass, same box,
+    // profiles/r02_notes.txt -- every input-channel group recomputes the apply while staging, and the producers become the slower side.)
     const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && (h->fusion & RU_FUSE_GN_BWD_APPLY);
     float *coef2 = nullptr, *coef1 = nullptr;
     int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2,

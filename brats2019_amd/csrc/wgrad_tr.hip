@@ -187,6 +187,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         // issue() is called for items 0, 1, 2, ... in order: (column, step) advance as counters and the column origin is recomputed
         // once per column, not with four integer divisions per item in this wave's VALU stream
         int is_k = 0, is_n = 0, is_y0 = 0, is_x0 = 0, is_ring0 = 0;
+        auto load_gc = [&](int n, int q) __attribute__((always_inline)) {          // (scale, shift, 3 coefficients) of this thread's 8 channels of output block q
+            if constexpr (DS == 3) {
+                const size_t go = (size_t)n * a.Cout + (og * OT + q) * 16 + hsel * 8;
+                gc4[0] = *reinterpret_cast<const float4*>(a.gb_scale + go); gc4[1] = *reinterpret_cast<const float4*>(a.gb_scale + go + 4);
+                gc4[2] = *reinterpret_cast<const float4*>(a.gb_shift + go); gc4[3] = *reinterpret_cast<const float4*>(a.gb_shift + go + 4);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) gc4[4 + t] = *reinterpret_cast<const float4*>(a.gb_coef + go * 3 + 4 * t);
+            }
+        };
         auto issue = [&](int item) {
             if (is_k == 0) item_origin(item, is_n, is_k, is_y0, is_x0, is_ring0);
             const int n = is_n, k = is_k, y0 = is_y0, x0 = is_x0, ring0 = is_ring0;
@@ -255,13 +264,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
                 sh4[0] = *reinterpret_cast<const float4*>(a.in_shift + cofs); sh4[1] = *reinterpret_cast<const float4*>(a.in_shift + cofs + 4);
             }
-            if constexpr (DS == 3) {                     // OT == 1: one output block
-                const size_t go = (size_t)n * a.Cout + og * 16 + hsel * 8;
-                gc4[0] = *reinterpret_cast<const float4*>(a.gb_scale + go); gc4[1] = *reinterpret_cast<const float4*>(a.gb_scale + go + 4);
-                gc4[2] = *reinterpret_cast<const float4*>(a.gb_shift + go); gc4[3] = *reinterpret_cast<const float4*>(a.gb_shift + go + 4);
-#pragma unroll
-                for (int t = 0; t < 6; ++t) gc4[4 + t] = *reinterpret_cast<const float4*>(a.gb_coef + go * 3 + 4 * t);
-                st_n = n; st_y0 = y0; st_x0 = x0;
+            if constexpr (DS == 3) {
+                if constexpr (OT == 1) load_gc(n, 0);    // one output block: its constants travel with the loads (two blocks: fetched per block
+                st_n = n; st_y0 = y0; st_x0 = x0;        // in store(), 40 registers live instead of 80 held across the whole item)
             }
         };
         auto store = [&](char* dbuf) {
@@ -306,6 +311,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
                 const int q = r / RPB, p = (r - q * RPB) * 128 + pslot;
+                if constexpr (DS == 3 && OT > 1) {
+                    if (r % RPB == 0) load_gc(st_n, q);  // (r is a compile-time constant after unrolling)
+                }
                 const bool ok = (md >> r) & 1u;
                 const float f[8] = {vd[r][0].x, vd[r][0].y, vd[r][0].z, vd[r][0].w, vd[r][1].x, vd[r][1].y, vd[r][1].z, vd[r][1].w};
                 float t[8];
@@ -458,14 +466,8 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
     if (a.gb_y) {
         RU_REQUIRE(!a.x_c4 && !a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && a.gb_out,
                    "wgrad3_tr: the fused GroupNorm-backward apply needs voxel-major x and all of its operands");
-        WTRChoice c1 = c;                                // one output block per workgroup: the second block's constants and streams do not fit the registers
-        c1.ot = 1;
-        c1.ngroups = (a.Cout / 16) * c1.ncg;
-        long nbx = 256 / c1.ngroups;
-        if (nbx < 1) nbx = 1;
-        if (nbx > c.nbx) nbx = c.nbx;                    // the workspace was sized for c.nbx partials
-        c1.nbx = (int)nbx;
-        return wtz_cfg<1, 0, 3>(a, c1, s);
+        if (c.ot == 2) return wtz_cfg<2, 0, 3>(a, c, s);   // two output blocks per workgroup: the constants of a block are fetched when it is converted
+        return wtz_cfg<1, 0, 3>(a, c, s);
     }
     const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
     if (c.ot == 2) {
