@@ -60,6 +60,19 @@ def main():
             exec_tf = flops * 3 * 28 / 27 / (us * 1e-6) / 1e12
             counter_gb = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024 / 1e9
             busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
+            if kind == "conv fwd" and c == 16 and "--json" in sys.argv:
+                import json
+                dst = sys.argv[sys.argv.index("--json") + 1]
+                old = json.load(open(dst)) if os.path.exists(dst) else {}
+                hist = old.get("history", {})
+                if "hbm_bytes_per_launch" in old:
+                    hist["round 1 consumer (one A fragment per M-tile and K-step)"] = {k: old[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch") if k in old}
+                json.dump({"kernel": "conv3_sb2_kernel<4,8,C16 in,C16 out,single chunk> (3x3x3 conv 16->16, split-bf16 x3, batch 4 x 128^3, voxel-major tensors)",
+                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; round 2",
+                           "FETCH_SIZE_KB": mean("FETCH_SIZE"), "WRITE_SIZE_KB": mean("WRITE_SIZE"),
+                           "correction": "FETCH_SIZE x2 for 16-byte-per-lane streaming reads on gfx950 (guide); WRITE_SIZE uncorrected",
+                           "hbm_bytes_per_launch": int((2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024), "algorithmic_bytes_per_launch": int(alg_bytes),
+                           "avg_launch_us_in_trace": round(us, 1), "mfma_busy_pct": round(busy, 1), "history": hist}, open(dst, "w"), indent=1)
             lines.append("%-8s %3dch %3d^3  %-30s %7.1f  %6.3f  %8.0f  %8.3f  %10.3f  %27.1f  %12.0f  %9.3f" % (
                 kind, c, size, name[:30], us, alg_bytes / 1e9, alg_bytes / (us * 1e-6) / 1e9, alg_bytes / (us * 1e-6) / HBM_PEAK, counter_gb, busy,
                 exec_tf, exec_tf * 1e12 / BF16_PEAK))
