@@ -644,7 +644,11 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");
     SBChoice c = sb_choose(a.N, a.Cout, a.D, a.H, a.W);
     RU_REQUIRE(!(a.bias && a.out_c16 && a.stat_partials), "conv3_sb: bias + voxel-major output + statistics is not a path of the network");
-    if (sb_use_v2(c) && a.bias && a.out_c16) c = SBChoice{2, 8};      // (no engine path: the persistent kernel has the bias for NCDHW output only)
+    if (sb_use_v2(c) && a.bias && a.out_c16) c = SBChoice{2, 8};
+#ifdef RU_SB2_DBG
+    if ((RU_SB2_DBG & 2048) && !a.stat_partials) c = SBChoice{2, 8};      // tools: time the one-stage kernel on a shape the persistent kernel would take
+    if ((RU_SB2_DBG & 4096) && !a.stat_partials) c = SBChoice{2, 4};
+#endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
     if (sb_use_v2(c)) {
         return (a.in_c16 && a.out_c16) ? conv3_sb2_launch_c16(a, s) : conv3_sb2_launch_mixed(a, s);
     }
