@@ -160,3 +160,32 @@ def test_shard_assignment():
     assert [S.shard(32, r, 8) for r in range(8)] == [slice(4 * r, 4 * r + 4) for r in range(8)]
     with pytest.raises(ValueError):
         S.shard(6, 0, 4)
+
+
+def test_argument_errors_are_reported_not_thrown(lib):
+    """every entry returns a negative code + ru_last_error() on a bad argument (SURVEY 8(b) conventions); none of these calls touches a GPU"""
+    import ctypes as C
+    from brats2019_amd import _lib as L
+    from brats2019_amd.engine import ParamLayout
+    lay = ParamLayout(**O.DEFAULT_CFG)
+    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0
+    assert lib.ru_unet_set_fusion(lay.handle, 4) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
+    assert lib.ru_unet_set_precision(lay.handle, 7) < 0
+    assert lib.ru_unet_workspace_bytes(lay.handle, 1, 12, 16, 16, 0) == 0            # extents must be divisible by 2^(depth-1)
+    assert lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 1) > lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 0) > 0
+    assert lib.ru_allreduce(None, None, 0, L.PRECISIONS["f32"], None) < 0 and b"ru_allreduce" in lib.ru_last_error()
+    h = C.c_void_p()
+    assert lib.ru_comm_init(C.byref(h), None, 0, 1) < 0 and lib.ru_comm_init(None, None, 0, 0) < 0
+    assert lib.ru_comm_destroy(None) == 0 and lib.ru_comm_rank(None) == -1 and lib.ru_comm_world(None) == 0
+    assert lib.ru_criterion_value_device(None, 3, 1.0, 1.0, 0.5, 0.5, None, None) < 0
+
+
+def test_default_precision_rule():
+    from brats2019_amd import model as M
+    assert M.default_precision([16, 32, 64, 128]) == "bf16x3" and M.default_precision([8, 16, 32]) == "f32"
+    net = M.UNet(**O.DEFAULT_CFG)
+    assert net._get_engine().precision == "bf16x3"
+    net.set_precision("f32")
+    assert net._get_engine().precision == "f32"
+    with pytest.raises(ValueError):
+        net.set_precision("fp16")
