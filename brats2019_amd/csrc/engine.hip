@@ -140,6 +140,7 @@ struct ru_unet {
     float* pack = nullptr;
     const float* x_in = nullptr;
     const float* x_in4 = nullptr;   // 4-channel copy of the input made for the stem conv (C16 flow), reused by its weight gradient
+    bool x_in4_planned = false;     // ... decided by structure (the dry walk has null pointers)
     // ru_unet_freeze_params: the weight packs at the head of the workspace are reused while (params, workspace, precision, layout) match
     bool params_frozen = false;
     const float* packed_params = nullptr;
@@ -431,12 +432,14 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     const int C0 = h->ch[0];
     h->x_in = x;
     h->x_in4 = nullptr;
+    h->x_in4_planned = false;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
     if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
         // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
         float* x4 = A.alloc((size_t)N * 4 * Vl(0));
         float* wf4 = wf4_in;
         h->x_in4 = x4;
+        h->x_in4_planned = true;
         RU_RUN(pad_to_c4_launch(x, x4, N, kInCh, Vl(0), s));
         if (!reuse_packs) RU_RUN(conv3_sb4_pack_weights(P(h, params, h->conv_in), wf4, kInCh, C0, 0, s));
         rc = conv3_gn(h, A, s, x4, nullptr, reinterpret_cast<const char*>(wf4), h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0,
@@ -570,6 +573,10 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         Wgrad3Args w{};
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
         w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
+        if (gb && !x_c16 && use4) {                              // stem: dy is the GroupNorm-backward apply of norm_input, computed while staging; nobody else reads it
+            w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = gb->g->act_slope;
+            w.gb_out = nullptr; w.dy = gb->y; w.dy_s16 = 0;      // (dy unused in this mode; any valid pointer)
+        }
         w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
         w.dw_cin = Cin; w.dw_cout = Cout;
         w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
@@ -843,9 +850,15 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     }
     // norm_input (no activation: slope 1) and conv_input
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
-    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst);
+    // voxel-major engine, no d/d(input) wanted: the gradient w.r.t. the stem conv's output is consumed by the stem's weight gradient alone, so
+    // the GroupNorm-backward apply of norm_input is computed in that kernel's staging (wgrad3_tz<1,1,3>) and never written
+    const bool fuse0 = c16 && h->precision == RU_PREC_BF16X3 && (h->fusion & RU_FUSE_GN_BWD_APPLY) && !dx_in && h->x_in4_planned;
+    float* coef0 = nullptr;
+    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst,
+                fuse0 ? &coef0 : nullptr);
     if (rc) return rc;
-    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16);
+    const GbApply gb0{h->y0, dcur, &h->g0, coef0};
+    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16, fuse0 ? &gb0 : nullptr);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks

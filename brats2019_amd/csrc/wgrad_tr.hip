@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + p * 32 + hsel * 16) = hi;
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
                 if constexpr (DS == 3) {                 // publish dy in split form (every position is staged once by input-channel group 0)
-                    if (ok && cgp == 0) {
+                    if (ok && cgp == 0 && a.gb_out) {    // (no output tensor: nobody but this weight gradient consumes the gradient, e.g. the stem)
                         const int row = p >> 4, z = row / TY;
                         const size_t vox = (size_t)((2 * st_k + z) * H + st_y0 + (row - z * TY)) * W + st_x0 + (p & 15);
                         u32x4* op = reinterpret_cast<u32x4*>(a.gb_out) + ((size_t)(st_n * CBo + og * OT + q) * DHW + vox) * 4;
@@ -464,8 +464,9 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         return RU_ENOMEM;
     }
     if (a.gb_y) {
-        RU_REQUIRE(!a.x_c4 && !a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && a.gb_out,
-                   "wgrad3_tr: the fused GroupNorm-backward apply needs voxel-major x and all of its operands");
+        RU_REQUIRE(!a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && (a.gb_out || a.x_c4),
+                   "wgrad3_tr: the fused GroupNorm-backward apply needs all of its operands");
+        if (a.x_c4) { RU_REQUIRE(c.ot == 1, "wgrad3_tr: a 4-channel copy stands for ONE 16-channel block"); return wtz_cfg<1, 1, 3>(a, c, s); }   // stem: x = network input
         if (c.ot == 2) return wtz_cfg<2, 0, 3>(a, c, s);   // two output blocks per workgroup: the constants of a block are fetched when it is converted
         return wtz_cfg<1, 0, 3>(a, c, s);
     }
