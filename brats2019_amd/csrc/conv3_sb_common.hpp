@@ -42,23 +42,9 @@ struct SB {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// v = hi + lo with hi = bf16_rne(v), lo = bf16_rne(v - hi); two values per v_cvt_pk_bf16_f32, the hi halves are
-// re-expanded with one shift / one mask (3 VALU per value in total)
+// v = hi + lo with hi = bf16_rne(v), lo = bf16_rne(v - hi) (split_pair in ru_common.h: 3 VALU per value)
 __device__ __forceinline__ void split8(const float (&t)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bf16x2 h;
-        h[0] = (__bf16)t[2 * i];
-        h[1] = (__bf16)t[2 * i + 1];
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16);
-        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        bf16x2 l;
-        l[0] = (__bf16)(t[2 * i] - h0);
-        l[1] = (__bf16)(t[2 * i + 1] - h1);
-        hi[i] = hb;
-        lo[i] = __builtin_bit_cast(unsigned, l);
-    }
+    split_n<4>(t, hi, lo);
 }
 
 // Epilogue of ONE M-tile (output row yy of plane zz), issued as soon as the tile's last MFMA is queued so the stores
@@ -441,10 +427,26 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
         const int hsel = (ptid >> 3) & 1;
         const int pslot = (ptid >> 4) * 8 + (ptid & 7);
-        const bool s16 = a.in_s16 != 0;                  // split form in HBM (gn_bwd_apply16_launch): the staging is a plain copy of hi / lo packets
         float4 v16[NR][2];
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
+        // Per thread and round the halo position p = r*128 + pslot is FIXED for the whole kernel: its coordinates (hz, hy, xc) and its byte
+        // offset inside a 16-channel block relative to the tile's halo origin are computed once.  Per item a round then costs three adds,
+        // three compares, one add and one select (the index arithmetic -- two divisions by constants and two 64-bit multiply-adds per
+        // round -- was a third of the staging waves' VALU instructions, and next to a wave that issues MFMAs back to back a VALU
+        // instruction of the other wave gets ONE issue slot per MFMA: tools/coissue_probe.hip).
+        const bool s16 = a.in_s16 != 0;                  // split form in HBM (gn_bwd_apply16_launch): the staging is a plain copy of hi / lo packets
+        const unsigned lofs = (s16 ? hsel * 4 : hsel * 8) * 4, second = s16 ? 32u : 16u;
+        int pk[NR], dlt[NR];                             // (hz | hy << 8 | xc << 16), byte offset of (hz, hy, xc) + this lane's half
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int p = r * 128 + pslot;
+            const int row = p / HX, xc = p - row * HX;
+            const int hz = row / HY, hy = row - hz * HY;
+            pk[r] = hz | (hy << 8) | (xc << 16);
+            dlt[r] = ((hz * H + hy) * W + xc) * 64 + (int)lofs;
+        }
+        const bool plast = (NR - 1) * 128 + pslot < NPOS;    // the last round covers positions beyond the image
         // z-walk order, one chunk: the tile of this step sits right below the previous one, so its halo planes 0 and 1 ARE planes 4 and 5
         // of the image staged one item earlier (already transformed and split, same y/x zero padding): the first CR rounds (positions
         // < CR*128 <= 2 planes) are copied LDS -> LDS from the other buffer instead of being loaded and converted again
@@ -456,20 +458,23 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             const int tile = tile_of(step), chunk = item % nchunk;
             int n, z0, y0, x0, tis;
             tile_origin(tile, n, z0, y0, x0, tis);
-            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
+            // one buffer descriptor per (sample, chunk): a position outside the volume gets an offset beyond num_records and the load
+            // returns zeros -- the zero padding costs no VALU select per value, and the address is one 32-bit offset per lane
+            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
+            const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
+            const int base = ((zm1 * H + ym1) * W + xm1) * 64;            // may be negative: only used where the position is inside
             vmask = 0;
             st_chain = zwalk && !MULTI && !(dbg & 512) && CR > 0 && (step % ntz) != 0;
             auto ld_round = [&](auto R) __attribute__((always_inline)) {
                 constexpr int r = decltype(R)::value;
-                const int p = r * 128 + pslot;
-                const int row = p / HX, xc = p - row * HX;
-                const int hz = row / HY, hy = row - hz * HY;
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
-                const bool ok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+                const int gz = zm1 + (pk[r] & 0xff), gy = ym1 + ((pk[r] >> 8) & 0xff), gx = xm1 + ((pk[r] >> 16) & 0xff);
+                bool ok = ((unsigned)gz < (unsigned)D) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);     // (no short-circuit branches)
+                if constexpr ((r + 1) * 128 > NPOS) ok = ok & plast;
+                const unsigned ofs = ok ? (unsigned)(base + dlt[r]) : 0x80000000u;
                 vmask |= ok ? (1u << r) : 0u;
-                v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
-                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + (s16 ? 8 : 4));
+                v16[r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
+                v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, second, 0));
             };
             if (st_chain) static_for<NR - CR>([&](auto R) { ld_round(std::integral_constant<int, decltype(R)::value + CR>{}); });    // one wave-uniform branch
             else static_for<NR>(ld_round);
@@ -518,23 +523,30 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int r = decltype(R0)::value; r < NR; ++r) {
                     const int p = r * 128 + pslot;
                     if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
-                    const bool ok = (vmask >> r) & 1u;
                     u32x4 hi, lo;
-                    if constexpr (mode == 2) {
-                        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-                        hi = ok ? __builtin_bit_cast(u32x4, v16[r][0]) : z;
-                        lo = ok ? __builtin_bit_cast(u32x4, v16[r][1]) : z;
+                    if constexpr (mode == 2) {                               // positions outside the volume were loaded as zeros
+                        hi = __builtin_bit_cast(u32x4, v16[r][0]);
+                        lo = __builtin_bit_cast(u32x4, v16[r][1]);
                     } else {
                         const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
                         float t[8];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            if constexpr (mode == 1) {
-                                const float u = fmaf(f[c], sc[c], sh[c]);
-                                t[c] = ok ? fmaxf(u, u * slope) : 0.f;      // zero padding applies to the ACTIVATED tensor
-                            } else {
-                                t[c] = ok ? f[c] : 0.f;
+                        if constexpr (mode == 1) {
+                            // the zero padding applies to the ACTIVATED tensor: lanes outside the volume skip the arithmetic under the
+                            // exec mask and store zeros (plain VALU only here -- packed-f32 instructions starve beside the MFMA waves)
+                            if (!((vmask >> r) & 1u)) {
+                                const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+                                buf[hsel * HVOLP + p] = z;
+                                buf[(2 + hsel) * HVOLP + p] = z;
+                                continue;
                             }
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                const float u = fmaf(f[c], sc[c], sh[c]);
+                                t[c] = fmaxf(u, u * slope);
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) t[c] = f[c];
                         }
                         split8(t, hi, lo);
                     }
@@ -836,6 +848,7 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
+    RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");
     hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;

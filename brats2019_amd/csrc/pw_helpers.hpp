@@ -42,20 +42,7 @@ static inline unsigned grid1d(size_t n, int per_block, unsigned cap = 1u << 20) 
 typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pw_split8(const float (&t)[8], pw_u32x4& hi, pw_u32x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        pw_bf16x2 h;
-        h[0] = (__bf16)t[2 * i];
-        h[1] = (__bf16)t[2 * i + 1];
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16);
-        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        pw_bf16x2 l;
-        l[0] = (__bf16)(t[2 * i] - h0);
-        l[1] = (__bf16)(t[2 * i + 1] - h1);
-        hi[i] = hb;
-        lo[i] = __builtin_bit_cast(unsigned, l);
-    }
+    split_n<4>(t, hi, lo);
 }
 
 // ------------------------------------------------------------------ trilinear x2 index helpers (model.py:12-14)

@@ -10,6 +10,36 @@
 
 namespace ru {
 
+// ---- split-bf16 operand format: v = hi + lo with hi = bf16_rne(v), lo = bf16_rne(v - hi); two values per call, packed (low half = a).
+// 3 VALU per value: v_cvt_pk_bf16_f32, v_perm_b32 / v_and_b32 to re-expand the hi halves, two v_sub_f32, v_cvt_pk_bf16_f32.  The low
+// half is re-expanded with a byte permute, not a shift: the optimizer rewrites (cvt_pk(a, b) << 16) as cvt_pk(a, undef) << 16 -- a
+// second conversion per pair.  The two remainders must stay two plain v_sub_f32 (the library is built with -fno-slp-vectorize so that
+// they are not paired into one v_pk_add_f32): these helpers run in the staging waves that share a SIMD with the MFMA waves, and
+// there a packed-f32 instruction starves (tools/coissue_probe.hip: 85 ns per v_pk_* against 7 ns per plain VALU instruction).
+typedef __bf16 ru_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hb, unsigned& lb) {
+    ru_bf16x2 h;
+    h[0] = (__bf16)a;
+    h[1] = (__bf16)b;
+    hb = __builtin_bit_cast(unsigned, h);
+    const float h0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(hb, hb, 0x01000c0cu));     // (hb & 0xffff) << 16
+    const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+    ru_bf16x2 l;
+    l[0] = (__bf16)(a - h0);
+    l[1] = (__bf16)(b - h1);
+    lb = __builtin_bit_cast(unsigned, l);
+}
+template <int NP, class V>
+__device__ __forceinline__ void split_n(const float (&t)[2 * NP], V& hi, V& lo) {       // 2*NP floats -> NP packed dwords of hi and of lo
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        unsigned hb, lb;
+        split_pair(t[2 * i], t[2 * i + 1], hb, lb);
+        hi[i] = hb;
+        lo[i] = lb;
+    }
+}
+
 // thread-local error message (ru_last_error)
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

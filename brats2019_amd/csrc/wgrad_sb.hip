@@ -42,20 +42,7 @@ struct WSB {
 
 // 4 floats -> 4 bf16 hi (8 bytes) + 4 bf16 lo (8 bytes)
 __device__ __forceinline__ void split4(const float (&t)[4], u32x2& hi, u32x2& lo) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        bf16x2 h;
-        h[0] = (__bf16)t[2 * i];
-        h[1] = (__bf16)t[2 * i + 1];
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16);
-        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        bf16x2 l;
-        l[0] = (__bf16)(t[2 * i] - h0);
-        l[1] = (__bf16)(t[2 * i + 1] - h1);
-        hi[i] = hb;
-        lo[i] = __builtin_bit_cast(unsigned, l);
-    }
+    split_n<2>(t, hi, lo);
 }
 
 // the 8 elements starting `s` elements (3, 4 or 5) into the 16-element window (w0 = packet b, w1 = packet b+1)
@@ -116,20 +103,7 @@ __device__ __forceinline__ void wsb_compute(const u32x4* __restrict__ xL, const 
 
 // 8 floats -> 8 bf16 hi + 8 bf16 lo (one 16-byte packet each)
 __device__ __forceinline__ void wsplit8(const float (&t)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bf16x2 h;
-        h[0] = (__bf16)t[2 * i];
-        h[1] = (__bf16)t[2 * i + 1];
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16);
-        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        bf16x2 l;
-        l[0] = (__bf16)(t[2 * i] - h0);
-        l[1] = (__bf16)(t[2 * i + 1] - h1);
-        hi[i] = hb;
-        lo[i] = __builtin_bit_cast(unsigned, l);
-    }
+    split_n<4>(t, hi, lo);
 }
 
 // X16 / DY16: the x / dy tensor is voxel-major (C16, [N][C/16][D][H][W][16]).  The packets need 8 consecutive x voxels of

@@ -42,20 +42,7 @@ __device__ __forceinline__ void wt_static_for(F&& f) {
 }
 
 __device__ __forceinline__ void wt_split8(const float (&t)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bf16x2 h;
-        h[0] = (__bf16)t[2 * i];
-        h[1] = (__bf16)t[2 * i + 1];
-        const unsigned hb = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hb << 16);
-        const float h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
-        bf16x2 l;
-        l[0] = (__bf16)(t[2 * i] - h0);
-        l[1] = (__bf16)(t[2 * i + 1] - h1);
-        hi[i] = hb;
-        lo[i] = __builtin_bit_cast(unsigned, l);
-    }
+    split_n<4>(t, hi, lo);
 }
 
 __device__ __forceinline__ bf16x8 wt_read_tr(const char* p0, const char* p1) {
