@@ -155,6 +155,11 @@ struct ru_unet {
     std::vector<DecSave> dstage;
     std::vector<const float*> skips;
     std::vector<GNSave> gn_order;
+    // ru_unet_probe: HIP event pairs around the launches of the dominant kernel (3x3x3 conv 16->16 at the input resolution, forward)
+    bool probe_on = false;
+    std::vector<hipEvent_t> probe_ev;      // pairs (begin, end), created on demand, reused
+    size_t probe_used = 0;                 // events recorded since the last read
+    ~ru_unet() { for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e); }
 };
 
 static int add_param(ru_unet* h, const std::string& name, std::initializer_list<int> dims, bool dead = false) {
@@ -281,6 +286,28 @@ extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
     h->have_fwd = false;            // the workspace layout of the backward depends on it
     return RU_OK;
 }
+extern "C" int ru_unet_probe(ru_unet_t h, int enable) {
+    RU_REQUIRE(h, "ru_unet_probe: null handle");
+    h->probe_on = enable != 0;
+    h->probe_used = 0;
+    return RU_OK;
+}
+extern "C" int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches) {
+    RU_REQUIRE(h && total_ms && launches, "ru_unet_probe_read: null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < h->probe_used; i += 2) {
+        hipError_t e = hipEventSynchronize(h->probe_ev[i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(probe)");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, h->probe_ev[i], h->probe_ev[i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(probe)");
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int)(h->probe_used / 2);
+    h->probe_used = 0;
+    return RU_OK;
+}
 extern "C" int ru_unet_freeze_params(ru_unet_t h, int frozen) {
     RU_REQUIRE(h, "ru_unet_freeze_params: null handle");
     h->params_frozen = frozen != 0;
@@ -356,7 +383,21 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.stat_partials = partials;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16; a.in_c4 = x_c4;
+    const bool probed = h->probe_on && !A.dry && h->c16 && x_c16 && !x_c4 && Cin == 16 && Cout == 16 && D == h->D && H == h->H && W == h->W;
+    if (probed) {
+        while (h->probe_ev.size() < h->probe_used + 2) {
+            hipEvent_t e;
+            const hipError_t er = hipEventCreate(&e);
+            if (er != hipSuccess) return hip_fail(er, "hipEventCreate(probe)");
+            h->probe_ev.push_back(e);
+        }
+        (void)hipEventRecord(h->probe_ev[h->probe_used], s);
+    }
     RU_RUN(conv3_launch(a, s));
+    if (probed) {
+        (void)hipEventRecord(h->probe_ev[h->probe_used + 1], s);
+        h->probe_used += 2;
+    }
     out_gn.k = (h->training && h->c16) ? A.alloc((size_t)N * 3 * Cout) : nullptr;
     RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
                               (size_t)D * H * W, kGroups, kEps, s, out_gn.k));

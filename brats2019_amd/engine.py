@@ -82,6 +82,17 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
         self._ws_key = None                    # the backward's workspace layout depends on it
 
+    def probe(self, enable=True):
+        """In-situ timing of the dominant kernel (ru_unet_probe): HIP event pairs around the 16->16 3x3x3 convolutions of the forward."""
+        L.check(L.load().ru_unet_probe(self.h, int(bool(enable))), "ru_unet_probe")
+
+    def probe_read(self):
+        """-> (total_ms, launches) since the last read; waits for the recorded events (ru_unet_probe_read)."""
+        import ctypes
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        L.check(L.load().ru_unet_probe_read(self.h, ctypes.byref(ms), ctypes.byref(n)), "ru_unet_probe_read")
+        return ms.value, n.value
+
     def freeze_params(self, frozen=True):
         """Inference with constant weights: the packed weights in the workspace are built once and reused (ru_unet_freeze_params).
         Leave off while training -- the optimizer rewrites the flat parameter buffer in place every step."""

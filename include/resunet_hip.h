@@ -156,6 +156,12 @@ int ru_unet_get_precision(ru_unet_t h);
 #define RU_FUSE_GN_BWD_STATS 1
 #define RU_FUSE_GN_BWD_APPLY 2
 int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
+/* In-situ timing of the dominant kernel (bench.py's roofline line): while enabled, every forward brackets its launches of
+ * the 3x3x3 convolution 16 -> 16 at the input resolution (voxel-major split-bf16 engine; the forward of the shipped net has four) with a
+ * HIP event pair on the stream the kernels run on.  ru_unet_probe_read waits for the recorded events, returns the summed duration and
+ * the number of launches since the last read, and clears the record.  Off by default; costs two event records per probed launch. */
+int ru_unet_probe(ru_unet_t h, int enable);
+int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
 int ru_unet_param_ndim(ru_unet_t h, int i);

@@ -432,3 +432,26 @@ def test_inplace_edit_of_probabilities_before_backward_is_caught():
         p.mul_(0.5)
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+@pytest.mark.gpu
+def test_probe_times_the_four_input_resolution_convs_of_a_forward():
+    """ru_unet_probe / ru_unet_probe_read (bench.py's in-place roofline timing): four launches per forward of the shipped config, a positive
+    duration, nothing recorded while off, and the forward's results are unchanged by the event records."""
+    net, _ = build_model(O.DEFAULT_CFG, 1337, "bf16x3")
+    net.eval()
+    x = torch.randn(2, 4, 32, 32, 32, device="cuda")
+    with torch.no_grad():
+        ref = net([x])[0].clone()
+        eng = net._get_engine()
+        assert eng.probe_read() == (0.0, 0)
+        eng.probe(True)
+        out = net([x])[0].clone()
+        out2 = net([x])[0]
+        ms, n = eng.probe_read()
+        assert n == 8 and ms > 0.0
+        assert eng.probe_read() == (0.0, 0)
+        eng.probe(False)
+        net([x])
+        assert eng.probe_read() == (0.0, 0)
+    assert torch.equal(out, ref) and torch.equal(out2, ref)

@@ -21,13 +21,14 @@ def main():
     start = [int(r["Start_Timestamp"]) for r in rows]
     # a step ends with the last adam_kernel launch of a run of adam launches
     ends = [i for i in range(len(names)) if "adam" in names[i] and (i + 1 == len(names) or "adam" not in names[i + 1])]
-    ends = ends[-(k + 1):]
-    per = ends[-1] - ends[-2]
-    assert all(ends[j + 1] - ends[j] == per for j in range(len(ends) - 1)), "steps differ in launch count"
+    ends = ends[-(k + 1):]                      # (bench.py's probe steps at the end launch the same kernels: they count as steps here)
+    per = min(ends[j + 1] - ends[j] for j in range(len(ends) - 1))
+    # a step is the `per` launches that END at its last adam launch (bench.py reads the loss between the timed region and the probe
+    # steps: one blit kernel that belongs to no step)
     lines = ["# launches per step %d; averaged over %d steps; columns: index, kernel, avg_us, gap_before_us" % (per, k)]
     tot = 0.0
     for p in range(per):
-        idx = [ends[j] + 1 + p for j in range(k)]
+        idx = [ends[j + 1] - per + 1 + p for j in range(k)]
         assert len(set(names[i] for i in idx)) == 1
         d = sum(dur[i] for i in idx) / k
         gap = sum((start[i] - (start[i - 1] + dur[i - 1] * 1e3)) / 1e3 for i in idx) / k
