@@ -269,6 +269,8 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
                     help="arithmetic of the 3x3x3 convolutions: split-bf16 3-product MFMA (default; |dp| ~ 5e-5, bar 1e-3) or exact f32 MFMA")
+    ap.add_argument("--grad-precision", choices=["bf16x3", "bf16"], default="bf16x3",
+                    help="3x3x3 data / weight gradients under the bf16x3 forward: three split-bf16 products (default) or bf16-rounded operands, one product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
@@ -291,7 +293,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    backend = P.HipBackend(device=dev, precision=args.precision)
+    backend = P.HipBackend(device=dev, precision=args.precision, grad_precision=args.grad_precision if args.precision == "bf16x3" else None)
     flat = init_params(backend)                      # same seed on every rank: identical replicas
     comm = P.RcclComm(rank, world) if (args.transport == "rccl" and world > 1) else None
     stepper = P.DataParallelStep(backend, flat, comm=comm)

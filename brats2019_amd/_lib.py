@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RU_LIB_PATH") or os.path.join(_PKG, "lib", "libresune
 
 _lib = None
 PRECISIONS = {"f32": 0, "bf16x3": 1}      # RU_PREC_F32 / RU_PREC_BF16X3
+GRAD_PRECISIONS = {"bf16x3": 1, "bf16": 2}   # ru_unet_set_grad_precision: RU_PREC_BF16X3 / RU_PREC_BF16
 FUSE_GN_BWD_STATS, FUSE_GN_BWD_APPLY = 1, 2   # RU_FUSE_*
 
 _vp, _f, _d, _i, _sz = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_size_t
@@ -50,6 +51,8 @@ SIGNATURES = {
     "ru_unet_set_precision": (_i, [_vp, _i]),
     "ru_unet_freeze_params": (_i, [_vp, _i]),
     "ru_unet_get_precision": (_i, [_vp]),
+    "ru_unet_set_grad_precision": (_i, [_vp, _i]),
+    "ru_unet_get_grad_precision": (_i, [_vp]),
     "ru_unet_set_fusion": (_i, [_vp, C.c_uint]),
     "ru_unet_probe": (_i, [_vp, _i]),
     "ru_unet_probe_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),

@@ -650,7 +650,8 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     if ((RU_SB2_DBG & 4096) && !a.stat_partials) c = SBChoice{2, 4};
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
     if (sb_use_v2(c)) {
-        return (a.in_c16 && a.out_c16) ? conv3_sb2_launch_c16(a, s) : conv3_sb2_launch_mixed(a, s);
+        if (a.in_c16 && a.out_c16) return a.products == 1 ? conv3_sb2_launch_c16_p1(a, s) : conv3_sb2_launch_c16(a, s);
+        return conv3_sb2_launch_mixed(a, s);             // (three products whatever a.products says: the NCDHW-side variants have no one-product form)
     }
     if (c.ty == 8) {
         if (a.in_c16) return a.out_c16 ? sb_cfg<2, 8, true, true>(a, s) : sb_cfg<2, 8, true, false>(a, s);

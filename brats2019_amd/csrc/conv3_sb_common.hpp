@@ -241,7 +241,10 @@ static __device__ unsigned long long sb2_prof[8];     // (one per translation un
 // BST: fused GroupNorm-backward statistics in the epilogue (Conv3Args::bst_*), C16 output only.
 // ADD: a residual tensor is added in the epilogue (Conv3Args::add).  Compile-time, like BST: without a per-row operand the consumer's
 // stream holds NO loads, so its s_waitcnt vmcnt never has to wait for older row stores to be acknowledged (vmcnt counts in order).
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST, bool ADD>
+// NP: MFMA products per operand pair.  3 = split-bf16 (hi*hi + lo*hi + hi*lo, ~2^-17 relative).  1 = plain bf16 operands (hi*hi only,
+// fp32 accumulate): the gradient precision RU_PREC_BF16 of the engine's backward -- the staging writes and the consumers read the hi
+// planes only, the weights' lo fragments are never fetched.  Voxel-major input only.
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST, bool ADD, int NP = 3>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg_arg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue.
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     constexpr int dbg = 0;
 #endif
     (void)dbg_arg;
+    static_assert(NP == 3 || (NP == 1 && IN16), "one-product variant: voxel-major input only");
     using P = SB<TZ, TY>;
     constexpr int MT = P::MT, HY = P::HY, HX = P::HX, HVOLP = P::HVOLP, NROW = P::NROW;
     constexpr int BUF = 4 * HVOLP;                      // packets per LDS buffer
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const unsigned ofs = ok ? (unsigned)(base + dlt[r]) : 0x80000000u;
                 vmask |= ok ? (1u << r) : 0u;
                 v16[r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
-                v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, second, 0));
+                if (NP == 3 || !s16) v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, second, 0));   // (split form, one product: the lo packet is not read)
             };
             if (st_chain) static_for<NR - CR>([&](auto R) { ld_round(std::integral_constant<int, decltype(R)::value + CR>{}); });    // one wave-uniform branch
             else static_for<NR>(ld_round);
@@ -507,13 +511,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int r = 0; r < CR; ++r) {
                     const int p = r * 128 + pslot;
                     ch[r][0] = prev[hsel * HVOLP + p + 4 * HY * HX];
-                    ch[r][1] = prev[(2 + hsel) * HVOLP + p + 4 * HY * HX];
+                    if constexpr (NP == 3) ch[r][1] = prev[(2 + hsel) * HVOLP + p + 4 * HY * HX];
                 }
 #pragma unroll
                 for (int r = 0; r < CR; ++r) {
                     const int p = r * 128 + pslot;
                     buf[hsel * HVOLP + p] = ch[r][0];
-                    buf[(2 + hsel) * HVOLP + p] = ch[r][1];
+                    if constexpr (NP == 3) buf[(2 + hsel) * HVOLP + p] = ch[r][1];
                 }
             }
             // ONE wave-uniform dispatch per item, then a branch-free unrolled loop: mode 0 plain, 1 fused transform, 2 split-form copy
@@ -523,10 +527,10 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 for (int r = decltype(R0)::value; r < NR; ++r) {
                     const int p = r * 128 + pslot;
                     if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
-                    u32x4 hi, lo;
+                    u32x4 hi, lo = u32x4{0u, 0u, 0u, 0u};
                     if constexpr (mode == 2) {                               // positions outside the volume were loaded as zeros
                         hi = __builtin_bit_cast(u32x4, v16[r][0]);
-                        lo = __builtin_bit_cast(u32x4, v16[r][1]);
+                        if constexpr (NP == 3) lo = __builtin_bit_cast(u32x4, v16[r][1]);
                     } else {
                         const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
                         float t[8];
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                             if (!((vmask >> r) & 1u)) {
                                 const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                                 buf[hsel * HVOLP + p] = z;
-                                buf[(2 + hsel) * HVOLP + p] = z;
+                                if constexpr (NP == 3) buf[(2 + hsel) * HVOLP + p] = z;
                                 continue;
                             }
 #pragma unroll
@@ -548,10 +552,20 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
                             for (int c = 0; c < 8; ++c) t[c] = f[c];
                         }
-                        split8(t, hi, lo);
+                        if constexpr (NP == 3) {
+                            split8(t, hi, lo);
+                        } else {                                             // hi = bf16_rne(v) only: one v_cvt_pk_bf16_f32 per two values
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                ru_bf16x2 h2;
+                                h2[0] = (__bf16)t[2 * c];
+                                h2[1] = (__bf16)t[2 * c + 1];
+                                hi[c] = __builtin_bit_cast(unsigned, h2);
+                            }
+                        }
                     }
                     buf[hsel * HVOLP + p] = hi;
-                    buf[(2 + hsel) * HVOLP + p] = lo;
+                    if constexpr (NP == 3) buf[(2 + hsel) * HVOLP + p] = lo;
                 }
             };
             auto dispatch = [&](auto R0) __attribute__((always_inline)) {
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 #pragma unroll
             for (int ks = 0; ks < SB_KSTEPS; ++ks) {
                 wreg[ks][0] = wp[(ks * 2 + 0) * 64];
-                wreg[ks][1] = wp[(ks * 2 + 1) * 64];
+                if constexpr (NP == 3) wreg[ks][1] = wp[(ks * 2 + 1) * 64];
             }
         };
         load_w(0);                                      // one chunk: the weights stay in registers for the whole run of tiles
@@ -700,9 +714,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             };
             bf16x8 fh[3], fl[3];                         // fragment ring: step s lives in slot s % 3, fetched two steps ahead
             fh[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{})]);
-            fl[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{}) + 2 * HVOLP]);
+            if constexpr (NP == 3) fl[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{}) + 2 * HVOLP]);
             fh[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{})]);
-            fl[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{}) + 2 * HVOLP]);
+            if constexpr (NP == 3) fl[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{}) + 2 * HVOLP]);
             float4 radd[3], rbst[3];                     // per-row operands (residual / BST forward tensor): tile i uses slot i % 3, loaded at row i + 1,
 #pragma unroll                                           // consumed at row i + 3
             for (int j = 0; j < 3; ++j) { radd[j] = make_float4(0.f, 0.f, 0.f, 0.f); rbst[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -721,8 +735,10 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                         const int o = frag_ofs(std::integral_constant<int, (s + 2 < NSTEP ? s + 2 : 0)>{});
                         fh[nxt] = __builtin_bit_cast(bf16x8, buf[o]);
                         __builtin_amdgcn_sched_barrier(0);
-                        fl[nxt] = __builtin_bit_cast(bf16x8, buf[o + 2 * HVOLP]);
-                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (NP == 3) {
+                            fl[nxt] = __builtin_bit_cast(bf16x8, buf[o + 2 * HVOLP]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     fetched = true;
                 };
@@ -738,16 +754,20 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                                     constexpr int ks = 3 * f + dy;
                                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
                                     const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                                    if constexpr (pr == 0) {
-                                        if constexpr (!MULTI && f == 0 && dy == 0) acc[i] = mm(al, bh, f32x4{0.f, 0.f, 0.f, 0.f});   // first touch of tile i (one chunk): zero operand
-                                        else acc[i] = mm(al, bh, acc[i]);
+                                    constexpr bool first = !MULTI && f == 0 && dy == 0;      // first touch of tile i (one chunk): zero operand
+                                    if constexpr (NP == 1) {
+                                        if constexpr (pr == 2) acc[i] = first ? mm(ah, bh, f32x4{0.f, 0.f, 0.f, 0.f}) : mm(ah, bh, acc[i]);
+                                    } else if constexpr (pr == 0) {
+                                        acc[i] = first ? mm(al, bh, f32x4{0.f, 0.f, 0.f, 0.f}) : mm(al, bh, acc[i]);
                                     } else if constexpr (pr == 1) {
                                         acc[i] = mm(ah, bl, acc[i]);
                                     } else {
                                         acc[i] = mm(ah, bh, acc[i]);
                                     }
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    if (!fetched) fetch();
+                                    if constexpr (NP == 3 || pr == 2) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        if (!fetched) fetch();
+                                    }
                                 }
                             });
                         });
@@ -760,11 +780,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                                 if constexpr (i >= 0 && i < MT) {
                                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
                                     const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
-                                    if constexpr (pr == 0) acc[i] = mm(al, bh, acc[i]);
+                                    if constexpr (NP == 1) { if constexpr (pr == 2) acc[i] = mm(ah, bh, acc[i]); }
+                                    else if constexpr (pr == 0) acc[i] = mm(al, bh, acc[i]);
                                     else if constexpr (pr == 1) acc[i] = mm(ah, bl, acc[i]);
                                     else acc[i] = mm(ah, bh, acc[i]);
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    if (!fetched) fetch();
+                                    if constexpr (NP == 3 || pr == 2) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        if (!fetched) fetch();
+                                    }
                                 }
                             });
                         });
@@ -789,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     constexpr int ksd = f < 4 ? (r >= 7 ? 3 * f + (r - 7) : -1) : (r == 7 ? 12 : (r == 9 ? 13 : -1));
                     if constexpr (ksd >= 0) {
                         wreg[ksd][0] = wnext[(ksd * 2 + 0) * 64];
-                        wreg[ksd][1] = wnext[(ksd * 2 + 1) * 64];
+                        if constexpr (NP == 3) wreg[ksd][1] = wnext[(ksd * 2 + 1) * 64];
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -832,13 +855,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 
 
 
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, bool ADD = false>
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, bool ADD = false, int NP = 3>
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static PerDevice attr_done;
     constexpr int LDS2 = 2 * P::LDS_BYTES;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         attr_done.set();
     }
@@ -849,22 +872,23 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
     RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
 }
-template <int TZ, int TY, bool IN16, bool OUT16>
+template <int TZ, int TY, bool IN16, bool OUT16, int NP = 3>
 static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
     if constexpr (IN16 && OUT16) {
-        if (a.bst_y && a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true, true>(a, s);
-        if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true>(a, s);
+        if (a.bst_y && a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true, true, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true, true, NP>(a, s);
+        if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true, false, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true, false, NP>(a, s);
     }
-    if (a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, true>(a, s);
-    return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false>(a, s);
+    if (a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, true, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, true, NP>(a, s);
+    return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, false, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, false, NP>(a, s);
 }
 
-// defined in conv3_sb2_c16.hip / conv3_sb2_mixed.hip
+// defined in conv3_sb2_c16.hip / conv3_sb2_c16_p1.hip (one product) / conv3_sb2_mixed.hip
 int conv3_sb2_launch_c16(const Conv3Args& a, hipStream_t s);
+int conv3_sb2_launch_c16_p1(const Conv3Args& a, hipStream_t s);
 int conv3_sb2_launch_mixed(const Conv3Args& a, hipStream_t s);
 
 }  // namespace ru

@@ -115,6 +115,7 @@ struct DecSave {
     int level = 0;
 };
 
+constexpr int kOneProduct = 0x100;         // flag in wgrad3_run's mode argument
 struct ru_unet {
     int depth = 0, nout = 0;
     std::vector<int> enc, dec, ch;
@@ -129,6 +130,9 @@ struct ru_unet {
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
     unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY;
+    int grad_precision = RU_PREC_BF16X3;   // ru_unet_set_grad_precision: RU_PREC_BF16 = one MFMA product in the 3x3x3 data / weight gradients
+    int grad_products() const { return (precision == RU_PREC_BF16X3 && grad_precision == RU_PREC_BF16) ? 1 : 3; }
+    int wgrad_mode() const { return precision | (grad_products() == 1 ? kOneProduct : 0); }   // `mode` argument of wgrad3_run
     bool c16 = false;           // this forward/backward pair keeps its activations voxel-major (split-bf16, channels % 16 == 0)
     char* fpack = nullptr;
 
@@ -308,6 +312,12 @@ extern "C" int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches) 
     h->probe_used = 0;
     return RU_OK;
 }
+extern "C" int ru_unet_set_grad_precision(ru_unet_t h, int precision) {
+    RU_REQUIRE(h && (precision == RU_PREC_BF16X3 || precision == RU_PREC_BF16), "ru_unet_set_grad_precision: RU_PREC_BF16X3 or RU_PREC_BF16");
+    h->grad_precision = precision;
+    return RU_OK;
+}
+extern "C" int ru_unet_get_grad_precision(ru_unet_t h) { return h ? h->grad_precision : -1; }
 extern "C" int ru_unet_freeze_params(ru_unet_t h, int frozen) {
     RU_REQUIRE(h, "ru_unet_freeze_params: null handle");
     h->params_frozen = frozen != 0;
@@ -601,6 +611,8 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
 struct GbApply { const float* y; const float* d; const GNSave* g; const float* coef; };
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
                       bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr, bool dy_s16 = false, const GbApply* gb = nullptr) {
+    const int products = (mode & kOneProduct) ? 1 : 3;
+    mode &= ~kOneProduct;
     if (x_c16 != dy_c16 && mode == RU_PREC_BF16X3 && Cin <= 16 && Cout <= 16) {
         // stem (x = network input) / head (dy = class gradient): the few-channel NCDHW side enters the transpose-read kernel as a
         // 16-channel block that is zero beyond its real channels -- from the 4-channel copy the conv of that tensor already made
@@ -614,6 +626,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         Wgrad3Args w{};
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
         w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
+        w.products = products;
         if (gb && !x_c16 && use4) {                              // stem: dy is the GroupNorm-backward apply of norm_input, computed while staging; nobody else reads it
             w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = gb->g->act_slope;
             w.gb_out = nullptr; w.dy = gb->y; w.dy_s16 = 0;      // (dy unused in this mode; any valid pointer)
@@ -628,6 +641,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     }
     Wgrad3Args w{};
     w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16; w.dy_s16 = dy_s16 ? 1 : 0;
+    w.products = products;
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -678,11 +692,11 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
                     fa ? &coef2 : nullptr);
     if (rc) return rc;
     const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
-    rc = wgrad3_run(A, s, h->precision, sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
+    rc = wgrad3_run(A, s, h->wgrad_mode(), sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.products = h->grad_products(); d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
     // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
     const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
@@ -699,11 +713,11 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
                 fa ? &coef1 : nullptr);
     if (rc) return rc;
     const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
-    rc = wgrad3_run(A, s, h->precision, sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
+    rc = wgrad3_run(A, s, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
-    d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
+    d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.products = h->grad_products(); d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
     d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = c16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     if (nx) { nx->part = nullptr; nx->nblk = 0; }
@@ -764,7 +778,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
         RU_RUN(bias_grad_launch(dlog, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
     }
-    int rc = wgrad3_run(A, s, h->precision, h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
+    int rc = wgrad3_run(A, s, h->wgrad_mode(), h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
     if (rc) return rc;
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
@@ -899,7 +913,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
                 fuse0 ? &coef0 : nullptr);
     if (rc) return rc;
     const GbApply gb0{h->y0, dcur, &h->g0, coef0};
-    rc = wgrad3_run(A, s, h->precision, h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16, fuse0 ? &gb0 : nullptr);
+    rc = wgrad3_run(A, s, h->wgrad_mode(), h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16, fuse0 ? &gb0 : nullptr);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks

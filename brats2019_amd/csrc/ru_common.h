@@ -102,6 +102,9 @@ struct Conv3Args {
     const float* bst_y;
     const float* bst_k;
     float bst_slope;
+    // MFMA products per operand pair in split-bf16 mode: 0 / 3 = hi*hi + lo*hi + hi*lo; 1 = hi*hi only (plain bf16 operands: the engine's
+    // gradient precision RU_PREC_BF16).  Honoured by the persistent voxel-major kernel; every other kernel keeps three products.
+    int products;
 };
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
@@ -158,6 +161,7 @@ struct Wgrad3Args {
     const float* gb_coef;
     float gb_slope;
     float* gb_out;
+    int products;            // wgrad_tr only: 0 / 3 = three split-bf16 products, 1 = hi*hi only (gradient precision RU_PREC_BF16), where such a variant exists
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);

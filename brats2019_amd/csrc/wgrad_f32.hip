@@ -373,7 +373,6 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_f32_kernel<TZ, TY, OT, CT>), grid, dim3(512), lds, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, TY), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
-    const int total = 27 * a.Cout * a.Cin;
     return wgrad_reduce_launch((const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s);
 }
 

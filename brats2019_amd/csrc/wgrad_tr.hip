@@ -45,6 +45,16 @@ __device__ __forceinline__ void wt_split8(const float (&t)[8], u32x4& hi, u32x4&
     split_n<4>(t, hi, lo);
 }
 
+__device__ __forceinline__ void wt_hi8(const float (&t)[8], u32x4& hi) {       // bf16_rne of 8 values, packed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ru_bf16x2 h;
+        h[0] = (__bf16)t[2 * i];
+        h[1] = (__bf16)t[2 * i + 1];
+        hi[i] = __builtin_bit_cast(unsigned, h);
+    }
+}
+
 __device__ __forceinline__ bf16x8 wt_read_tr(const char* p0, const char* p1) {
     // two transposed reads: rows 0-3 and 4-7 of this lane group's K-slots
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
@@ -80,15 +90,17 @@ struct WTZ {
 // four row pairs (p, p+2), p = 0..3 of the halo image, so per (dz, dx) 8 operands (hi and lo) feed 18 MFMAs; with the dy image
 // read once per half that is 0.94 transposed reads per MFMA instead of 1.5, and no wave re-reads another wave's dy fragments.
 // The reads of the next (dz, dx) group are issued between the MFMAs of the current one.
-template <int OT>
+// NP = 1: plain bf16 operands (hi*hi only; gradient precision RU_PREC_BF16) -- the lo operands are neither read nor multiplied.
+template <int OT, int NP>
 __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const int (&pw)[3], const char* __restrict__ dl, f32x4 (&acc)[27]) {
     using P = WTZ<OT>;
     constexpr int HX = P::HX, NHALF = OT, NU = NHALF * 9;       // units: (row half, (dz, dx))
     bf16x8 bh[2][4], bl[2][4];                                  // x operands of a unit: row pairs p = 0..3, double buffered
     bf16x8 ah[2][2], al[2][2];                                  // dy operands of a half: K-blocks (0,2), (1,3), double buffered by half
     // read r of unit u: r < 8 -> x operand (pair r>>1, hi/lo r&1); then, for the first unit of a half, the 4 dy operands
+    // (one product: the odd reads -- the lo operands -- do not exist, read index rr counts the hi reads only)
     auto read_one = [&](auto U, auto R) {
-        constexpr int u = decltype(U)::value, r = decltype(R)::value;
+        constexpr int u = decltype(U)::value, r = NP == 3 ? decltype(R)::value : 2 * decltype(R)::value;
         constexpr int h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
         if constexpr (r < 8) {
             constexpr int pr = r >> 1;
@@ -103,19 +115,20 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
             else al[h & 1][kbi] = wt_read_tr(dl + P::DPLANE + off0, dl + P::DPLANE + off1);
         }
     };
-    auto nreads = [](int u) constexpr { return (u % 9 == 0) ? 12 : 8; };
+    auto nreads = [](int u) constexpr { return ((u % 9 == 0) ? 12 : 8) / (NP == 3 ? 1 : 2); };
     wt_static_for<nreads(0)>([&](auto R) { read_one(std::integral_constant<int, 0>{}, R); });
     wt_static_for<NU>([&](auto U) {
         constexpr int u = decltype(U)::value, h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
         constexpr int nr = u + 1 < NU ? nreads(u + 1) : 0;
-        wt_static_for<18>([&](auto M) {
-            constexpr int m = decltype(M)::value, prod = m / 6, kbi = (m / 3) % 2, dy = m % 3;
+        constexpr int NM = 6 * NP;
+        wt_static_for<NM>([&](auto M) {
+            constexpr int m = decltype(M)::value, prod = NP == 3 ? m / 6 : 2, kbi = (m / 3) % 2, dy = m % 3;
             constexpr int tap = dz * 9 + dy * 3 + dx, pr = kbi + dy;
             if constexpr (prod == 0) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
             if constexpr (prod == 1) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bl[set][pr], acc[tap], 0, 0, 0);
             if constexpr (prod == 2) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int ra = m * nr / 18, rb = (m + 1) * nr / 18;
+            constexpr int ra = m * nr / NM, rb = (m + 1) * nr / NM;
             wt_static_for<rb - ra>([&](auto K) {
                 read_one(std::integral_constant<int, u + 1>{}, std::integral_constant<int, ra + decltype(K)::value>{});
             });
@@ -127,7 +140,7 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
 // XS: source of x -- 0 C16, 1 C4 copy (a 16-channel block that is zero beyond channel 3).  DS: source of dy -- 0 C16, 1 split C16 (hi/lo
 // packets in HBM, copied), 2 C4 copy.  Compile-time: a runtime branch inside the unrolled load loops breaks the load batches apart
 // (it cost ~100 us per launch when these were kernel arguments).
-template <int OT, int XS, int DS>
+template <int OT, int XS, int DS, int NP = 3>
 __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WTZ<OT>;
     constexpr int HX = P::HX, PPOS = P::PPOS, DPOS = P::DPOS, TY = P::TY;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     md |= ok ? (1u << r) : 0u;
                     const float* ds = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 4;
                     vd[r][0] = *reinterpret_cast<const float4*>(ds);
-                    vd[r][1] = *reinterpret_cast<const float4*>(ds + 8);
+                    if constexpr (NP == 3) vd[r][1] = *reinterpret_cast<const float4*>(ds + 8);      // (one product: the lo packet is not read)
                 } else if constexpr (DS == 2) {
                     md |= (ok && hsel == 0) ? (1u << r) : 0u;
                     vd[r][0] = *reinterpret_cast<const float4*>(a.dy + (size_t)n * DHW * 4 + (ofs >> 2));
@@ -283,11 +296,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     }
                 }
                 u32x4 hi, lo;
-                wt_split8(t, hi, lo);
+                if constexpr (NP == 3) wt_split8(t, hi, lo);
+                else wt_hi8(t, hi);                      // one product: only the hi image exists
                 const int slot = (st_ring0 + hp0 + pl) & (P::NSLOT - 1);
                 char* dst = lds + slot * P::PLANE + p * 32 + hsel * 16;
                 *reinterpret_cast<u32x4*>(dst + P::X_OFF) = hi;
-                *reinterpret_cast<u32x4*>(dst + P::XLO_OFF) = lo;
+                if constexpr (NP == 3) *reinterpret_cast<u32x4*>(dst + P::XLO_OFF) = lo;
             };
             wt_static_for<NR2>(sround);
             if (st_k == 0) wt_static_for<NRX - NR2>([&](auto R) { sround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
@@ -319,16 +333,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #pragma unroll
                     for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
-                u32x4 hi, lo;
+                u32x4 hi, lo = u32x4{0u, 0u, 0u, 0u};
                 if constexpr (DS == 1) {
                     const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                     hi = ok ? __builtin_bit_cast(u32x4, vd[r][0]) : z;
-                    lo = ok ? __builtin_bit_cast(u32x4, vd[r][1]) : z;
+                    if constexpr (NP == 3) lo = ok ? __builtin_bit_cast(u32x4, vd[r][1]) : z;
+                } else if constexpr (NP == 3 || DS == 3) {
+                    wt_split8(t, hi, lo);                // (fused apply: the published gradient keeps its lo half whatever this kernel multiplies)
                 } else {
-                    wt_split8(t, hi, lo);
+                    wt_hi8(t, hi);
                 }
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + p * 32 + hsel * 16) = hi;
-                *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
+                if constexpr (NP == 3) *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
                 if constexpr (DS == 3) {                 // publish dy in split form (every position is staged once by input-channel group 0)
                     if (ok && cgp == 0 && a.gb_out) {    // (no output tensor: nobody but this weight gradient consumes the gradient, e.g. the stem)
                         const int row = p >> 4, z = row / TY;
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #pragma unroll
             for (int p = 0; p < 3; ++p) pw[p] = ((s0 + p) & (P::NSLOT - 1)) * P::PLANE + xrow_off;
             const char* dl = lds + P::D_OFF + (w & 1) * P::DBUF + drow_off;
-            wtz_consume<OT>(lds, pw, dl, acc);
+            wtz_consume<OT, NP>(lds, pw, dl, acc);
             __syncthreads();
         }
         // ---- the waves that worked on the same output tile are summed through LDS (the staging memory is free now): ONE partial per
@@ -424,12 +440,12 @@ size_t wgrad3_tr_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W) 
     return (size_t)c.nbx * 27 * Cout * Cin * sizeof(float);       // one partial per workgroup
 }
 
-template <int OT, int XS, int DS>
+template <int OT, int XS, int DS, int NP = 3>
 static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     using P = WTZ<OT>;
     static PerDevice attr_done;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_tz_kernel<OT, XS, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3_tz_kernel<OT, XS, DS, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(wgrad3_tz)");
         attr_done.set();
     }
@@ -437,7 +453,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     const long ncol = (long)a.N * nty * ntx;
     int nbx = c.nbx;
     if (nbx > ncol) nbx = (int)ncol;
-    hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
+    hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS, NP>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
     return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
@@ -450,20 +466,26 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         set_error("wgrad3_tr: workspace too small");
         return RU_ENOMEM;
     }
+    const bool p1 = a.products == 1;                     // one-product forms exist for the variants the engine's backward runs
     if (a.gb_y) {
         RU_REQUIRE(!a.dy_c4 && a.gb_d && a.gb_scale && a.gb_shift && a.gb_coef && (a.gb_out || a.x_c4),
                    "wgrad3_tr: the fused GroupNorm-backward apply needs all of its operands");
-        if (a.x_c4) { RU_REQUIRE(c.ot == 1, "wgrad3_tr: a 4-channel copy stands for ONE 16-channel block"); return wtz_cfg<1, 1, 3>(a, c, s); }   // stem: x = network input
+        if (a.x_c4) {                                    // stem: x = network input
+            RU_REQUIRE(c.ot == 1, "wgrad3_tr: a 4-channel copy stands for ONE 16-channel block");
+            return p1 ? wtz_cfg<1, 1, 3, 1>(a, c, s) : wtz_cfg<1, 1, 3>(a, c, s);
+        }
+        if (p1 && c.ot == 1) return wtz_cfg<1, 0, 3, 1>(a, c, s);
         if (c.ot == 2) return wtz_cfg<2, 0, 3>(a, c, s);   // two output blocks per workgroup: the constants of a block are fetched when it is converted
         return wtz_cfg<1, 0, 3>(a, c, s);
     }
     const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
     if (c.ot == 2) {
         RU_REQUIRE(xs == 0 && ds != 2, "wgrad3_tr: 4-channel copies stand for ONE 16-channel block");
+        if (p1 && ds == 1) return wtz_cfg<2, 0, 1, 1>(a, c, s);
         return ds == 1 ? wtz_cfg<2, 0, 1>(a, c, s) : wtz_cfg<2, 0, 0>(a, c, s);
     }
     if (xs == 1) { RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy"); return ds == 1 ? wtz_cfg<1, 1, 1>(a, c, s) : wtz_cfg<1, 1, 0>(a, c, s); }
-    if (ds == 2) return wtz_cfg<1, 0, 2>(a, c, s);
+    if (ds == 2) return p1 ? wtz_cfg<1, 0, 2, 1>(a, c, s) : wtz_cfg<1, 0, 2>(a, c, s);
     return ds == 1 ? wtz_cfg<1, 0, 1>(a, c, s) : wtz_cfg<1, 0, 0>(a, c, s);
 }
 

@@ -64,6 +64,7 @@ class UNetEngine:
                  number_of_channels=(16, 32, 64, 128), number_of_outputs=3, precision="f32"):
         self.layout = ParamLayout(depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs)
         self.h = self.layout.handle
+        self.grad_precision = "bf16x3"
         self.set_precision(precision)
         self.n_out = int(number_of_outputs)
         self._ws = None
@@ -74,6 +75,15 @@ class UNetEngine:
         """"f32": exact-f32 MFMA convolutions; "bf16x3": split-bf16 3-product convolutions (|dp| ~ 5e-5)."""
         L.check(L.load().ru_unet_set_precision(self.h, L.PRECISIONS[precision]), "ru_unet_set_precision")
         self.precision = precision
+
+    def set_grad_precision(self, grad_precision):
+        """Arithmetic of the 3x3x3 data / weight gradients under a bf16x3 forward (ru_unet_set_grad_precision): "bf16x3" (default, three
+        split-bf16 products) or "bf16" (operands rounded to bf16, one product: BASELINE configs[2]'s "bf16 forward+backward" for the
+        backward; the forward and the probabilities do not change)."""
+        if grad_precision not in L.GRAD_PRECISIONS:
+            raise ValueError("grad_precision must be one of %s" % sorted(L.GRAD_PRECISIONS))
+        L.check(L.load().ru_unet_set_grad_precision(self.h, L.GRAD_PRECISIONS[grad_precision]), "ru_unet_set_grad_precision")
+        self.grad_precision = grad_precision
 
     def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True):
         """Backward-pass fusions of the voxel-major engine (ru_unet_set_fusion; both on by default, tests switch them off to hold the

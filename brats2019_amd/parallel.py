@@ -24,13 +24,15 @@ import torch.distributed as dist
 class HipBackend:
     """Arithmetic of the step on the local GPU through the C-ABI (no CPU fallback)."""
 
-    def __init__(self, cfg=None, device=None, precision=None):
+    def __init__(self, cfg=None, device=None, precision=None, grad_precision=None):
         from . import _lib as L
         from .engine import UNetEngine, DEFAULT_CFG
         from .model import default_precision
         L.require_gpu()
         self.cfg = dict(cfg or DEFAULT_CFG)
         self.engine = UNetEngine(precision=precision or default_precision(self.cfg["number_of_channels"]), **self.cfg)
+        if grad_precision:
+            self.engine.set_grad_precision(grad_precision)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.total = self.engine.layout.total
         # contiguous runs of LIVE parameters: the reference's Adam skips tensors whose grad is None (the never-executed

@@ -37,6 +37,7 @@ extern "C" {
  *                  Needs W % 4 == 0, otherwise the f32 kernel runs.  HBM tensors stay float32 in both modes. */
 #define RU_PREC_F32 0
 #define RU_PREC_BF16X3 1
+#define RU_PREC_BF16 2        /* gradient precision only (ru_unet_set_grad_precision): plain bf16 operands, one MFMA product, fp32 accumulate */
 
 typedef void* ru_stream_t;                /* hipStream_t */
 typedef struct ru_unet* ru_unet_t;        /* opaque engine handle */
@@ -148,6 +149,16 @@ int ru_unet_set_precision(ru_unet_t h, int precision);
  * reference's optimizer changes the weights every step (train.py:220).  */
 int ru_unet_freeze_params(ru_unet_t h, int frozen);
 int ru_unet_get_precision(ru_unet_t h);
+/* Arithmetic of the 3x3x3 DATA and WEIGHT gradients of subsequent ru_unet_backward calls when the forward precision is RU_PREC_BF16X3
+ * (ignored otherwise).  RU_PREC_BF16X3 (default): three split-bf16 products like the forward, gradients within ~1e-5 relative of float32.
+ * RU_PREC_BF16: the operands of the gradient convolutions are rounded to bf16 (hi*hi only, fp32 accumulate) -- BASELINE configs[2]
+ * ("bf16 forward+backward") taken literally for the backward; the forward, and with it the probabilities (bar 1e-3, train.py:201-205 /
+ * model.py:407-433), is untouched.  One third of the matrix work and half of the operand staging in those kernels; parameter gradients
+ * then carry bf16 rounding noise (relative L2 error ~3e-3 per tensor against the float32 reference, tests/test_hip_unet.py).  The
+ * persistent voxel-major kernels honour it (every level of the shipped configuration at training sizes); the small-shape fallbacks and
+ * the 4-channel stem / head data paths keep three products. */
+int ru_unet_set_grad_precision(ru_unet_t h, int precision);
+int ru_unet_get_grad_precision(ru_unet_t h);
 /* Backward-pass fusions of the voxel-major split-bf16 engine (both on by default; same arithmetic either way up to summation order --
  * the separate passes stay available so that tests can hold the fused kernels to them):
  *   RU_FUSE_GN_BWD_STATS  the GroupNorm-backward sums are taken in the epilogue of the data-gradient conv that produces the incoming

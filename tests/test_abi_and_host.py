@@ -182,6 +182,7 @@ def test_argument_errors_are_reported_not_thrown(lib):
 
 def test_default_precision_rule():
     from brats2019_amd import model as M
+    from brats2019_amd import _lib as L
     assert M.default_precision([16, 32, 64, 128]) == "bf16x3" and M.default_precision([8, 16, 32]) == "f32"
     net = M.UNet(**O.DEFAULT_CFG)
     assert net._get_engine().precision == "bf16x3"
@@ -189,3 +190,14 @@ def test_default_precision_rule():
     assert net._get_engine().precision == "f32"
     with pytest.raises(ValueError):
         net.set_precision("fp16")
+    # gradient precision: three products unless asked otherwise; the setting survives until the engine exists and is applied to it
+    assert net._get_engine().grad_precision == "bf16x3"
+    lib = L.load()
+    assert lib.ru_unet_get_grad_precision(net._get_engine().h) == L.GRAD_PRECISIONS["bf16x3"]
+    net.set_grad_precision("bf16")
+    assert net._get_engine().grad_precision == "bf16" and lib.ru_unet_get_grad_precision(net._get_engine().h) == L.GRAD_PRECISIONS["bf16"]
+    net2 = M.UNet(**O.DEFAULT_CFG).set_grad_precision("bf16")
+    assert net2._get_engine().grad_precision == "bf16"
+    with pytest.raises(ValueError):
+        net.set_grad_precision("f32")
+    assert lib.ru_unet_set_grad_precision(net._get_engine().h, 0) < 0 and lib.ru_unet_set_grad_precision(None, 1) < 0

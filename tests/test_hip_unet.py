@@ -28,11 +28,13 @@ def build_model(cfg, seed, precision="f32"):
     return net.cuda(), params
 
 
-def run_train_step(cfg, n, dhw, seed, precision="f32", fusion=None):
+def run_train_step(cfg, n, dhw, seed, precision="f32", fusion=None, grad_precision=None):
     from brats2019_amd import loss as L
     net, params = build_model(cfg, seed, precision)
     if fusion is not None:
         net._get_engine().set_fusion(*fusion)
+    if grad_precision is not None:
+        net.set_grad_precision(grad_precision)
     x = T(O.make_input(n, *dhw, seed=seed)).cuda()
     g = T(O.make_target(n, *dhw, seed=seed)).cuda()
     net.train()
@@ -455,3 +457,39 @@ def test_probe_times_the_four_input_resolution_convs_of_a_forward():
         net([x])
         assert eng.probe_read() == (0.0, 0)
     assert torch.equal(out, ref) and torch.equal(out2, ref)
+
+
+@pytest.mark.gpu
+def test_unet128_train_step_bf16_gradient_precision(golden):
+    """ru_unet_set_grad_precision(RU_PREC_BF16): the 3x3x3 data / weight gradients on bf16-rounded operands (one MFMA product) under the
+    unchanged bf16x3 forward.  Against the REFERENCE fixture: probabilities, mask and loss exactly as in the bf16x3 run (same forward:
+    2e-4 / 5e-5), every parameter-gradient norm within 5e-3.  Against the three-product backward on the same inputs: every parameter
+    gradient within bf16 rounding noise -- relative L2 error below 1e-2 for convolution weights (measured ~3e-3) and below 3e-2 for the
+    GroupNorm / bias vectors (sums of millions of signed terms that cancel) -- and NOT identical (the switch is live)."""
+    g = golden("unet128_train")
+    net3, probs3, loss3, _ = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "bf16x3")
+    net1, probs1, loss1, vals1 = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "bf16x3", grad_precision="bf16")
+    assert net1._get_engine().grad_precision == "bf16" and net3._get_engine().grad_precision == "bf16x3"
+    assert torch.equal(probs1, probs3) and float(loss1) == float(loss3)           # the forward does not depend on the switch
+    p = probs1.cpu().numpy()
+    assert np.abs(p.ravel()[:: int(g["sample_stride"])][:4096] - g["samples"]).max() <= 2e-4
+    assert abs(float(loss1) - float(g["loss"])) < 5e-5
+    worst_w, worst_v, differs = (0.0, ""), (0.0, ""), False
+    g3 = dict(net3.named_parameters())
+    for k, prm in net1.named_parameters():
+        if prm.grad is None:
+            assert g3[k].grad is None
+            continue
+        a, b = prm.grad.double(), g3[k].grad.double()
+        rel = float(torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(b))
+        differs = differs or rel > 0
+        if a.dim() == 5:
+            worst_w = max(worst_w, (rel, k))
+        else:
+            worst_v = max(worst_v, (rel, k))
+        ref = float(g["gnorm_" + k])
+        assert abs(float(torch.linalg.vector_norm(a)) - ref) <= 5e-3 * ref + 1e-9, (k, float(torch.linalg.vector_norm(a)), ref)
+    print("bf16 gradient precision vs three products: worst relative L2 error, conv weights %.2e (%s), vectors %.2e (%s)" % (worst_w + worst_v))
+    assert differs
+    assert worst_w[0] < 1e-2, worst_w
+    assert worst_v[0] < 3e-2, worst_v

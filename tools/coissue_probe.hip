@@ -150,6 +150,50 @@ static void run_mix(float* out) {
     printf("MFMA wave with %-18s after every third MFMA: %5.2f ns per MFMA\n", nm[MIX], ms * 1e6 / (24.0 * iters));
 }
 
+// MFMA only, one wave per SIMD, operands either all 1.0 (the probes above) or pseudo-random bf16 in (-2, 2): the matrix pipe's power
+// depends on the data, and the chip runs into its power cap with real data long before the issue rate is the limit
+template <int RANDOM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void probe_data(float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    u32x4* buf = reinterpret_cast<u32x4*>(lds);
+    const int lane = threadIdx.x & 63;
+    unsigned st = 0x9e3779b9u * (threadIdx.x + 1) + blockIdx.x * 7919u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; const unsigned m = (st >> 9) & 0x7fu, e = 0x3f00u + ((st >> 20) & 0x80u), sg = (st >> 16) & 0x8000u; return (sg | e | m) & 0xffffu; };
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) {
+        u32x4 v;
+        for (int j = 0; j < 4; ++j) v[j] = RANDOM ? (rnd() | (rnd() << 16)) : 0x3f803f80u;
+        buf[i] = v;
+    }
+    __syncthreads();
+    bf16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = __builtin_bit_cast(bf16x8, buf[lane + i * 64]); b[i] = __builtin_bit_cast(bf16x8, buf[lane + 512 + i * 64]); }
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k & 3], b[(k >> 2) & 3], acc[k & 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+template <int RANDOM, int WAVES>
+static void run_data(float* out, int launches) {
+    const int iters = 20000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(probe_data<RANDOM, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    probe_data<RANDOM, WAVES><<<256, WAVES * 64, 81920>>>(out, 200);
+    (void)hipEventRecord(e0);
+    for (int l = 0; l < launches; ++l) probe_data<RANDOM, WAVES><<<256, WAVES * 64, 81920>>>(out, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double ns = ms * 1e6 / (24.0 * iters * launches * (WAVES / 4.0));
+    printf("MFMA only, %d wave(s) per SIMD, %s operands, %3d launches of %.1f ms: %5.2f ns per MFMA per SIMD -> %5.0f TFLOP/s\n", WAVES / 4, RANDOM ? "random" : "all-ones",
+           launches, ms / launches, ns, 16384.0 / ns * 1024 / 1e3);
+}
+
 int main() {
     float* out; (void)hipMalloc(&out, 1 << 20);
     unsigned long long* stat; (void)hipMalloc(&stat, 64);
@@ -160,6 +204,7 @@ int main() {
         RU_BOTH(K_SUB); RU_BOTH(K_DSW); RU_BOTH(K_DSR);
         run<K_IDLE, true>(out, stat);
     }
+    run_data<0, 4>(out, 1); run_data<1, 4>(out, 1); run_data<0, 4>(out, 50); run_data<1, 4>(out, 50); run_data<0, 8>(out, 50); run_data<1, 8>(out, 50);
     for (int rep = 0; rep < 2; ++rep) { run_mix<0>(out); run_mix<1>(out); run_mix<2>(out); run_mix<3>(out); run_mix<4>(out); }
     return 0;
 }
