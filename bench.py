@@ -17,6 +17,7 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  `whole_step_frac` = the per-layer roofline of the whole step (sum over the convolutions of max(executed FLOPs / MFMA
                  peak, fp32 in+out bytes / HBM peak)) divided by the measured step time,
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
+  train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
   fwd          : forward-only volumes/s at batch 1 in the precision of the run,
   fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1).
 """
@@ -361,6 +362,20 @@ def main():
                               "algorithmic_tflops": round(it / dt32 * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
                               "roofline_frac": round(step_roofline_ms(1, args.size, "f32", forward_only=True) / (1e3 * dt32 / it), 4)}
             del be32
+        if args.precision == "bf16x3" and args.grad_precision == "bf16x3":
+            # the same step with the opt-in gradient precision RU_PREC_BF16 (3x3x3 data / weight gradients on bf16-rounded operands, one
+            # MFMA product; forward unchanged): reported beside the headline, never as `value`
+            backend.engine.freeze_params(False)
+            backend.engine.set_grad_precision("bf16")
+            for _ in range(2):
+                one_step()
+            dtg = time_region(one_step, args.steps, False)
+            backend.engine.set_grad_precision("bf16x3")
+            backend.engine.freeze_params(True)       # (the sliding-window leg below is inference again)
+            out["train_bf16_grad"] = {"value": round(args.batch * args.steps / dtg, 3), "unit": "volumes/s", "ms_per_step": round(1e3 * dtg / args.steps, 3),
+                                      "grad_precision": "bf16 operands, one MFMA product, fp32 accumulate in the 3x3x3 data / weight gradients (ru_unet_set_grad_precision); "
+                                                        "forward bf16x3 as in `value`; parameter gradients within 2.5e-3 relative L2 of the three-product backward "
+                                                        "(tests/test_hip_unet.py::test_unet128_train_step_bf16_gradient_precision)"}
         out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu)
         out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
         if args.size == 128:
