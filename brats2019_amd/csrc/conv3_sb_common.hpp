@@ -196,7 +196,10 @@ struct SBChoice { int tz, ty; };
 static inline SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
     const int ncog = cdiv(Cout, 16);
     auto blocks = [&](int tz, int ty) { return (long)N * cdiv(D, tz) * cdiv(H, ty) * cdiv(W, 16) * ncog; };
-    if (blocks(4, 8) >= 256) return {4, 8};        // one persistent producer/consumer workgroup per CU is enough (deep levels: 8 chunks per tile)
+    // the persistent kernel addresses a 16-channel block of a voxel-major input through a buffer descriptor with 32-bit byte offsets
+    // (its out-of-range lanes are the zero padding): volumes of 2^25 voxels and more (e.g. 336^3) take the one-stage kernel
+    const bool fits32 = (size_t)D * H * W * 64 < ((size_t)1 << 31);
+    if (fits32 && blocks(4, 8) >= 256) return {4, 8};   // one persistent producer/consumer workgroup per CU is enough (deep levels: 8 chunks per tile)
     if (blocks(2, 8) >= 1024) return {2, 8};
     return {2, 4};
 }

@@ -125,3 +125,21 @@ def test_upsample_c16_equals_ncdhw(shape):
     dx_ref = ops.upsample2x_bwd(dy)
     dx = ops.from_c16(ops.upsample2x_bwd_c16(ops.to_c16(dy)))
     assert float((dx - dx_ref).abs().max()) <= 1e-5
+
+
+def test_conv3_voxel_major_volume_beyond_32bit_block_offsets():
+    """Maximum sizes: the persistent kernel addresses a 16-channel block of its voxel-major input with 32-bit byte offsets (buffer
+    loads), so a volume of 2^25 voxels or more -- 64 bytes per voxel: 2 GiB per block -- must take the one-stage kernel instead of
+    wrapping around.  1 x 16 x 336 x 320 x 320 (34.4 M voxels) against the exact-f32 kernel, and the far corner against a direct sum."""
+    from brats2019_amd import ops
+    d, h, w = 336, 320, 320
+    assert d * h * w * 64 >= 2 ** 31
+    x = _rand(1, 16, d, h, w, seed=11)
+    wt = _rand(16, 16, 3, 3, 3, seed=12) * 0.1
+    y = ops.from_c16(ops.conv3d_layout(ops.to_c16(x), wt, in_c16=True, out_c16=True))
+    exact = ops.conv3d(x, wt, precision="f32")
+    assert float((y - exact).abs().max()) <= 2e-4 * float(exact.abs().max())
+    # last voxel of the volume, channel 5: taps beyond the far faces are zero padding
+    patch = x[0, :, d - 2:, h - 2:, w - 2:].double()
+    direct = float((patch * wt[5, :, :2, :2, :2].double()).sum())
+    assert abs(float(y[0, 5, d - 1, h - 1, w - 1]) - direct) <= 1e-4 * max(1.0, abs(direct))
