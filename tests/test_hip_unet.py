@@ -493,3 +493,29 @@ def test_unet128_train_step_bf16_gradient_precision(golden):
     assert differs
     assert worst_w[0] < 1e-2, worst_w
     assert worst_v[0] < 3e-2, worst_v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 72, 88), (3, 24, 40, 48)], ids=["ragged-x", "three-samples"])
+def test_bf16_gradient_precision_at_ragged_shapes(shape):
+    """The one-product gradient kernels at extents that are not multiples of the (4, 8, 16) tile (every level below the first is ragged)
+    and with an odd sample count: same forward, parameter gradients within bf16 rounding noise of the three-product backward."""
+    n, d, h, w = shape
+    net, _ = build_model(O.DEFAULT_CFG, 99, "bf16x3")
+    x = torch.randn(n, 4, d, h, w, generator=torch.Generator().manual_seed(5)).cuda()
+    up = torch.randn(n, 3, d, h, w, generator=torch.Generator().manual_seed(6)).cuda() * 1e-3
+    res = {}
+    for gp in ("bf16x3", "bf16"):
+        net.set_grad_precision(gp)
+        net.zero_grad()
+        p = net([x])[0]
+        (p * up).sum().backward()
+        res[gp] = (p.detach().clone(), {k: q.grad.detach().double().clone() for k, q in net.named_parameters() if q.grad is not None})
+    assert torch.equal(res["bf16"][0], res["bf16x3"][0])
+    worst = (0.0, "")
+    for k, g3 in res["bf16x3"][1].items():
+        rel = float(torch.linalg.vector_norm(res["bf16"][1][k] - g3) / torch.linalg.vector_norm(g3))
+        worst = max(worst, (rel, k))
+        assert rel < (1e-2 if g3.dim() == 5 else 3e-2), (k, rel)
+    assert worst[0] > 0
+    print("bf16 gradient precision at %s: worst relative L2 error %.2e (%s)" % ((shape,) + worst))
