@@ -37,18 +37,31 @@ constexpr int kGroups = 8;        // GroupNorm(8, C), model.py:95-96,338
 constexpr float kEps = 1e-5f;
 constexpr int kInCh = 4;          // model.py:336
 
+// Bump allocator over the caller's workspace.  Tensors grow from the bottom (`off`); an inference forward REWINDS to a mark when a
+// block's temporaries are dead (everything runs on one stream, so a later kernel may overwrite them), `peak` is the high-water mark.
+// Small per-layer arrays that must outlive those rewinds (GroupNorm mean / rstd / scale / shift, read by ru_unet_gn_stats and by the
+// backward) are taken from the TOP of the workspace (`keep`).  The dry walk of ru_unet_workspace_bytes mirrors the real one call for call.
 struct Arena {
     char* base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0, off = 0, peak = 0, keep = 0;
     bool dry = true, failed = false;
     float* alloc(size_t nfloats) {
         const size_t bytes = align_up(nfloats * sizeof(float), 256);
         const size_t o = off;
         off += bytes;
+        if (off > peak) peak = off;
         if (dry) return nullptr;
-        if (off > cap) { failed = true; return nullptr; }
+        if (off + keep > cap) { failed = true; return nullptr; }
         return reinterpret_cast<float*>(base + o);
     }
+    float* alloc_keep(size_t nfloats) {
+        keep += align_up(nfloats * sizeof(float), 256);
+        if (dry) return nullptr;
+        if (off + keep > cap) { failed = true; return nullptr; }
+        return reinterpret_cast<float*>(base + cap - keep);
+    }
+    void rewind(size_t mark) { off = mark; }
+    size_t need() const { return peak + keep; }
 };
 
 #define RU_RUN(call)                      \
@@ -140,7 +153,7 @@ struct ru_unet {
     bool have_fwd = false, training = false;
     int N = 0, D = 0, H = 0, W = 0;
     char* ws = nullptr;
-    size_t ws_bytes = 0, fwd_end = 0;
+    size_t ws_bytes = 0, fwd_end = 0, fwd_keep = 0;
     float* pack = nullptr;
     const float* x_in = nullptr;
     const float* x_in4 = nullptr;   // 4-channel copy of the input made for the stem conv (C16 flow), reused by its weight gradient
@@ -381,10 +394,10 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
                     bool x_c4 = false) {
     const int nblk = h->c16 ? conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
-    out_gn.mean = A.alloc((size_t)N * kGroups);
-    out_gn.rstd = A.alloc((size_t)N * kGroups);
-    out_gn.scale = A.alloc((size_t)N * Cout);
-    out_gn.shift = A.alloc((size_t)N * Cout);
+    out_gn.mean = A.alloc_keep((size_t)N * kGroups);
+    out_gn.rstd = A.alloc_keep((size_t)N * kGroups);
+    out_gn.scale = A.alloc_keep((size_t)N * Cout);
+    out_gn.shift = A.alloc_keep((size_t)N * Cout);
     Conv3Args a{};
     a.x = x; a.wp = wp; a.y = y; a.mode = h->precision; a.wfrag = wf;
     a.in_scale = in_gn ? in_gn->scale : nullptr;
@@ -408,7 +421,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
         (void)hipEventRecord(h->probe_ev[h->probe_used + 1], s);
         h->probe_used += 2;
     }
-    out_gn.k = (h->training && h->c16) ? A.alloc((size_t)N * 3 * Cout) : nullptr;
+    out_gn.k = (h->training && h->c16) ? A.alloc_keep((size_t)N * 3 * Cout) : nullptr;
     RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
                               (size_t)D * H * W, kGroups, kEps, s, out_gn.k));
     h->gn_order.push_back(out_gn);
@@ -425,6 +438,15 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     sv.xprev = xprev;
     const int C = bp.c;
     const float* x = xprev;
+    // inference: nothing but the block's output survives it -- the output is allocated first and the arena rewound behind it at the end
+    // (the workspace of 8 tiles of 192^3 fell from 45 to ~20 GiB); training keeps every tensor for the backward
+    const bool recycle = !h->training;
+    float* out_early = nullptr;
+    if (recycle) {
+        const int sh = bp.down >= 0 ? 1 : 0;
+        out_early = A.alloc((size_t)N * C * (size_t)(D >> sh) * (H >> sh) * (W >> sh));
+    }
+    const size_t mark = A.off;
     if (bp.down >= 0) {
         const int Do = D / 2, Ho = H / 2, Wo = W / 2;
         const size_t Vo = (size_t)Do * Ho * Wo;
@@ -452,11 +474,12 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     sv.y2 = A.alloc((size_t)N * C * V);
     rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, h->fpack + bp.fk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
     if (rc) return rc;
-    sv.out = A.alloc((size_t)N * C * V);
+    sv.out = recycle ? out_early : A.alloc((size_t)N * C * V);
     if (h->c16) RU_RUN(gn_apply16_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s,
                                          xin_gn ? xin_gn->scale : nullptr, xin_gn ? xin_gn->shift : nullptr, xin_gn ? xin_gn->act_slope : 1.f));
     else RU_RUN(gn_apply_launch(sv.y2, sv.g2.scale, sv.g2.shift, x, sv.out, N, C, V, kSlope, s));
     *out = sv.out;
+    if (recycle) A.rewind(mark);
     return RU_OK;
 }
 
@@ -485,6 +508,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     h->x_in4 = nullptr;
     h->x_in4_planned = false;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
+    const size_t stem_mark = A.off;
     if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
         // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
         float* x4 = A.alloc((size_t)N * 4 * Vl(0));
@@ -499,6 +523,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         rc = conv3_gn(h, A, s, x, h->pack + h->pk_in, h->fpack + h->fk_in, h->y0, nullptr, P(h, params, h->nin_w), P(h, params, h->nin_b), h->g0, N, kInCh, C0, Dl[0], Hl[0], Wl[0], false);
     }
     if (rc) return rc;
+    if (!h->training) A.rewind(stem_mark);                      // inference: the 4-channel copy and the statistics partials are dead (the weight gradient reuses the copy in training)
     // norm_input has no activation.  Voxel-major flow: its output is never written -- the first block reads the raw stem output with
     // the affine fused into its staging (conv, weight gradient) and into its residual add
     h->g0.act_slope = 1.0f;
@@ -539,6 +564,9 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         // C16 flow: the 1x1x1 conv and the trilinear interpolation are both linear and act on different axes, so
         // conv(up(z)) = up(conv(z)): the conv runs on the COARSE grid (8x fewer voxels) and the up-sampling on Ci = Cc/2 channels,
         // with the LeakyReLU fused into its store; the Cc-channel fine tensor `u` never exists.
+        const bool recycle = !h->training;                       // inference: only the stage's output c survives it
+        float* c_early = recycle ? A.alloc((size_t)N * Ci * Vl(i)) : nullptr;
+        const size_t dmark = A.off;
         if (!h->c16) {
             ds.u = A.alloc((size_t)N * Cc * Vl(i));
             RU_RUN(up2_fwd_launch(cur, ds.u, N, Cc, Dl[i + 1], Hl[i + 1], Wl[i + 1], s));
@@ -547,7 +575,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         Conv1Args c1{};
         c1.x0 = ds.u; c1.C0 = Cc; c1.y = ds.v; c1.out_slope = kSlope;                                                 // + LeakyReLU (model.py:422)
         c1.N = N; c1.Cout = Ci; c1.V = Vl(i);
-        ds.c = A.alloc((size_t)N * Ci * Vl(i));
+        ds.c = recycle ? c_early : A.alloc((size_t)N * Ci * Vl(i));
         Conv1Args c2{};
         c2.x0 = ds.skip; c2.C0 = Ci; c2.x1 = ds.v; c2.C1 = Ci;                                                        // cat([skip, up]) (model.py:424)
         c2.y = ds.c; c2.out_slope = 1.f; c2.N = N; c2.Cout = Ci; c2.V = Vl(i);
@@ -565,6 +593,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
             c2.wT = h->pack + h->pk_decT[i]; c2.ldw = Ci;
             RU_RUN(conv1_launch(c2, s));
         }
+        if (recycle) A.rewind(dmark);
         cur = ds.c;
         h->dec_s[i].assign(h->dec_blocks[i].size(), BlockSave());
         for (size_t j = 0; j < h->dec_blocks[i].size(); ++j) {
@@ -949,7 +978,7 @@ extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int 
     if (training) {
         if (unet_backward_impl(&tmp, nullptr, nullptr, nullptr, (float*)1, A, nullptr) != RU_OK) return 0;
     }
-    return A.off + 4096;
+    return A.need() + 4096;
 }
 
 extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x, float* probs, int N, int D, int H, int W, int training,
@@ -966,6 +995,7 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_forward: workspace too small (%zu bytes given)", ws_bytes); return RU_ENOMEM; }
     h->fwd_end = A.off;
+    h->fwd_keep = A.keep;
     h->have_fwd = true;
     return RU_OK;
 }
@@ -974,7 +1004,7 @@ extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* d
     RU_REQUIRE(h && params && dprobs && grads, "ru_unet_backward: null argument");
     if (!h->have_fwd || !h->training) { set_error("ru_unet_backward: needs a preceding training-mode ru_unet_forward"); return RU_ESTATE; }
     Arena A;
-    A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end;
+    A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end; A.keep = h->fwd_keep;
     int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream);
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_backward: workspace too small"); return RU_ENOMEM; }

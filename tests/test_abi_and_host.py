@@ -201,3 +201,18 @@ def test_default_precision_rule():
     with pytest.raises(ValueError):
         net.set_grad_precision("f32")
     assert lib.ru_unet_set_grad_precision(net._get_engine().h, 0) < 0 and lib.ru_unet_set_grad_precision(None, 1) < 0
+
+
+def test_inference_workspace_recycles_block_temporaries():
+    """ru_unet_workspace_bytes (host-side dry walk, no GPU): an inference forward rewinds the arena behind every block's output, so its
+    workspace is less than a third of the training one at the same shape, grows linearly with the batch, and 8 tiles of 192^3 -- the
+    reference's sliding-window tile (train.py:158-174) -- fit in 26 GiB (45 GiB before the rewinds)."""
+    from brats2019_amd import _lib as L
+    from brats2019_amd.engine import UNetEngine
+    lib = L.load()
+    eng = UNetEngine(precision="bf16x3")
+    ws = lambda n, s, tr: lib.ru_unet_workspace_bytes(eng.h, n, s, s, s, tr)
+    assert 0 < ws(4, 128, 0) < ws(4, 128, 1) / 3
+    assert abs(ws(8, 128, 0) - 2 * ws(4, 128, 0)) < 0.05 * ws(8, 128, 0)
+    assert ws(8, 192, 0) < 26 * 2 ** 30
+    assert ws(1, 36, 0) == 0                      # extents must be divisible by 8 (three stride-2 levels): size query says 0
