@@ -376,12 +376,13 @@ def main():
                                       "grad_precision": "bf16 operands, one MFMA product, fp32 accumulate in the 3x3x3 data / weight gradients (ru_unet_set_grad_precision); "
                                                         "forward bf16x3 as in `value`; parameter gradients within 2.5e-3 relative L2 of the three-product backward "
                                                         "(tests/test_hip_unet.py::test_unet128_train_step_bf16_gradient_precision)"}
-        out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu)
-        out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
         if args.size == 128:
             out["sliding_window"] = sliding_window_probe(backend, flat, args.precision)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
+    if rank == 0 and not args.no_extras:               # at every N: the dominant kernel as timed inside rank 0's steps
+        out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu)
+        out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
