@@ -715,11 +715,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 constexpr int r = decltype(S)::value / 5, f = decltype(S)::value % 5;
                 return fbase[f < 4 ? f : (r < 8 ? 4 : 5)] + r * HX;
             };
-            bf16x8 fh[3], fl[3];                         // fragment ring: step s lives in slot s % 3, fetched two steps ahead
-            fh[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{})]);
-            if constexpr (NP == 3) fl[0] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 0>{}) + 2 * HVOLP]);
-            fh[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{})]);
-            if constexpr (NP == 3) fl[1] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, 1>{}) + 2 * HVOLP]);
+            constexpr int RING = (dbg & 16384) ? 4 : 3;  // (devtools bit 16384: one more step of look-ahead; +8 VGPRs)
+            constexpr int AH = RING - 1;                 // steps of look-ahead
+            bf16x8 fh[RING], fl[RING];                   // fragment ring: step s lives in slot s % RING, fetched AH steps ahead
+            static_for<AH>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                fh[j] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, j>{})]);
+                if constexpr (NP == 3) fl[j] = __builtin_bit_cast(bf16x8, buf[frag_ofs(std::integral_constant<int, j>{}) + 2 * HVOLP]);
+            });
             float4 radd[3], rbst[3];                     // per-row operands (residual / BST forward tensor): tile i uses slot i % 3, loaded at row i + 1,
 #pragma unroll                                           // consumed at row i + 3
             for (int j = 0; j < 3; ++j) { radd[j] = make_float4(0.f, 0.f, 0.f, 0.f); rbst[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -730,12 +733,12 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
             };
             static_for<NSTEP>([&](auto S) {
-                constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % 3, nxt = (s + 2) % 3;
+                constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % RING, nxt = (s + AH) % RING;
                 const bf16x8 ah = fh[cur], al = fl[cur];
-                bool fetched = (s + 2 >= NSTEP);
+                bool fetched = (s + AH >= NSTEP);
                 auto fetch = [&]() __attribute__((always_inline)) {            // the slot of step s-1 is free once its MFMAs are issued
-                    if constexpr (s + 2 < NSTEP) {
-                        const int o = frag_ofs(std::integral_constant<int, (s + 2 < NSTEP ? s + 2 : 0)>{});
+                    if constexpr (s + AH < NSTEP) {
+                        const int o = frag_ofs(std::integral_constant<int, (s + AH < NSTEP ? s + AH : 0)>{});
                         fh[nxt] = __builtin_bit_cast(bf16x8, buf[o]);
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (NP == 3) {
