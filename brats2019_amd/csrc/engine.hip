@@ -971,6 +971,8 @@ static int check_dims(ru_unet* h, int N, int D, int H, int W) {
 extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int W, int training) {
     if (!h || check_dims(h, N, D, H, W) != RU_OK) return 0;
     ru_unet tmp = *h;            // dry walk on a copy: does not disturb a live forward state
+    tmp.probe_ev.clear();        // (the copy must not own the handle's HIP events: its destructor would destroy them)
+    tmp.probe_on = false;
     tmp.N = N; tmp.D = D; tmp.H = H; tmp.W = W; tmp.training = training != 0;
     Arena A;
     A.dry = true;

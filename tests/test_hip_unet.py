@@ -453,6 +453,12 @@ def test_probe_times_the_four_input_resolution_convs_of_a_forward():
         ms, n = eng.probe_read()
         assert n == 8 and ms > 0.0
         assert eng.probe_read() == (0.0, 0)
+        # a workspace-size query walks a COPY of the handle: the copy must not take the recorded events with it
+        from brats2019_amd import _lib as L
+        assert L.load().ru_unet_workspace_bytes(eng.h, 1, 64, 64, 64, 0) > 0
+        net([x])
+        ms2, n2 = eng.probe_read()
+        assert n2 == 4 and ms2 > 0.0
         eng.probe(False)
         net([x])
         assert eng.probe_read() == (0.0, 0)
