@@ -51,14 +51,15 @@ struct Arena {
         off += bytes;
         if (off > peak) peak = off;
         if (dry) return nullptr;
-        if (off + keep > cap) { failed = true; return nullptr; }
+        if (off + keep > (cap & ~(size_t)255)) { failed = true; return nullptr; }
         return reinterpret_cast<float*>(base + o);
     }
     float* alloc_keep(size_t nfloats) {
         keep += align_up(nfloats * sizeof(float), 256);
         if (dry) return nullptr;
-        if (off + keep > cap) { failed = true; return nullptr; }
-        return reinterpret_cast<float*>(base + cap - keep);
+        const size_t top = cap & ~(size_t)255;           // (a caller may pass any size: the top region stays 256-byte aligned)
+        if (off + keep > top) { failed = true; return nullptr; }
+        return reinterpret_cast<float*>(base + top - keep);
     }
     void rewind(size_t mark) { off = mark; }
     size_t need() const { return peak + keep; }

@@ -180,6 +180,9 @@ int ru_unet_param_dim(ru_unet_t h, int i, int d);
 size_t ru_unet_param_offset(ru_unet_t h, int i);             /* in floats, into the flat buffer */
 size_t ru_unet_param_total(ru_unet_t h);                     /* floats */
 int ru_unet_param_is_dead(ru_unet_t h, int i);
+/* Bytes of device workspace `ws` a forward (training == 0: inference, block temporaries are recycled) or a forward + backward pair
+ * (training != 0: every activation is kept) needs at this shape; 0 for extents the network cannot take.  `ws` must be 256-byte aligned
+ * (any hipMalloc pointer is) and may be larger than asked for. */
 size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int W, int training);
 /* UNet.forward (model.py:407-433): x [N,4,D,H,W] -> probs [N,n_out,D,H,W] (sigmoid).  D,H,W divisible by
  * 2^(depth-1).  training != 0 keeps activations in `ws` for ru_unet_backward; `x` and `probs` are then read again by
