@@ -16,6 +16,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  committed under profiles/,
                  `whole_step_frac` = the per-layer roofline of the whole step (sum over the convolutions of max(executed FLOPs / MFMA
                  peak, fp32 in+out bytes / HBM peak)) divided by the measured step time,
+  power        : socket power / clock from rocm-smi while the step loops (`roofline.hot_loop_power`: while the dominant kernel loops) next to the
+                 package limit -- the 3x3x3 kernels run AT the limit, which is what bounds them,
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
   train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
   fwd          : forward-only volumes/s at batch 1 in the precision of the run,
@@ -135,7 +137,7 @@ def roofline_insitu(backend, one_step, steps=5):
     return (total_ms / n, n) if n else None
 
 
-def roofline_probe(batch, size, precision, launches=20, insitu=None):
+def roofline_probe(batch, size, precision, launches=20, insitu=None, power_index=None):
     """Dominant kernel: 3x3x3 conv 16->16 at size^3 (4 forward + 4 data-gradient launches of it per L0 block pair per step).
     `insitu` = (ms, launches) from roofline_insitu: the line is priced on it; a loop of `launches` back-to-back launches of the same
     kernel through the op-level entry point is timed beside it (HIP events on torch's current stream = the launch stream) and reported
@@ -166,6 +168,7 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None):
     e1.record()
     torch.cuda.synchronize()
     hot_ms = e0.elapsed_time(e1) / launches      # includes the ~2 us weight-pack kernel that precedes each conv launch
+    hot_power = power_probe(launch, 1.5, power_index) if power_index is not None else None
     ms = insitu[0] if insitu else hot_ms
     how = ("HIP event pairs around the %d forward launches of this kernel inside %d training steps run after the timed region (ru_unet_probe)"
            % (insitu[1], insitu[1] // 4)) if insitu else "%d back-to-back launches through ru_conv3d_fwd_l, HIP events" % launches
@@ -190,6 +193,7 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None):
         return {"bound": "hbm", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
                 "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "measured": how, "hot_loop_ms": round(hot_ms, 4),
+                "hot_loop_power": hot_power,
                 "algorithmic_bytes_per_launch": int(abytes),
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_algorithmic_tflops": round(achieved, 2),
                 "mfma_algorithmic_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
@@ -199,6 +203,50 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None):
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "measured": how, "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
             "algorithmic_bytes_per_launch": int(abytes), "hbm_algorithmic_gbps": round(gbps, 1)}
+
+
+def power_probe(fn, seconds=1.2, device_index=0):
+    """Socket power and clock while `fn` loops for `seconds`: rocm-smi sampled from a side thread (a subprocess every ~0.1 s; host-side only),
+    the first third of the samples dropped.  -> {"median_w", "median_sclk_mhz", "limit_w", "samples"} or None when rocm-smi is not usable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    rows, limit, stop = [], [None], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                d = json.loads(subprocess.run([smi, "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower", "--json"],
+                                              capture_output=True, text=True, timeout=5).stdout)
+                c = d[sorted(d.keys())[0]]
+                w = [float(v) for k, v in c.items() if "Current Socket" in k or "Average Graphics Package Power" in k]
+                clk = [int(re.sub(r"[^0-9]", "", v)) for k, v in c.items() if k.startswith("sclk clock speed")]
+                mx = [float(v) for k, v in c.items() if k.startswith("Max Graphics Package Power")]
+                if mx:
+                    limit[0] = mx[0]
+                if w and clk:
+                    rows.append((w[0], clk[0]))
+            except Exception:
+                return
+            stop.wait(0.05)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=6)
+    rows = rows[len(rows) // 3:]                     # the reading is a moving average: the first third still carries the previous leg
+    if not rows:
+        return None
+    return {"median_w": float(np.median([r[0] for r in rows])), "median_sclk_mhz": float(np.median([r[1] for r in rows])), "limit_w": limit[0], "samples": len(rows)}
 
 
 def sliding_window_probe(backend, flat, precision, batch_tiles=8):
@@ -273,6 +321,7 @@ def main():
     ap.add_argument("--grad-precision", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="3x3x3 data / weight gradients under the bf16x3 forward: three split-bf16 products (default) or bf16-rounded operands, one product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power sampling leg")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads for the cpu_baseline leg (0 = min(cores, %d))" % CPU_BASELINE_THREADS)
     ap.add_argument("--no-extras", action="store_true", help="skip fwd-only / roofline / cpu legs")
     ap.add_argument("--probe-steps", type=int, default=5, help="steps after the timed region in which the dominant kernel is timed in place (0 = off)")
@@ -381,8 +430,15 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if rank == 0 and not args.no_extras:               # at every N: the dominant kernel as timed inside rank 0's steps
-        out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu)
+        out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu,
+                                         power_index=local if (world == 1 and not args.no_power) else None)
         out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_power:
+        # socket power under the workload (rocm-smi): the 3x3x3 kernels run at the package limit, which is what bounds them
+        backend.engine.freeze_params(False)
+        pw = power_probe(one_step, seconds=3.0, device_index=local)
+        if pw is not None:
+            out["power"] = {"training_step": pw, "source": "rocm-smi sampled while the step loops for ~3 s after the timed region"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
