@@ -91,17 +91,20 @@ struct WTZ {
 // read once per half that is 0.94 transposed reads per MFMA instead of 1.5, and no wave re-reads another wave's dy fragments.
 // The reads of the next (dz, dx) group are issued between the MFMAs of the current one.
 // NP = 1: plain bf16 operands (hi*hi only; gradient precision RU_PREC_BF16) -- the lo operands are neither read nor multiplied.
-template <int OT, int NP>
+// PACK (x is a 4-channel copy, XS == 2): the staged x packet of halo position p holds the 4 channels of positions p, p+1, p+2, p+3, so the
+// dx = 0 read of a unit delivers the operands of the taps dx = 0, 1, 2 at once in its 16 columns (j, c): 3 units (dz) per half and nine
+// accumulators (dz, dy) instead of 9 units and 27 -- a third of the matrix work for an operand that has 4 real channels of 16.
+template <int OT, int NP, bool PACK>
 __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const int (&pw)[3], const char* __restrict__ dl, f32x4 (&acc)[27]) {
     using P = WTZ<OT>;
-    constexpr int HX = P::HX, NHALF = OT, NU = NHALF * 9;       // units: (row half, (dz, dx))
+    constexpr int HX = P::HX, NHALF = OT, NG = PACK ? 3 : 9, NU = NHALF * NG;       // units: (row half, (dz, dx))
     bf16x8 bh[2][4], bl[2][4];                                  // x operands of a unit: row pairs p = 0..3, double buffered
     bf16x8 ah[2][2], al[2][2];                                  // dy operands of a half: K-blocks (0,2), (1,3), double buffered by half
     // read r of unit u: r < 8 -> x operand (pair r>>1, hi/lo r&1); then, for the first unit of a half, the 4 dy operands
     // (one product: the odd reads -- the lo operands -- do not exist, read index rr counts the hi reads only)
     auto read_one = [&](auto U, auto R) {
         constexpr int u = decltype(U)::value, r = NP == 3 ? decltype(R)::value : 2 * decltype(R)::value;
-        constexpr int h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
+        constexpr int h = u / NG, g = u % NG, dz = PACK ? g : g / 3, dx = PACK ? 0 : g % 3, set = u & 1;
         if constexpr (r < 8) {
             constexpr int pr = r >> 1;
             constexpr int off0 = ((4 * h + pr) * HX + dx) * 32, off1 = off0 + 2 * HX * 32;
@@ -115,15 +118,15 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
             else al[h & 1][kbi] = wt_read_tr(dl + P::DPLANE + off0, dl + P::DPLANE + off1);
         }
     };
-    auto nreads = [](int u) constexpr { return ((u % 9 == 0) ? 12 : 8) / (NP == 3 ? 1 : 2); };
+    auto nreads = [](int u) constexpr { return ((u % NG == 0) ? 12 : 8) / (NP == 3 ? 1 : 2); };
     wt_static_for<nreads(0)>([&](auto R) { read_one(std::integral_constant<int, 0>{}, R); });
     wt_static_for<NU>([&](auto U) {
-        constexpr int u = decltype(U)::value, h = u / 9, g = u % 9, dz = g / 3, dx = g % 3, set = u & 1;
+        constexpr int u = decltype(U)::value, h = u / NG, g = u % NG, dz = PACK ? g : g / 3, dx = PACK ? 0 : g % 3, set = u & 1;
         constexpr int nr = u + 1 < NU ? nreads(u + 1) : 0;
         constexpr int NM = 6 * NP;
         wt_static_for<NM>([&](auto M) {
             constexpr int m = decltype(M)::value, prod = NP == 3 ? m / 6 : 2, kbi = (m / 3) % 2, dy = m % 3;
-            constexpr int tap = dz * 9 + dy * 3 + dx, pr = kbi + dy;
+            constexpr int tap = PACK ? dz * 3 + dy : dz * 9 + dy * 3 + dx, pr = kbi + dy;    // PACK: accumulator (dz, dy), columns (dx, c)
             if constexpr (prod == 0) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
             if constexpr (prod == 1) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bl[set][pr], acc[tap], 0, 0, 0);
             if constexpr (prod == 2) acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[h & 1][kbi], bh[set][pr], acc[tap], 0, 0, 0);
@@ -137,7 +140,8 @@ __device__ __forceinline__ void wtz_consume(const char* __restrict__ xl, const i
     });
 }
 
-// XS: source of x -- 0 C16, 1 C4 copy (a 16-channel block that is zero beyond channel 3).  DS: source of dy -- 0 C16, 1 split C16 (hi/lo
+// XS: source of x -- 0 C16, 1 C4 copy (a 16-channel block that is zero beyond channel 3; kept for reference, not instantiated), 2 C4 copy
+// with the three dx taps packed into the block's 16 columns (wtz_consume PACK; what the launcher uses for a 4-channel x).  DS: source of dy -- 0 C16, 1 split C16 (hi/lo
 // packets in HBM, copied), 2 C4 copy.  Compile-time: a runtime branch inside the unrolled load loops breaks the load batches apart
 // (it cost ~100 us per launch when these were kernel arguments).
 template <int OT, int XS, int DS, int NP = 3>
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         float4 vg[DS == 3 ? NRD : 1][2], gc4[DS == 3 ? 10 : 1];       // DS == 3: the gradient stream and (scale, shift, coefficients) of this thread's 8 channels
         int st_n = 0, st_y0 = 0, st_x0 = 0;
         float4 sc4[2], sh4[2];
-        unsigned mx = 0, md = 0;
+        unsigned mx = 0, md = 0, mx2 = 0;                // (mx2: XS == 2, validity of the second 4-channel group of this half)
         int st_ring0 = 0, st_k = 0;                      // of the item whose loads are in the registers
         // issue() is called for items 0, 1, 2, ... in order: (column, step) advance as counters and the column origin is recomputed
         // once per column, not with four integer divisions per item in this wave's VALU stream
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             st_ring0 = ring0; st_k = k;
             const int hp0 = k == 0 ? 0 : 2 * k + 2, npl = k == 0 ? 4 : 2;       // new halo planes hp0 .. hp0 + npl - 1 (halo plane hp <-> z = hp - 1)
             const float* xb = a.x + ((size_t)(n * CBi + cgp) * DHW) * 16 + hsel * 8;
-            mx = 0; md = 0;
+            mx = 0; md = 0; mx2 = 0;
             // rounds 0 .. NR2-1 cover the two planes every step loads; rounds NR2 .. NRX-1 only exist at the start of a column (four
             // planes): ONE wave-uniform branch around them, none inside the unrolled loops (a branch per round splits the load batch)
             auto xround = [&](auto R) {
@@ -219,6 +223,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     mx |= (ok && hsel == 0) ? (1u << r) : 0u;
                     vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
                     vx[r][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if constexpr (XS == 2) {          // 4-channel copy, taps packed: channels (j, c) = x4[gx + j][c]; this half holds j = 2*hsel, 2*hsel + 1
+                    const bool rowok = live && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H;
+                    const int g0 = gx + 2 * hsel, g1 = g0 + 1;
+                    const bool ok0 = rowok && (unsigned)g0 < (unsigned)W, ok1 = rowok && (unsigned)g1 < (unsigned)W;
+                    mx |= ok0 ? (1u << r) : 0u;
+                    mx2 |= ok1 ? (1u << r) : 0u;
+                    const float* x4 = a.x + (size_t)n * DHW * 4;
+                    const size_t row = rowok ? (size_t)(gz * H + gy) * W : 0;
+                    vx[r][0] = *reinterpret_cast<const float4*>(x4 + (row + (ok0 ? g0 : 0)) * 4);      // unconditional, clamped
+                    vx[r][1] = *reinterpret_cast<const float4*>(x4 + (row + (ok1 ? g1 : 0)) * 4);
                 } else {
                     mx |= ok ? (1u << r) : 0u;
                     vx[r][0] = *reinterpret_cast<const float4*>(xb + ofs);          // unconditional, clamped
@@ -284,15 +298,17 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const int pl = u / PPOS, p = u - pl * PPOS;
                 if (pl >= npl) return;
                 const bool ok = (mx >> r) & 1u;
+                const bool ok_hi = XS == 2 ? ((mx2 >> r) & 1u) != 0 : ok;          // packed taps: the second 4-channel group has its own x position
                 const float f[8] = {vx[r][0].x, vx[r][0].y, vx[r][0].z, vx[r][0].w, vx[r][1].x, vx[r][1].y, vx[r][1].z, vx[r][1].w};
                 float t[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
+                    const bool okc = c < 4 ? ok : ok_hi;
                     if constexpr (XF) {
                         const float u2 = fmaf(f[c], sc[c], sh[c]);
-                        t[c] = ok ? fmaxf(u2, u2 * slope) : 0.f;   // zero padding applies to the ACTIVATED tensor
+                        t[c] = okc ? fmaxf(u2, u2 * slope) : 0.f;   // zero padding applies to the ACTIVATED tensor
                     } else {
-                        t[c] = ok ? f[c] : 0.f;
+                        t[c] = okc ? f[c] : 0.f;
                     }
                 }
                 u32x4 hi, lo;
@@ -391,30 +407,39 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #pragma unroll
             for (int p = 0; p < 3; ++p) pw[p] = ((s0 + p) & (P::NSLOT - 1)) * P::PLANE + xrow_off;
             const char* dl = lds + P::D_OFF + (w & 1) * P::DBUF + drow_off;
-            wtz_consume<OT, NP>(lds, pw, dl, acc);
+            wtz_consume<OT, NP, XS == 2>(lds, pw, dl, acc);
             __syncthreads();
         }
         // ---- the waves that worked on the same output tile are summed through LDS (the staging memory is free now): ONE partial per
         // workgroup instead of four / two -- a quarter / half of the partial traffic here and in the reduce kernel
         f32x4* red = reinterpret_cast<f32x4*>(lds);      // [wave][tap][lane]
+        constexpr int NT = XS == 2 ? 9 : 27;             // live accumulators (packed taps: (dz, dy))
 #pragma unroll
-        for (int t = 0; t < 27; ++t) red[(rw * 27 + t) * 64 + lane] = acc[t];
+        for (int t = 0; t < NT; ++t) red[(rw * 27 + t) * 64 + lane] = acc[t];
         __syncthreads();
     }
     // partials[workgroup][tap][o][c]; D lane = (rows o = 4*(l>>4) + r, column c = l&15); fixed summation order
     {
         const f32x4* red = reinterpret_cast<const f32x4*>(lds);
         const int c0 = cgp * 16;
-        for (int e = tid; e < OT * 27 * 64; e += 512) {
-            const int q = e & 63, t = (e >> 6) % 27, ot = (e >> 6) / 27;
+        constexpr int NT = XS == 2 ? 9 : 27;
+        for (int e = tid; e < OT * NT * 64; e += 512) {
+            const int q = e & 63, t = (e >> 6) % NT, ot = (e >> 6) / NT;
             f32x4 v;
             if constexpr (OT == 1) v = (red[(0 * 27 + t) * 64 + q] + red[(1 * 27 + t) * 64 + q]) + (red[(2 * 27 + t) * 64 + q] + red[(3 * 27 + t) * 64 + q]);
             else v = red[(ot * 27 + t) * 64 + q] + red[((ot + 2) * 27 + t) * 64 + q];
-            const int c = c0 + (q & 15);
+            int c = c0 + (q & 15), tap = t;
+            bool live = true;
+            if constexpr (XS == 2) {                     // column (j, c) of accumulator (dz, dy) is tap (dz, dy, dx = j), input channel c
+                const int j = (q & 15) >> 2;
+                c = q & 3;
+                tap = (t / 3) * 9 + (t % 3) * 3 + j;
+                live = j < 3;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = og * OT * 16 + ot * 16 + (q >> 4) * 4 + r;
-                if (o < CoP && c < CiP) partials[(((size_t)blockIdx.x * 27 + t) * CoP + o) * CiP + c] = v[r];
+                if (live && o < CoP && c < CiP) partials[(((size_t)blockIdx.x * 27 + tap) * CoP + o) * CiP + c] = v[r];
             }
         }
     }
@@ -472,7 +497,7 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
                    "wgrad3_tr: the fused GroupNorm-backward apply needs all of its operands");
         if (a.x_c4) {                                    // stem: x = network input
             RU_REQUIRE(c.ot == 1, "wgrad3_tr: a 4-channel copy stands for ONE 16-channel block");
-            return p1 ? wtz_cfg<1, 1, 3, 1>(a, c, s) : wtz_cfg<1, 1, 3>(a, c, s);
+            return p1 ? wtz_cfg<1, 2, 3, 1>(a, c, s) : wtz_cfg<1, 2, 3>(a, c, s);      // (taps packed into the 16 columns: XS == 2)
         }
         if (p1 && c.ot == 1) return wtz_cfg<1, 0, 3, 1>(a, c, s);
         if (c.ot == 2) return wtz_cfg<2, 0, 3>(a, c, s);   // two output blocks per workgroup: the constants of a block are fetched when it is converted
@@ -484,7 +509,7 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         if (p1 && ds == 1) return wtz_cfg<2, 0, 1, 1>(a, c, s);
         return ds == 1 ? wtz_cfg<2, 0, 1>(a, c, s) : wtz_cfg<2, 0, 0>(a, c, s);
     }
-    if (xs == 1) { RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy"); return ds == 1 ? wtz_cfg<1, 1, 1>(a, c, s) : wtz_cfg<1, 1, 0>(a, c, s); }
+    if (xs == 1) { RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy"); return ds == 1 ? wtz_cfg<1, 2, 1>(a, c, s) : wtz_cfg<1, 2, 0>(a, c, s); }
     if (ds == 2) return p1 ? wtz_cfg<1, 0, 2, 1>(a, c, s) : wtz_cfg<1, 0, 2>(a, c, s);
     return ds == 1 ? wtz_cfg<1, 0, 1>(a, c, s) : wtz_cfg<1, 0, 0>(a, c, s);
 }
