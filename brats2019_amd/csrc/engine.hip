@@ -657,6 +657,10 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
         w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
         w.products = products;
+        // head (dy has 3 real channels, no fused transform on x): exchange the operands, so that the few-channel tensor is the 4-channel
+        // x operand whose packet carries the three dx taps (a third of the matrix work); the result comes out transposed with mirrored taps
+        const bool swap = x_c16 && use4 && !xg && !gb;
+        if (swap) { w.x = fewp; w.dy = x; w.x_c4 = 1; w.dy_c4 = 0; w.dy_s16 = 0; w.swapped = 1; }
         if (gb && !x_c16 && use4) {                              // stem: dy is the GroupNorm-backward apply of norm_input, computed while staging; nobody else reads it
             w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = gb->g->act_slope;
             w.gb_out = nullptr; w.dy = gb->y; w.dy_s16 = 0;      // (dy unused in this mode; any valid pointer)
@@ -664,6 +668,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
         w.dw_cin = Cin; w.dw_cout = Cout;
         w.N = N; w.Cin = x_c16 ? Cin : 16; w.Cout = x_c16 ? 16 : Cout; w.D = D; w.H = H; w.W = W;
+        if (swap) { w.dw_cin = Cout; w.dw_cout = Cin; w.Cin = 16; w.Cout = Cin; }      // kernel view: x' = d (few channels), dy' = x
         w.ws_bytes = wgrad3_workspace_bytes(N, w.Cin, w.Cout, D, H, W);
         w.ws = A.alloc(w.ws_bytes / sizeof(float));
         RU_RUN(wgrad3_launch(w, s));

@@ -162,11 +162,17 @@ struct Wgrad3Args {
     float gb_slope;
     float* gb_out;
     int products;            // wgrad_tr only: 0 / 3 = three split-bf16 products, 1 = hi*hi only (gradient precision RU_PREC_BF16), where such a variant exists
+    // wgrad_tr only: the operands are EXCHANGED -- `x` (with its halo) is the convolution's OUTPUT gradient, `dy` (tile centres) its input:
+    //     T[t][o'][c'] = sum_v dy[v][o'] * x[v + t][c'] = dW[26 - t][cout = c'][cin = o']
+    // so the result is stored transposed with the taps mirrored (dw_cout / dw_cin then name the real channel counts of dy / x).  Used
+    // for the head, whose output gradient has 3 channels: as the 4-channel x operand it takes the packed-tap form (wgrad3_tz XS == 2).
+    int swapped;
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
 // sum of `nparts` partial gradients [nparts][taps][CoP][CiP] into dw (fixed order; wgrad_f32.hip)
-int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s);
+int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s,
+                        int flip_taps = 0);
 size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s);
 // both tensors voxel-major: transpose-read kernel (wgrad_tr.hip); workspace 0 if the channel counts do not fit

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 4) void wgrad3_f32_kernel(const Wgrad3Args a, 
 // gradient has 1024) want narrow blocks -- 64-wide blocks left a 256-load dependent chain per thread on 4 workgroups.
 template <int LO>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
-                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc, int split) {
+                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc, int split, int flip_taps) {
     constexpr int NS = 256 / LO;
     __shared__ float red[NS][LO];
     const int lane_o = threadIdx.x % LO, slice = threadIdx.x / LO;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     red[slice][lane_o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     // split > 0: c = t*split + ci enumerates (tap t, channel ci) of a 2x2x2 conv whose gradient layout is [o][ci][8]
-    const size_t dst = split > 0 ? (size_t)o * so + (size_t)(c % split) * 8 + c / split : (size_t)o * so + (size_t)c * sc + tap;
+    // flip_taps: the partials were computed with the operands exchanged (tap t there is tap taps-1-t of the convolution)
+    const size_t dst = split > 0 ? (size_t)o * so + (size_t)(c % split) * 8 + c / split : (size_t)o * so + (size_t)c * sc + (flip_taps ? taps - 1 - tap : tap);
     if (slice == 0 && ok) {
         float t = 0.f;
 #pragma unroll
@@ -320,10 +321,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 // fixed summation order for a given (nparts, shape): deterministic
-int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s) {
+int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s, int flip_taps) {
     const int total = taps * Cout * Cin;
-    if (nparts >= 128) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split);
+    if (nparts >= 128) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split, flip_taps);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split, flip_taps);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
     return RU_OK;
 }

@@ -481,6 +481,7 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS, NP>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
+    if (a.swapped) return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, 27, co * 27, 0, s, 1);   // dw[cout = c'][cin = o'][26 - t]
     return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
 }
 
@@ -509,7 +510,11 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         if (p1 && ds == 1) return wtz_cfg<2, 0, 1, 1>(a, c, s);
         return ds == 1 ? wtz_cfg<2, 0, 1>(a, c, s) : wtz_cfg<2, 0, 0>(a, c, s);
     }
-    if (xs == 1) { RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy"); return ds == 1 ? wtz_cfg<1, 2, 1>(a, c, s) : wtz_cfg<1, 2, 0>(a, c, s); }
+    if (xs == 1) {
+        RU_REQUIRE(ds != 2, "wgrad3_tr: only one operand can be a 4-channel copy");
+        if (ds == 1) return wtz_cfg<1, 2, 1>(a, c, s);
+        return p1 ? wtz_cfg<1, 2, 0, 1>(a, c, s) : wtz_cfg<1, 2, 0>(a, c, s);
+    }
     if (ds == 2) return p1 ? wtz_cfg<1, 0, 2, 1>(a, c, s) : wtz_cfg<1, 0, 2>(a, c, s);
     return ds == 1 ? wtz_cfg<1, 0, 1>(a, c, s) : wtz_cfg<1, 0, 0>(a, c, s);
 }
