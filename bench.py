@@ -205,6 +205,18 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None, power_index
             "algorithmic_bytes_per_launch": int(abytes), "hbm_algorithmic_gbps": round(gbps, 1)}
 
 
+def smi_index(local):
+    """rocm-smi card index of the process's device `local`: the visible-devices variables renumber the devices the process sees."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                return int(v.split(",")[local])
+            except (ValueError, IndexError):
+                break
+    return local
+
+
 def power_probe(fn, seconds=1.2, device_index=0):
     """Socket power and clock while `fn` loops for `seconds`: rocm-smi sampled from a side thread (a subprocess every ~0.1 s; host-side only),
     the first third of the samples dropped.  -> {"median_w", "median_sclk_mhz", "limit_w", "samples"} or None when rocm-smi is not usable."""
@@ -431,12 +443,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if rank == 0 and not args.no_extras:               # at every N: the dominant kernel as timed inside rank 0's steps
         out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu,
-                                         power_index=local if (world == 1 and not args.no_power) else None)
+                                         power_index=smi_index(local) if (world == 1 and not args.no_power) else None)
         out["roofline"]["whole_step_frac"] = out["whole_step_frac"]
     if rank == 0 and world == 1 and not args.no_extras and not args.no_power:
         # socket power under the workload (rocm-smi): the 3x3x3 kernels run at the package limit, which is what bounds them
         backend.engine.freeze_params(False)
-        pw = power_probe(one_step, seconds=3.0, device_index=local)
+        pw = power_probe(one_step, seconds=3.0, device_index=smi_index(local))
         if pw is not None:
             out["power"] = {"training_step": pw, "source": "rocm-smi sampled while the step loops for ~3 s after the timed region"}
     if rank == 0:
