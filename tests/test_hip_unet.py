@@ -525,3 +525,33 @@ def test_bf16_gradient_precision_at_ragged_shapes(shape):
         assert rel < (1e-2 if g3.dim() == 5 else 3e-2), (k, rel)
     assert worst[0] > 0
     print("bf16 gradient precision at %s: worst relative L2 error %.2e (%s)" % ((shape,) + worst))
+
+
+@pytest.mark.gpu
+def test_bf16_gradient_precision_training_trajectory():
+    """Six optimizer steps with the reference's hyper-parameters (Adam amsgrad lr 2e-5, wd 1e-6, StepLR(16000, 0.5): main.py:133-142) on batch
+    2 x 128^3 with the two gradient precisions from the same start: the loss trajectories stay together to 1e-5 (measured 3e-6) and the weights to 5e-5
+    relative L2, and both runs reduce the loss.  (Adam's first steps are sign-like, m / sqrt(v) ~ sign(g): elements whose gradient is
+    below its bf16 rounding noise move in either direction in either arithmetic, so the runs differ by a few per cent OF THE UPDATE.)"""
+    import bench
+    from brats2019_amd import parallel as P
+    dev = torch.device("cuda")
+    x, g = bench.synth(2, 128, 4321, dev)
+    runs = {}
+    for gp in ("bf16x3", "bf16"):
+        be = P.HipBackend(device=dev, precision="bf16x3", grad_precision=gp)
+        flat = bench.init_params(be)
+        w0 = flat.clone()
+        st = P.DataParallelStep(be, flat)
+        losses = [float(st.step(x, g)[0]) for _ in range(6)]
+        runs[gp] = (losses, flat.clone(), w0)
+    la, lb = runs["bf16x3"][0], runs["bf16"][0]
+    assert la[0] == lb[0]                                    # same forward before any update
+    assert all(abs(a - b) < 1e-5 for a, b in zip(la, lb)), (la, lb)
+    assert la[-1] < la[0] and lb[-1] < lb[0]                 # (both runs train)
+    wa, wb, w0 = runs["bf16x3"][1].double(), runs["bf16"][1].double(), runs["bf16x3"][2].double()
+    rel = float(torch.linalg.vector_norm(wa - wb) / torch.linalg.vector_norm(wa))
+    upd = float(torch.linalg.vector_norm(wa - w0) / torch.linalg.vector_norm(wa))
+    print("bf16 vs three-product gradients after 6 steps: losses %s / %s; weights differ by %.2e relative L2, the update itself is %.2e" %
+          (["%.6f" % v for v in la], ["%.6f" % v for v in lb], rel, upd))
+    assert 0 < rel < 5e-5 and rel < 0.2 * upd
