@@ -2,7 +2,8 @@
 """Headline benchmark of the ResUNet hot path (BASELINE.json: 128^3 x 4ch volumes/sec fwd+bwd at 1/2/4/8 MI355X).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...;
+     started bare with --gpus N > 1 the script launches exactly that command itself, as fresh child processes, before any GPU call)
 
 A "step" is one data-parallel training step on synthetic 128^3 4-modality crops, per-GPU batch 4 (BASELINE
 configs[2]/[3]; weak scaling): UNet forward + Dice/BCE criterion + backward + RCCL all-reduce of the criterion
@@ -20,7 +21,7 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  package limit -- the 3x3x3 kernels run AT the limit, which is what bounds them,
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
   train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
-  fwd          : forward-only volumes/s at batch 1 in the precision of the run,
+  fwd          : forward-only volumes/s at batch 1 in the precision of the run (at every N: N independent replicas),
   fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1).
 """
 import argparse
@@ -321,6 +322,26 @@ def cpu_baseline(size, threads=0):
             "fwd_only_value": round(1.0 / dtf, 4), "step_s": [round(v, 3) for v in dts]}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks as fresh child processes -- the very
+    command the contract names (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same arguments>`) -- and hand back its exit code.  Rank 0's single JSON line reaches stdout through the inherited
+    descriptor.  This process has made no HIP / torch.cuda call (argument parsing only), and it is not replaced (no exec): it waits."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (parallel.init_process_group_from_env)
+    env.setdefault("OMP_NUM_THREADS", "8")                # torch.distributed.run would set 1: the cpu_baseline leg is off at N > 1 anyway
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +363,9 @@ def main():
                     help="collectives of the step: torch.distributed (nccl == RCCL; default) or the library's own ru_allreduce on the kernels' stream")
     ap.add_argument("--shared-gpu", action="store_true", help="plumbing test: let every rank use cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        raise SystemExit(self_launch(args.gpus))     # started bare: become the launcher (no GPU call has happened in this process)
 
     from brats2019_amd import parallel as P
     if args.shared_gpu:
@@ -399,18 +423,22 @@ def main():
         else:
             for _ in range(args.probe_steps):
                 one_step()
-    if rank == 0 and world == 1 and not args.no_extras:
-        # forward-only, batch 1, in the precision of the run
+    if not args.no_extras:
+        # forward-only, batch 1, in the precision of the run -- at every N (BASELINE metric: forward volumes/s at 1/2/4/8 GPUs): inference
+        # does not shard a volume, so the ranks are independent replicas; `value` = N volumes per max-over-ranks time
         x1 = x[:1].contiguous()
         backend.engine.freeze_params(True)       # inference legs: the weights no longer change, their packed copies are built once (as test.py would run)
         fwd = lambda: backend.forward(flat, x1, training=False)
         for _ in range(2):
             fwd()
         it = max(5, args.steps)
-        dtf = time_region(fwd, it, False)
-        out["fwd"] = {"value": round(it / dtf, 3), "unit": "volumes/s", "batch": 1, "ms": round(1e3 * dtf / it, 3), "precision": args.precision,
-                      "algorithmic_tflops": round(it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
+        dtf = time_region(fwd, it, distributed)
+        backend.engine.freeze_params(False)
+        out["fwd"] = {"value": round(world * it / dtf, 3), "unit": "volumes/s", "batch": 1, "replicas": world, "ms": round(1e3 * dtf / it, 3), "precision": args.precision,
+                      "algorithmic_tflops": round(world * it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
                       "roofline_frac": round(step_roofline_ms(1, args.size, args.precision, forward_only=True) / (1e3 * dtf / it), 4)}
+    if rank == 0 and world == 1 and not args.no_extras:
+        backend.engine.freeze_params(True)
         if args.precision != "f32":
             # BASELINE configs[1]: fp32 forward, batch 1 -- exact-f32 MFMA arithmetic, its own engine and workspace
             be32 = P.HipBackend(device=dev, precision="f32")

@@ -73,6 +73,8 @@ SIGNATURES = {
     "ru_comm_rank": (_i, [_vp]),
     "ru_comm_world": (_i, [_vp]),
     "ru_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ru_comm_group_begin": (_i, []),
+    "ru_comm_group_end": (_i, []),
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),

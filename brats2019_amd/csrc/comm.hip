@@ -20,6 +20,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     bool ok = false;
 };
 
@@ -37,7 +39,9 @@ static RcclApi& rccl() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
-        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString;
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.lib, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GetErrorString && api.GroupStart && api.GroupEnd;
     });
     return api;
 }
@@ -96,4 +100,17 @@ extern "C" int ru_allreduce(ru_comm_t c, void* buf, size_t count, int dtype, ru_
     if (count == 0) return RU_OK;
     const ncclResult_t r = rccl().AllReduce(buf, buf, count, dtype == RU_DT_F32 ? ncclFloat32 : ncclFloat64, ncclSum, c->comm, (hipStream_t)stream);
     return r == ncclSuccess ? RU_OK : rccl_fail(r, "ncclAllReduce");
+}
+
+// ncclGroupStart / ncclGroupEnd around several ru_allreduce calls: RCCL fuses them into ONE launch (the gradient runs of a step travel
+// together instead of as back-to-back collectives, each with its own launch and ring set-up)
+extern "C" int ru_comm_group_begin(void) {
+    if (!rccl().ok) { set_error("ru_comm_group_begin: librccl could not be loaded"); return RU_EHIP; }
+    const ncclResult_t r = rccl().GroupStart();
+    return r == ncclSuccess ? RU_OK : rccl_fail(r, "ncclGroupStart");
+}
+extern "C" int ru_comm_group_end(void) {
+    if (!rccl().ok) { set_error("ru_comm_group_end: librccl could not be loaded"); return RU_EHIP; }
+    const ncclResult_t r = rccl().GroupEnd();
+    return r == ncclSuccess ? RU_OK : rccl_fail(r, "ncclGroupEnd");
 }

@@ -942,7 +942,9 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
     // voxel-major engine, no d/d(input) wanted: the gradient w.r.t. the stem conv's output is consumed by the stem's weight gradient alone, so
     // the GroupNorm-backward apply of norm_input is computed in that kernel's staging (wgrad3_tz<1,1,3>) and never written
-    const bool fuse0 = c16 && h->precision == RU_PREC_BF16X3 && (h->fusion & RU_FUSE_GN_BWD_APPLY) && !dx_in && h->x_in4_planned;
+    // (only the Cin <= 16 && Cout <= 16 branch of wgrad3_run computes the apply while staging: a wider stem takes the generic
+    // weight-gradient kernel, which reads a WRITTEN dy0)
+    const bool fuse0 = c16 && h->precision == RU_PREC_BF16X3 && (h->fusion & RU_FUSE_GN_BWD_APPLY) && !dx_in && h->x_in4_planned && C0 <= 16 && kInCh <= 4;
     float* coef0 = nullptr;
     rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst,
                 fuse0 ? &coef0 : nullptr);

@@ -49,6 +49,8 @@ class HipBackend:
             else:
                 self.live_segments.append([off, off + n])
 
+        self.reduce_runs = merge_runs(self.live_segments)
+
     def new_flat(self, fill=0.0):
         return torch.full((self.total,), float(fill), dtype=torch.float32, device=self.device)
 
@@ -76,6 +78,20 @@ class HipBackend:
         from . import ops
         for a, b in self.live_segments:
             ops.adam_amsgrad_step(flat[a:b], grads[a:b], m[a:b], v[a:b], vmax[a:b], step, lr, betas, eps, weight_decay)
+
+
+def merge_runs(runs, max_gap=1 << 16):
+    """Runs of the flat gradient bucket that travel in the all-reduce: the live runs, joined across dead gaps of at most `max_gap`
+    floats (decoder_convs1x1.{depth-1}, 32 768 zeros, is cheaper to send than a third collective); the large dead block
+    (decoder_convs.{depth-1}, 0.9 M floats) still splits the bucket.  Dead gradients are zero on every rank, so their sum stays zero and
+    the optimizer never reads them (HipBackend.adam walks live_segments)."""
+    out = []
+    for a, e in runs:
+        if out and a - out[-1][1] <= max_gap:
+            out[-1][1] = e
+        else:
+            out.append([a, e])
+    return out
 
 
 class RcclComm:
@@ -112,6 +128,21 @@ class RcclComm:
             raise TypeError("RcclComm.all_reduce: float32 or float64, got %s" % t.dtype)
         L.check(L.load().ru_allreduce(self.h, L.ptr(t), t.numel(), 0 if t.dtype == torch.float32 else 1, L.stream()), "ru_allreduce")
         return t
+
+    def all_reduce_many(self, tensors):
+        """the all-reduces of `tensors` as ONE RCCL launch (ncclGroupStart / ncclGroupEnd)"""
+        from . import _lib as L
+        if len(tensors) <= 1:
+            for t in tensors:
+                self.all_reduce(t)
+            return
+        lib = L.load()
+        L.check(lib.ru_comm_group_begin(), "ru_comm_group_begin")
+        try:
+            for t in tensors:
+                self.all_reduce(t)
+        finally:
+            L.check(lib.ru_comm_group_end(), "ru_comm_group_end")
 
     def close(self):
         from . import _lib as L
@@ -177,10 +208,10 @@ class DataParallelStep:
         if self.distributed:
             # only the live runs of the flat bucket travel: the never-executed deepest decoder stage (a third of the 21.7 MB) has zero
             # gradients on every rank.  SUM, not mean: the criterion already carries the global 1/count.
-            segs = getattr(b, "live_segments", None)
+            # The runs go out as ONE grouped collective (ncclGroupStart/End through either transport).
+            segs = getattr(b, "reduce_runs", None) or getattr(b, "live_segments", None)
             if segs and sum(e - a for a, e in segs) < 0.9 * self.grads.numel():
-                for a, e in segs:
-                    self._all_reduce(self.grads[a:e])
+                self._all_reduce_many([self.grads[a:e] for a, e in segs])
             else:
                 self._all_reduce(self.grads)
         self.last_probs = probs
@@ -191,6 +222,12 @@ class DataParallelStep:
             self.comm.all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_reduce_many(self, tensors):
+        if self.comm is not None:
+            self.comm.all_reduce_many(tensors)
+        else:
+            all_reduce_coalesced(tensors, self.group)
 
     def step(self, x_shard, target_shard):
         loss, dice, bce = self.loss_and_grads(x_shard, target_shard)
@@ -206,6 +243,17 @@ class DataParallelStep:
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.vmax.copy_(sd["vmax"])
         self.global_step = int(sd["global_step"])
+
+
+def all_reduce_coalesced(tensors, group=None):
+    """SUM all-reduce of several tensors as one coalesced collective (ProcessGroup.allreduce_coalesced: one ncclGroup'd launch on RCCL,
+    one flattened ring on gloo); every rank must pass the same number of tensors of the same sizes."""
+    if len(tensors) == 1:
+        dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group)
+        return
+    with dist._coalescing_manager(group=group):
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def world_info(group=None):
@@ -244,8 +292,8 @@ def all_reduce_gradients(model, group=None):
             else:
                 runs.append([a, a + g.numel()])
         if runs:
-            for a, e in runs:
-                dist.all_reduce(flat[a:e], op=dist.ReduceOp.SUM, group=group)
+            runs = merge_runs(runs)              # (the executor zero-fills the bucket: dead gaps are zeros on every rank)
+            all_reduce_coalesced([flat[a:e] for a, e in runs], group)
             return sum(e - a for a, e in runs)
     bucket = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
@@ -266,6 +314,10 @@ def init_process_group_from_env(backend=None):
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # The host driver of this pool (and of the GPU boxes) supports only dmabuf IPC: with the legacy mode RCCL's intra-node transport set-up
+    # and any cross-process device-memory sharing fail with `hipIpcGetMemHandle: invalid argument`.  The image exports the variable
+    # already; a launcher that scrubs the environment would lose it, so it is restored here -- before the first HIP call of the rank --
+    # and never overridden when the operator set it.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -216,6 +216,10 @@ int ru_comm_destroy(ru_comm_t c);
 int ru_comm_rank(ru_comm_t c);
 int ru_comm_world(ru_comm_t c);
 int ru_allreduce(ru_comm_t c, void* buf, size_t count, int dtype, ru_stream_t stream);
+/* ncclGroupStart / ncclGroupEnd: the ru_allreduce calls between them are issued as ONE RCCL launch (the runs of the gradient bucket of
+ * a step; replaces the per-parameter reduce_add loop inside nn.DataParallel's backward, main.py:61) */
+int ru_comm_group_begin(void);
+int ru_comm_group_end(void);
 
 /* ---------------------------------------------------------------- inference post-processing (test.py:115-159)
  * ru_tta_merge: `probs` holds K predictions [K][C][D][H][W] of flipped copies of one volume; bits 3k..3k+2 of `flips` say

@@ -415,6 +415,38 @@ def test_fused_and_unfused_backward_agree_tightly():
     assert worst_v[0] < 2e-3, worst_v
 
 
+WIDE = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[32, 64, 128], number_of_outputs=3)
+
+
+def test_wide_stem_voxel_major_training_fused_equals_unfused_and_oracle():
+    """A voxel-major (C16) configuration whose FIRST channel count is above 16 (number_of_channels=[32,64,128]; bf16x3 is its default):
+    the stem weight gradient then takes the generic kernel, which has no fused GroupNorm-backward apply -- the gradient w.r.t. the stem
+    output must be WRITTEN for it (round-2 advisor finding: with the apply fusion on it was not).  Fusions on and off must agree, and both
+    must agree with the CPU oracle elementwise (relative L2 of the difference)."""
+    from brats2019_amd import model as M
+    assert M.default_precision(WIDE["number_of_channels"]) == "bf16x3"
+    n, dhw, seed = 2, (32, 32, 32), 5
+    res = {}
+    for fusion in ((True, True), (False, False)):
+        net, probs, loss, vals = run_train_step(WIDE, n, dhw, seed, "bf16x3", fusion)
+        assert net._get_engine().precision == "bf16x3"
+        res[fusion] = (probs.clone(), float(loss), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
+    pa, la, ga = res[(True, True)]
+    pb, lb, gb = res[(False, False)]
+    assert torch.equal(pa, pb) and la == lb
+    params = O.make_params(seed, **WIDE)
+    ref_p, ref_loss, ref_grads = O.forward_backward(params, O.make_input(n, *dhw, seed=seed), O.make_target(n, *dhw, seed=seed), **WIDE)
+    assert np.abs(pa.cpu().numpy() - ref_p).max() <= 2e-4
+    assert abs(la - ref_loss) < 5e-5
+    for k in ga:
+        rel = float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-30))
+        assert rel < (5e-4 if ga[k].dim() == 5 else 5e-3), ("fused vs unfused", k, rel)
+        r = T(ref_grads[k]).double()
+        for tag, gg in (("fused", ga), ("unfused", gb)):
+            rel = float((gg[k].double().cpu() - r).norm() / (r.norm() + 1e-30))
+            assert rel < 1e-2, (tag, k, rel)
+
+
 def test_default_precision_is_bf16x3_for_the_shipped_configuration():
     from brats2019_amd import model as M
     assert M.UNet(**O.DEFAULT_CFG)._get_engine().precision == "bf16x3"          # what a drop-in Trainer user gets (main.py:56-59)

@@ -299,3 +299,24 @@ def test_trainer_loop_shards_batches_and_sums_gradients(tmp_path):
     assert moved.max() > 1e-3                                 # the run really trained
     assert abs(float(r0["metric"]) - float(ref["metric"])) < 1e-6 and float(r0["metric"]) == float(r1["metric"])
     assert int(r0["ckpt"]) == 1 and int(r1["ckpt"]) == 1 and os.path.exists(tmp_path / "m2" / "dp" / "dplast_model.pth")
+
+
+def test_bare_bench_spawns_ranks_and_relays_their_exit_code():
+    """bench.py started bare with --gpus 2 (WORLD_SIZE unset) must become the launcher: it starts `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py <same arguments>` as a child and hands back its exit code.
+    Without a GPU the ranks refuse to run (HIP-only path, no CPU fallback): the launcher must relay that failure, not hide it, and
+    no JSON line may appear.  (The success path runs on the GPU box: tests/test_parallel_gpu.py::test_bare_bench_launches_its_own_ranks.)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "[rank0]" in r.stderr and "[rank1]" in r.stderr   # both ranks were started (under torch.distributed.run's elastic agent) ...
+    assert "No HIP GPUs are available" in r.stderr or "no ROCm GPU visible" in r.stderr      # ... and refused to run without a GPU
+    assert "ChildFailedError" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

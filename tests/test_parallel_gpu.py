@@ -108,3 +108,22 @@ def test_library_rccl_entry_points_execute_with_one_rank(tmp_path):
     np.testing.assert_array_equal(got["probe32"], np.arange(1000, dtype=np.float32) * 0.5)
     np.testing.assert_array_equal(got["probe64"], np.arange(7, dtype=np.float64) + 0.25)
     assert float(got["loss"]) == float(ref["loss"]) and np.array_equal(got["grads"], ref["grads"]) and np.array_equal(got["weights"], ref["weights"])
+
+
+@pytest.mark.timeout(1800)
+def test_bare_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` started WITHOUT a launcher (how the driver starts the scaling runs) spawns its two ranks through
+    torch.distributed.run as fresh child processes and relays rank 0's single JSON line: n_gpus 2, weak scaling, whole-job `value`, and
+    the forward leg (2 replicas) that BASELINE's metric asks for at every N.  One MI355X here: the ranks share cuda:0 over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--size", "64", "--batch", "1", "--no-cpu-baseline", "--no-power", "--probe-steps", "0"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
+    assert out["fwd"]["replicas"] == 2 and out["fwd"]["value"] > 0
+    assert np.isfinite(out["final_loss"])
