@@ -22,7 +22,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
   train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
   fwd          : forward-only volumes/s at batch 1 in the precision of the run (at every N: N independent replicas),
-  fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1).
+  fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
+  trainer_step : the same training step driven through the reference surface (train.Trainer._train_one_epoch set up as main.py:126-142).
 """
 import argparse
 import json
@@ -288,6 +289,42 @@ def sliding_window_probe(backend, flat, precision, batch_tiles=8):
             "batch_tiles": batch_tiles, "ms_per_volume": round(dt * 1e3, 2), "tiles_per_s": round(len(positions) / dt, 1), "precision": precision}
 
 
+def trainer_step_probe(backend, flat, x, g, steps, warmup=2):
+    """The reference-surface loop: `train.Trainer._train_one_epoch` over `steps` resident batches, set up exactly as main.py:126-142
+    drives `Trainer.train` -- model.UNet, criterion=[Dice_loss_joint(index=0, priority=1), BCE_Loss(index=0, bg_weight=1e-2)],
+    optimizer=torch.optim.Adam with lr 2e-5 / weight_decay 1e-6 / amsgrad, StepLR(16000, 0.5) stepped per iteration, metrics.Dice as the
+    train metric.  Same weights, batch and arithmetic as `value` (which times parallel.DataParallelStep)."""
+    import tempfile
+    from brats2019_amd import model as M, loss as LS, train as TR, metrics as MT
+    net = M.UNet(**backend.cfg)
+    net.set_precision(backend.engine.precision)
+    net.cuda()
+    with torch.no_grad():
+        for (name, p), (_n, v) in zip(net.named_parameters(), backend.engine.layout.views(flat).items()):
+            assert name == _n
+            p.copy_(v)
+    with tempfile.TemporaryDirectory() as root:
+        tr = TR.Trainer(name="bench", models_root=root, model=net, rewrite=True, connect_tb=False)
+        criterion = [LS.Dice_loss_joint(index=0, priority=1), LS.BCE_Loss(index=0, bg_weight=1e-2)]
+        opt, sched = tr._make_optimizer(torch.optim.Adam, {"lr": 2e-5, "weight_decay": 1e-6, "amsgrad": True},
+                                        torch.optim.lr_scheduler.StepLR, {"step_size": 16000, "gamma": 0.5})
+        results = {"Dice": []}
+        metric = [MT.Dice(name="Dice", input_index=0, target_index=0, classes=4)]
+        run = lambda k, gs: tr._train_one_epoch(criterion, opt, [([x], [g])] * k, metric, results, 0, gs, sched)
+        gs = run(warmup, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gs = run(steps, gs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    optname = type(opt).__module__ + "." + type(opt).__name__
+    del net, tr, opt
+    return {"value": round(x.shape[0] * steps / dt, 3), "unit": "volumes/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "optimizer": optname + " (instantiated by Trainer for optimizer=torch.optim.Adam)",
+            "what": "train.Trainer._train_one_epoch: model.UNet forward, criterion=[Dice_loss_joint, BCE_Loss] (evaluated as one fused pair), loss.backward(), "
+                    "Adam(amsgrad) + StepLR per iteration, metrics.Dice update -- the loop of main.py:126-158 / train.py:178-241; includes the epoch-end metric read-back"}
+
+
 def cpu_baseline(size, threads=0):
     """The CPU oracle = the reference's op sequence on torch CPU, fwd+loss+bwd, batch 1.
     `cores` = torch threads actually used: on a many-core host the oneDNN/OpenMP path of this op mix is fastest well
@@ -465,6 +502,12 @@ def main():
                                       "grad_precision": "bf16 operands, one MFMA product, fp32 accumulate in the 3x3x3 data / weight gradients (ru_unet_set_grad_precision); "
                                                         "forward bf16x3 as in `value`; parameter gradients within 2.5e-3 relative L2 of the three-product backward "
                                                         "(tests/test_hip_unet.py::test_unet128_train_step_bf16_gradient_precision)"}
+        if args.precision == "bf16x3" and args.grad_precision == "bf16x3":
+            backend.engine.freeze_params(False)
+            ts = trainer_step_probe(backend, flat, x, g, args.steps)
+            ts["vs_data_parallel_step"] = round(ts["ms_per_step"] / (1e3 * dt / args.steps), 4)
+            out["trainer_step"] = ts
+            backend.engine.freeze_params(True)
         if args.size == 128:
             out["sliding_window"] = sliding_window_probe(backend, flat, args.precision)
         if not args.no_cpu_baseline:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ru_criterion_value": (_i, [C.POINTER(_d), _i, _d, _d, C.POINTER(_d), C.POINTER(_d)]),
     "ru_criterion_value_device": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp]),
     "ru_adam_amsgrad_step": (_i, [_vp] * 5 + [_sz] + [_f] * 5 + [_i, _vp]),
+    "ru_adam_step": (_i, [_vp] * 5 + [_sz] + [_f] * 5 + [_i, _vp]),
     "ru_unet_create": (_vp, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i]),
     "ru_unet_destroy": (None, [_vp]),
     "ru_unet_set_precision": (_i, [_vp, _i]),

@@ -1300,6 +1300,12 @@ extern "C" int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v
     return adam_launch(w, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
 }
 
+extern "C" int ru_adam_step(float* w, const float* g, float* m, float* v, float* vmax_or_null, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, ru_stream_t stream) {
+    RU_REQUIRE(w && g && m && v, "ru_adam_step: null argument");
+    return adam_launch(w, g, m, v, vmax_or_null, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- inference post-processing
 extern "C" int ru_tta_merge(const float* probs, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts,
                             int C, int D, int H, int W, ru_stream_t stream) {

@@ -1168,6 +1168,8 @@ int augment_patch_launch(const AugmentArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ Adam(amsgrad=True, weight_decay) (main.py:133-137)
+// AMS = false: plain Adam (torch.optim.Adam(amsgrad=False)), vmax is not touched
+template <bool AMS>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    float* __restrict__ vmax, size_t n, float step_size, float b1, float b2, float eps, float wd,
                                                    float bc2_sqrt) {
@@ -1176,9 +1178,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
         const float gi = g[i] + wd * wi;
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * b2 + (1.f - b2) * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float vm = fmaxf(vmax[i], vi);
+        float vm = vi;
+        if (AMS) { vm = fmaxf(vmax[i], vi); vmax[i] = vm; }
         const float denom = sqrtf(vm) / bc2_sqrt + eps;
-        m[i] = mi; v[i] = vi; vmax[i] = vm;
+        m[i] = mi; v[i] = vi;
         w[i] = wi - step_size * (mi / denom);
     }
 }
@@ -1187,8 +1190,10 @@ int adam_launch(float* w, const float* g, float* m, float* v, float* vmax, size_
     if (n == 0) return RU_OK;
     RU_REQUIRE(step >= 1, "adam: step is 1-based");
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n, 256 * 4, 4096)), dim3(256), 0, s, w, g, m, v, vmax, n, (float)((double)lr / bc1), b1, b2, eps, wd,
-                       (float)sqrt(bc2));
+    if (vmax) hipLaunchKernelGGL(adam_kernel<true>, dim3(grid1d(n, 256 * 4, 4096)), dim3(256), 0, s, w, g, m, v, vmax, n, (float)((double)lr / bc1), b1, b2, eps, wd,
+                                 (float)sqrt(bc2));
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3(grid1d(n, 256 * 4, 4096)), dim3(256), 0, s, w, g, m, v, vmax, n, (float)((double)lr / bc1), b1, b2, eps, wd,
+                            (float)sqrt(bc2));
     RU_CHECK_LAUNCH("adam_kernel");
     return RU_OK;
 }

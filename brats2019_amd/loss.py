@@ -45,6 +45,52 @@ class _CriterionFn(torch.autograd.Function):
         return dp.mul_(gout.to(dp.dtype)), None, None, None, None, None, None
 
 
+class _PairFn(torch.autograd.Function):
+    """[Dice_loss_joint, BCE_Loss] evaluated together (train.py:203-205: loss = (dice + bce) / 2): ONE sums pass gives both values,
+    ONE gradient pass gives d loss / d p.  Returns (loss, dice, bce); only `loss` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, bg_weight, priority, group):
+        sums = ops.criterion_sums(pred, gt, bg_weight)
+        world = _all_reduce_sums(sums, group)
+        count = float(pred.numel()) * world
+        out = ops.criterion_losses(sums, count, priority, 0.5, 0.5).to(torch.float32)
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.cfg = (count, bg_weight, priority)
+        loss, dice, bce = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(dice, bce)
+        return loss, dice, bce
+
+    @staticmethod
+    def backward(ctx, gout, _gd, _gb):
+        pred, gt, sums = ctx.saved_tensors
+        count, bg_weight, priority = ctx.cfg
+        dp = ops.criterion_grad(pred, gt, sums, count, 0.5, 0.5, bg_weight, priority)
+        return dp.mul_(gout.to(dp.dtype)), None, None, None, None
+
+
+def fuse_criterion_list(criterion):
+    """`criterion=[Dice_loss_joint(index, priority), BCE_Loss(index, bg_weight)]` (main.py:126-128, either order, same index) ->
+    a callable `(x_list, y_list) -> (loss, [value per list entry])` with loss == sum(values) / 2 exactly as train.py:203-205 forms it,
+    computed by one pass of each criterion phase instead of two.  Anything else -> None (the caller evaluates the list as written)."""
+    if not isinstance(criterion, (tuple, list)) or len(criterion) != 2:
+        return None
+    kinds = [type(c) for c in criterion]
+    if sorted(k.__name__ for k in kinds) != ["BCE_Loss", "Dice_loss_joint"] or not all(k in (Dice_loss_joint, BCE_Loss) for k in kinds):
+        return None
+    dice = criterion[0] if kinds[0] is Dice_loss_joint else criterion[1]
+    bce = criterion[0] if kinds[0] is BCE_Loss else criterion[1]
+    if dice.index != bce.label_index or dice.data_parallel != bce.data_parallel:
+        return None
+    dice_first = kinds[0] is Dice_loss_joint
+
+    def run(x, y):
+        assert x[dice.index].shape == y[dice.index].shape                  # loss.py:71,107
+        loss, d, b = _PairFn.apply(x[dice.index], y[dice.index], float(bce.bg_weight), float(dice.priority), dice.data_parallel)
+        return loss, ([d, b] if dice_first else [b, d])
+    return run
+
+
 class _LossBase(nn.Module):
     """`data_parallel`: False (reference semantics, single process), or True / a process group: all-reduce the partial
     sums so that every rank forms the GLOBAL-batch loss the reference computes on GPU 0 under nn.DataParallel."""

@@ -76,6 +76,10 @@ class Trainer(object):
         self.state = TrainingState()
         self.resume_training = False
         self.shard_batches = True          # data parallel: slice each loader batch per rank (nn.DataParallel's scatter)
+        self.hip_optimizer = True          # Trainer.train(optimizer=torch.optim.Adam, ...) -> brats2019_amd.optim.Adam (same surface, HIP kernel)
+        self.fuse_criteria = True          # criterion=[Dice_loss_joint, BCE_Loss] -> one sums pass + one gradient pass (loss.fuse_criterion_list)
+        self.log_every = 50                # loss scalars are queued on the device and written every `log_every` steps: no per-step host sync
+        self._pending_scalars = []
         rank, world = world_info()
         if rank == 0:
             if os.path.exists(self.model_path):
@@ -125,12 +129,7 @@ class Trainer(object):
             self.state.best_val = default_val
         if self.state.cuda:
             self.model.cuda()
-        if isinstance(optimizer, type):
-            optimizer = optimizer(params=self.model.parameters(), **optimizer_params)
-        if scheduler is not None and isinstance(scheduler, type):
-            scheduler = scheduler(optimizer=optimizer, **scheduler_params)
-        assert isinstance(optimizer, torch.optim.Optimizer)
-        assert scheduler is None or isinstance(scheduler, torch.optim.lr_scheduler.LRScheduler)
+        optimizer, scheduler = self._make_optimizer(optimizer, optimizer_params, scheduler, scheduler_params)
         if self.state.optimizer_state is not None and not continue_form_pretraining:
             optimizer.load_state_dict(self.state.optimizer_state)
             print("Loaded optimizer state")
@@ -149,6 +148,22 @@ class Trainer(object):
             self._save(suffix="_epoch_" + str(self.state.epoch))
             self._save(suffix="last_model")
             self.state.epoch = self.state.epoch + 1
+
+    def _make_optimizer(self, optimizer, optimizer_params, scheduler, scheduler_params):
+        """train.py:82-90: instantiate the optimizer / scheduler classes the caller handed over."""
+        if isinstance(optimizer, type):
+            # main.py:134 passes the CLASS torch.optim.Adam: on the HIP path it is instantiated as brats2019_amd.optim.Adam -- the same
+            # torch.optim.Optimizer surface and state_dict() layout (a checkpoint of either resumes under the other, train.py:92-94),
+            # with the update as one ru_adam_step launch per contiguous run of the flat parameter buffer.  `hip_optimizer = False` keeps torch's.
+            if optimizer is torch.optim.Adam and self.hip_optimizer and self.state.cuda:
+                from . import optim as hip_optim
+                optimizer = hip_optim.Adam
+            optimizer = optimizer(params=self.model.parameters(), **optimizer_params)
+        if scheduler is not None and isinstance(scheduler, type):
+            scheduler = scheduler(optimizer=optimizer, **scheduler_params)
+        assert isinstance(optimizer, torch.optim.Optimizer)
+        assert scheduler is None or isinstance(scheduler, torch.optim.lr_scheduler.LRScheduler)
+        return optimizer, scheduler
 
     def _to_device(self, tensors):
         return [t.cuda(non_blocking=True) for t in tensors] if self.state.cuda else list(tensors)
@@ -173,9 +188,9 @@ class Trainer(object):
         if world <= 1 or not hasattr(m, "accumulator"):
             return
         import torch.distributed as dist
-        acc = torch.as_tensor(np.asarray(m.accumulator, dtype=np.float64))
-        if torch.cuda.is_available() and dist.get_backend() == "nccl":
-            acc = acc.cuda()
+        acc = m.accumulator
+        acc = acc.detach().to(torch.float64) if isinstance(acc, torch.Tensor) else torch.as_tensor(np.asarray(acc, dtype=np.float64))
+        acc = acc.cuda() if (torch.cuda.is_available() and dist.get_backend() == "nccl") else acc.cpu()
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         acc = (acc / world).cpu().numpy()
         m.accumulator = acc if acc.ndim else float(acc)
@@ -187,11 +202,15 @@ class Trainer(object):
             self.model.cuda()
         self.model.train()
         optimizer.zero_grad()
+        from . import loss as hip_loss
+        fused = hip_loss.fuse_criterion_list(criterion) if self.fuse_criteria else None
         for batch in loader:
             assert isinstance(batch[0], list) and isinstance(batch[1], list)
             data, target = self._to_device(self._shard(batch[0])), self._to_device(self._shard(batch[1]))
             output = self.model(data)                                        # train.py:201
-            if isinstance(criterion, (tuple, list)):
+            if fused is not None:
+                loss, loss_val = fused(output, target)                       # the same list of values and their mean, one pass per phase
+            elif isinstance(criterion, (tuple, list)):
                 loss_val = [c(output, target) for c in criterion]            # train.py:203-205
                 loss = sum(loss_val) / len(loss_val)
             else:
@@ -205,17 +224,30 @@ class Trainer(object):
                 scheduler.step()                                             # per iteration (train.py:222-223)
             for m in train_metrics:
                 m.update(output, target)
-            for i, lv in enumerate(loss_val):
-                self.tb_writer.add_scalar("loss/loss-%d" % i, lv.item(), global_step)
-            for i, group in enumerate(optimizer.param_groups):
-                self.tb_writer.add_scalar("misc/lr-%d" % i, group["lr"], global_step)
+            if not isinstance(self.tb_writer, _NullWriter):
+                # train.py:226-227 logs lv.item() per step -- a host sync per step; here the values wait on the device and go out in batches
+                for i, lv in enumerate(loss_val):
+                    self._pending_scalars.append(("loss/loss-%d" % i, lv.detach(), global_step))
+                for i, group in enumerate(optimizer.param_groups):
+                    self.tb_writer.add_scalar("misc/lr-%d" % i, group["lr"], global_step)
+                if len(self._pending_scalars) >= self.log_every * max(1, len(loss_val)):
+                    self._flush_scalars()
             global_step += 1
+        self._flush_scalars()
         for m in train_metrics:
             self._reduce_metric(m)
             results[m.name].append(m.get())
             _log_metric(self.tb_writer, m, "train/", epoch)
         self.state.optimizer_state = optimizer.state_dict()
         return global_step
+
+    def _flush_scalars(self):
+        if not self._pending_scalars:
+            return
+        vals = torch.stack([v.reshape(()).to(torch.float64) for _, v, _ in self._pending_scalars]).cpu().tolist()     # one device -> host copy
+        for (tag, _, step), v in zip(self._pending_scalars, vals):
+            self.tb_writer.add_scalar(tag, v, step)
+        self._pending_scalars = []
 
     # ------------------------------------------------------------------ inference (train.py:129-176)
     def predict(self, batch):

@@ -130,6 +130,12 @@ int ru_criterion_value_device(const double* sums, int C, double count, double pr
 int ru_adam_amsgrad_step(float* w, const float* g, float* m, float* v, float* vmax, size_t n,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          ru_stream_t stream);
+/* the same with amsgrad optional: vmax_or_null == NULL is torch.optim.Adam(amsgrad=False).  What brats2019_amd.optim.Adam.step() -- the
+ * optimizer class Trainer.train instantiates in place of torch.optim.Adam (main.py:134, train.py:82-83) -- calls once per contiguous run
+ * of parameters of the flat buffer.  */
+int ru_adam_step(float* w, const float* g, float* m, float* v, float* vmax_or_null, size_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                 ru_stream_t stream);
 
 /* ---------------------------------------------------------------- whole-network engine
  * model.UNet(depth, encoder_layers, decoder_layers, number_of_channels, number_of_outputs) (model.py:309)
