@@ -13,6 +13,7 @@
 #include "ru_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -65,12 +66,26 @@ struct Arena {
     size_t need() const { return peak + keep; }
 };
 
+// RU_TRACE=1 in the environment: every launch of the executor is named on stderr and followed by a stream synchronisation, so a
+// faulting kernel is the last line printed (debugging aid; one getenv per process, nothing on the normal path)
+static bool trace_on() {
+    static const bool on = [] { const char* e = getenv("RU_TRACE"); return e && *e && *e != '0'; }();
+    return on;
+}
+static int trace_sync(const char* what, hipStream_t s) {
+    fprintf(stderr, "[ru] %s\n", what);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { fprintf(stderr, "[ru]   -> %s\n", hipGetErrorString(e)); return hip_fail(e, what); }
+    return RU_OK;
+}
+
 #define RU_RUN(call)                      \
     do {                                  \
         if (!A.dry) {                     \
             if (A.failed) { set_error("workspace too small"); return RU_ENOMEM; } \
             const int rc__ = (call);      \
             if (rc__ != RU_OK) return rc__; \
+            if (trace_on()) { const int rt__ = trace_sync(#call, s); if (rt__ != RU_OK) return rt__; } \
         }                                 \
     } while (0)
 
@@ -621,7 +636,9 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
 // fused_part / fused_nblk: the partial sums were already taken by the conv that produced `dact` (Conv3Args::bst_*): no reduce pass
 static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
                   float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const float* fused_part = nullptr, int fused_nblk = 0,
-                  float** coef_out = nullptr /* non-null: stop after the finalize; the apply is fused into the weight gradient (Wgrad3Args::gb_*) */) {
+                  float** coef_out = nullptr /* non-null: stop after the finalize; the apply is fused into the weight gradient (Wgrad3Args::gb_*) */,
+                  bool split = true /* voxel-major flow: publish dy as hi/lo bf16 packets (read by the transpose-read weight gradient and the
+                                       persistent data-gradient conv) or as plain float32 C16 (the generic weight-gradient kernel) */) {
     const bool fused = fused_nblk > 0;
     const int nblk = fused ? fused_nblk : (c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V));
     float* part = fused ? const_cast<float*>(fused_part) : A.alloc((size_t)N * C * nblk * 2);
@@ -632,7 +649,7 @@ static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const fl
     }
     RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s, fused ? 1 : 0));
     if (coef_out) { *coef_out = coef; return RU_OK; }
-    if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, 1, s));   // split form: read by MFMA kernels only
+    if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, split ? 1 : 0, s));   // split form: read by MFMA kernels only
     else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
     return RU_OK;
 }
@@ -804,16 +821,21 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     const bool c16 = h->c16;
     const bool head4 = c16 && conv3_sb4_usable(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);      // few channels: one 4-channel copy feeds both head kernels
     float* d4 = head4 ? A.alloc((size_t)N * 4 * Vl(0)) : nullptr;
-    float* dlog = head4 ? nullptr : A.alloc((size_t)N * h->nout * Vl(0));
+    // the 4-channel copy feeds the head's weight gradient only in the Cin <= 16 && Cout <= 16 branch of wgrad3_run: a wider first level
+    // takes the generic kernel, which reads the class gradient in NCDHW form -- it is then written as well
+    const bool need_dlog = !head4 || C0 > 16;
+    float* dlog = need_dlog ? A.alloc((size_t)N * h->nout * Vl(0)) : nullptr;
     const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
     float* wsp = A.alloc(wsb / sizeof(float) + 1);
     if (head4) {                                                 // sigmoid backward, 4-channel copy and bias gradient in one pass
         RU_RUN(head_grad_c4_launch(h->probs, dprobs, d4, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
+        if (need_dlog) RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
     } else {
         RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
         RU_RUN(bias_grad_launch(dlog, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
     }
-    int rc = wgrad3_run(A, s, h->wgrad_mode(), h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false, d4);
+    int rc = wgrad3_run(A, s, h->wgrad_mode(), h->head_in, nullptr, dlog, G(h, grads, h->conv_out_w), N, C0, h->nout, Dl[0], Hl[0], Wl[0], c16, false,
+                        C0 <= 16 ? d4 : nullptr);
     if (rc) return rc;
     float* dcur_buf = A.alloc((size_t)N * C0 * Vl(0));
     Conv3Args dh{};
@@ -946,11 +968,15 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // weight-gradient kernel, which reads a WRITTEN dy0)
     const bool fuse0 = c16 && h->precision == RU_PREC_BF16X3 && (h->fusion & RU_FUSE_GN_BWD_APPLY) && !dx_in && h->x_in4_planned && C0 <= 16 && kInCh <= 4;
     float* coef0 = nullptr;
+    // a stem wider than 16 channels: its weight gradient is the generic mixed-layout kernel (x NCDHW, dy voxel-major float32), which does
+    // not read the split form
+    const bool split0 = c16 && C0 <= 16;
     rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst,
-                fuse0 ? &coef0 : nullptr);
+                fuse0 ? &coef0 : nullptr, split0);
     if (rc) return rc;
     const GbApply gb0{h->y0, dcur, &h->g0, coef0};
-    rc = wgrad3_run(A, s, h->wgrad_mode(), h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, h->x_in4, c16, fuse0 ? &gb0 : nullptr);
+    rc = wgrad3_run(A, s, h->wgrad_mode(), h->x_in, nullptr, dy0, G(h, grads, h->conv_in), N, kInCh, C0, Dl[0], Hl[0], Wl[0], false, c16, C0 <= 16 ? h->x_in4 : nullptr, split0,
+                    fuse0 ? &gb0 : nullptr);
     if (rc) return rc;
     if (dx_in) {
         // d/d(input): not needed by training (train.py:201-210), offered for gradient checks
@@ -959,7 +985,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         Conv3Args di{};
         if (c16) {                                               // dy0 is voxel-major: the split-bf16 kernel reads it
             RU_RUN(conv3_sb_pack_weights(P(h, params, h->conv_in), wfd, kInCh, C0, 1, s));
-            di.mode = RU_PREC_BF16X3; di.wfrag = wfd; di.in_c16 = 1; di.in_s16 = 1;
+            di.mode = RU_PREC_BF16X3; di.wfrag = wfd; di.in_c16 = 1; di.in_s16 = split0 ? 1 : 0;
         } else {
             RU_RUN(conv3_pack_weights(P(h, params, h->conv_in), wpd, kInCh, C0, 1, s));
         }

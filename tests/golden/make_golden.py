@@ -248,7 +248,7 @@ def gn_stats_hooks(net, store):
     return hooks
 
 
-def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16):
+def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16, full_grads=()):
     out = {"seed": np.int64(seed), "shape": np.asarray((n,) + dhw, np.int64)}
     net, params = load_ref_unet(cfg, seed)
     x = O.make_input(n, *dhw, seed=seed)
@@ -274,6 +274,9 @@ def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16):
             out["gsamp_" + k] = gflat[:: max(1, gflat.size // nsamp)][:nsamp].copy()
             if gflat.size <= 4096:
                 out["gfull_" + k] = p.grad.numpy().copy()
+            if k in full_grads:                                                # whole convolution-weight gradients: elementwise parity of the
+                out["gconv_" + k] = p.grad.numpy().copy()                      # persistent weight-gradient kernels at full size
+        assert all(("gconv_" + k) in out for k in full_grads), "full_grads names a parameter the reference did not produce a gradient for"
         out["dead_params"] = np.asarray(dead)
         probs = probs.detach()
     else:
@@ -512,7 +515,9 @@ if __name__ == "__main__":
     if want("unet128_train"):
         # a TRAINING step at a size where every persistent kernel path of the HIP engine is taken (batch 2 x 128^3; the reference needs
         # ~15 s and ~10 GB for it): train.py:201-210 around the imported model / loss modules
-        gen_unet("unet128_train", full, 2, (128, 128, 128), 2024, full_output=False, with_backward=True, nsamp=64)
+        gen_unet("unet128_train", full, 2, (128, 128, 128), 2024, full_output=False, with_backward=True, nsamp=64,
+                 full_grads=("conv_first.0.conv1.conv1.weight", "encoder_convs.0.1.conv2.conv1.weight", "encoder_convs.2.3.conv1.conv1.weight",
+                             "decoder_convs.0.0.conv2.conv1.weight"))
     if want("sliding240"):
         gen_sliding240()
     if want("adam"):

@@ -46,7 +46,7 @@ def run_train_step(cfg, n, dhw, seed, precision="f32", fusion=None, grad_precisi
     return net, out[0].detach(), loss, vals
 
 
-def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, loss_tol=5e-6, flip_band=1e-5):
+def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, loss_tol=5e-6, flip_band=1e-5, conv_rel=None):
     p = probs.cpu().numpy()
     if "probs" in g:
         err = np.abs(p - g["probs"]).max()
@@ -75,6 +75,13 @@ def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, lo
             # magnitude: the fp32 CPU reference itself carries ~1e-3 relative noise there, hence 4x the norm tolerance
             np.testing.assert_allclose(gr, g["gfull_" + k].ravel().astype(np.float64), rtol=0, atol=4 * grad_rel * np.abs(g["gfull_" + k]).max() + 1e-9,
                                        err_msg=k)
+        if "gconv_" + k in g:
+            # whole convolution-weight gradients of the full-size step against the REFERENCE, elementwise: relative L2 of the difference
+            # (a wrong halo term on one face of a tile, a mirrored tap or a transposed channel pair cannot hide in a norm)
+            r = g["gconv_" + k].astype(np.float64).ravel()
+            rel = float(np.linalg.norm(gr - r) / np.linalg.norm(r))
+            print("  full gradient %-42s relative L2 vs reference %.2e" % (k, rel))
+            assert rel <= (conv_rel if conv_rel is not None else 2 * grad_rel), (k, rel)
         ns = int(g["gsamp_" + k].size)
         samp = gr[:: max(1, gr.size // ns)][:ns]
         np.testing.assert_allclose(samp, g["gsamp_" + k].astype(np.float64), rtol=0, atol=10 * grad_rel * ref / np.sqrt(gr.size) + 1e-9, err_msg=k)
