@@ -278,11 +278,10 @@ def sliding_window_probe(backend, flat, precision, batch_tiles=8):
 
     def run():
         for s0 in range(0, len(positions), batch_tiles):
-            idx = [tiling.get_indices(p, centre, border) for p in positions[s0:s0 + batch_tiles]]
-            tiles = torch.cat([tiling.copy(vol, tile, lo, hi) for lo, hi in idx], dim=0)
+            los = [tiling.get_indices(p, centre, border)[0] for p in positions[s0:s0 + batch_tiles]]
+            tiles = tiling.copy_tiles(vol, tile, los)                      # ru_tile_gather: the batch tensor in one launch
             probs = backend.forward(flat, tiles, training=False)
-            for t, (lo, hi) in enumerate(idx):
-                tiling.copy_back(out, probs[t:t + 1], centre, lo, hi, border)
+            tiling.copy_back_tiles(out, probs, centre, los, border)        # ru_tile_scatter
     run()
     dt = time_region(run, 3, False) / 3
     return {"value": round(1.0 / dt, 3), "unit": "240x240x155 volumes/s", "tiles": len(positions), "tile": 128, "centre": 64, "border": 32,

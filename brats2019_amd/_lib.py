@@ -79,6 +79,16 @@ SIGNATURES = {
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),
+    "ru_tile_gather": (_i, [_vp, _vp] + [_i] * 6 + [C.POINTER(_i), _i, _i, _i, _vp]),
+    "ru_tile_scatter": (_i, [_vp, _vp] + [_i] * 6 + [C.POINTER(_i), _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    "ru_case_bbox": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ru_case_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ru_case_stats": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp, _sz, _vp]),
+    "ru_case_prepare": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, C.c_uint, _vp]),
+    "ru_tta_merge_box": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
+    "ru_cc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ru_cc_reject": (_i, [_vp, _i, _i, _i, _d, _vp, _sz, _vp]),
+    "ru_paste_labels": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     "ru_zscore_workspace_bytes": (_sz, [_i, _sz]),
     "ru_zscore_stats": (_i, [_vp, _vp, _i, _sz, _vp, _sz, _vp]),
     "ru_augment_patch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

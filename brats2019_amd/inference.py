@@ -1,13 +1,18 @@
-"""Inference driver around the forward pass: the per-case pipeline of the reference's test.py (:82-164) with the
-device-side pieces moved next to the network --
+"""Inference driver around the forward pass: the per-case pipeline of the reference's test.py (:82-164), on the device from the upload
+of the case to the download of its label volume (kernels in csrc/inference.hip) --
 
-  host (numpy, as the reference): bbox crop (test.py:85-87), zero-pad to x16 (:92-99), per-channel non-zero z-score (:103-113);
-  device: the FOUR test-time-augmentation flips (:115-120) are built on the GPU and run as ONE batch-4 forward instead of
-          four forward calls with host round trips (:124-132); un-flip + average + threshold + per-class counts are one
-          HIP kernel (ru_tta_merge, :134-144), label composition another (ru_compose_labels, :146-159);
-  host: 26-connected component rejection (:162-164; scipy.ndimage instead of skimage), paste into the full volume (:167-168).
+  ru_case_bbox      bounding box of the non-zero voxels (test.py:47-49,85-87); its 6 integers are the only values that visit the host
+                    in between: they fix the tensor shapes of everything downstream;
+  ru_case_stats     non-zero z-score moments of the crop (test.py:103-111), float64;
+  ru_case_prepare   crop + zero-pad to x16 (test.py:92-99) + z-score (:113) + the FOUR test-time flips (:115-120) written as ONE batch;
+  model             one batch-4 forward instead of four forward calls with host round trips (:124-132);
+  ru_tta_merge_box  un-flip + average + un-pad + threshold + per-class counts (:134-144); ru_compose_labels (:146-159);
+  ru_cc_reject      26-connected components (skimage.morphology.label) + rejection of regions below ratio 0.1 (:51-62,162-164);
+  ru_paste_labels   paste into the full volume (:167-168).
 
-NIfTI reading/writing (nibabel) is out of scope; `predict_case` takes and returns arrays.
+The numpy functions below (`get_bbox`, `prepare_case`, `reject_small_regions`, `postprocess_labels`) are the host restatement the
+device pipeline is tested against; `predict_case` does not call them.  NIfTI reading/writing (nibabel) is out of scope; `predict_case`
+takes and returns arrays.
 """
 from __future__ import annotations
 
@@ -98,12 +103,41 @@ def postprocess_labels(labels):
     return labels
 
 
+def prepare_case_device(image):
+    """test.py:85-120 on the device.  image: [C,D,H,W] float32 device tensor.  Returns (batch [4,C,Dp,Hp,Wp] = the four test-time flips
+    of the padded, normalised crop; lo, size = the crop box; pad_left; padded extents)."""
+    boxes = ops.case_bbox(image)                                     # [C,6] on the host: the only device -> host copy before the labels
+    lo = boxes[:, :3].min(axis=0)
+    hi = boxes[:, 3:].max(axis=0)                                    # test.py:87 uses the max INDEX as an exclusive slice end
+    size = hi - lo
+    if (lo < 0).any() or (size <= 0).any():
+        raise ValueError("predict_case: a modality without non-zero voxels (or a one-voxel-thick box) gives an empty crop (test.py:85-87)")
+    padded = np.array([closest_to_k(int(v), 16) for v in size])
+    left = (padded - size) // 2
+    stats = ops.case_stats(image, lo, size)
+    batch = ops.case_prepare(image, stats, lo, size, left, padded, TTA_FLIPS)
+    return batch, lo, size, left, padded
+
+
+def predict_case_device(model, image):
+    """The per-case pipeline of test.py:82-168 with every array on the device: image [4,D,H,W] device tensor -> (uint8 device label volume
+    [D,H,W] with values {0,1,2,4}, int64 device tensor of the (wt, tc, et) voxel counts)."""
+    image = image.contiguous().float()
+    batch, lo, size, left, _padded = prepare_case_device(image)
+    model.eval()
+    if hasattr(model, "freeze_params"):
+        model.freeze_params(True)
+    with torch.no_grad():
+        probs = model([batch])[0]                                    # [4,3,Dp,Hp,Wp]
+    mask, counts, _ = ops.tta_merge_box(probs, TTA_FLIPS, left, size)
+    labels = ops.compose_labels(mask, counts, et_min=32)
+    ops.cc_reject(labels, 0.1)
+    return ops.paste_labels(labels, image.shape[1:], lo), counts
+
+
 def predict_case(model, image):
-    """Full per-case pipeline of test.py:82-168 for one multimodal volume `image` [4,D,H,W] (numpy).
-    Returns (uint8 label volume [D,H,W] with values {0,1,2,4}, (wt, tc, et) voxel counts)."""
-    x, bbox, left, right = prepare_case(np.asarray(image))
-    labels, counts, _ = predict_tta(model, x, left, right)
-    lab = postprocess_labels(labels.cpu().numpy())
-    out = np.zeros(image.shape[1:], dtype=np.uint8)
-    out[bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]] = lab
-    return out, tuple(int(v) for v in counts.cpu().tolist())
+    """Full per-case pipeline of test.py:82-168 for one multimodal volume `image` [4,D,H,W] (numpy or tensor): one upload, the device
+    pipeline above, one download.  Returns (uint8 label volume [D,H,W] with values {0,1,2,4}, (wt, tc, et) voxel counts)."""
+    img = torch.as_tensor(np.asarray(image) if not isinstance(image, torch.Tensor) else image, dtype=torch.float32).cuda()
+    full, counts = predict_case_device(model, img)
+    return full.cpu().numpy(), tuple(int(v) for v in counts.cpu().tolist())

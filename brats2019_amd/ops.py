@@ -217,6 +217,120 @@ def compose_labels(mask, counts, et_min=32):
     return labels
 
 
+def _ints(v):
+    import ctypes
+    v = [int(x) for x in v]
+    return (ctypes.c_int * len(v))(*v)
+
+
+def _flip_bits(flip_axes):
+    flips = 0
+    for i, axes in enumerate(flip_axes):
+        for ax in axes:
+            flips |= TTA_FLIP_BITS[ax] << (3 * i)
+    return flips
+
+
+def tile_gather(data, tile_shape, origins):
+    """loader_helper.copy (:42-60) for T tiles in one launch: data [N,C,D,H,W] -> [T*N, C, *tile_shape], tile t = the zero-padded
+    block starting at origins[t] (= get_indices' index_min; may be negative)."""
+    data = _prep(data)
+    n, c, d, h, w = _dims5(data)
+    t = len(origins)
+    td, th, tw = (int(v) for v in tile_shape)
+    tiles = torch.empty((t * n, c, td, th, tw), dtype=torch.float32, device=data.device)
+    L.check(L.load().ru_tile_gather(L.f32(data), L.f32(tiles), n, c, d, h, w, t, _ints([v for o in origins for v in o]), td, th, tw, L.stream()),
+            "ru_tile_gather")
+    return tiles
+
+
+def tile_scatter(out, tiles, origins, border, center):
+    """loader_helper.copy_back (:82-97) for T tiles in one launch: the centre block of tile t goes to out[..., origins[t] + border ...]."""
+    tiles = _prep(tiles)
+    if not (out.is_cuda and out.is_contiguous() and out.dtype == torch.float32):
+        raise ValueError("tile_scatter: `out` must be a contiguous float32 device tensor (it is written in place)")
+    n, c, d, h, w = _dims5(out)
+    t = len(origins)
+    td, th, tw = (int(v) for v in tiles.shape[2:])
+    if int(tiles.shape[0]) != t * n or int(tiles.shape[1]) != c:
+        raise ValueError("tile_scatter: tiles %s do not match %d tiles of a %s volume" % (tuple(tiles.shape), t, tuple(out.shape)))
+    L.check(L.load().ru_tile_scatter(L.f32(tiles), L.f32(out), n, c, d, h, w, t, _ints([v for o in origins for v in o]), td, th, tw,
+                                     _ints(border), _ints(center), L.stream()), "ru_tile_scatter")
+    return out
+
+
+def case_bbox(image):
+    """test.py:47-49 on the device: per modality {min z, y, x, max z, y, x} of the non-zero voxels -> int64 numpy [C,6] (one small copy to
+    the host: the crop extents fix the shapes of everything downstream); all-zero modality: {-1,-1,-1, 0,0,0} as loader_helper.bbox3."""
+    image = _prep(image)
+    c, d, h, w = (int(v) for v in image.shape)
+    box = torch.empty((c, 6), dtype=torch.int32, device=image.device)
+    L.check(L.load().ru_case_bbox(L.f32(image), L.ptr(box), c, d, h, w, L.stream()), "ru_case_bbox")
+    b = box.cpu().numpy().astype("int64")
+    empty = b[:, 3] < 0
+    b[empty, :3] = -1
+    b[empty, 3:] = 0
+    return b
+
+
+def case_stats(image, lo, size):
+    """float64 device tensor [C,3] = count(x > 0), sum x, sum x^2 over the crop box (test.py:103-111)."""
+    image = _prep(image)
+    c, d, h, w = (int(v) for v in image.shape)
+    lib = L.load()
+    stats = torch.empty((c, 3), dtype=torch.float64, device=image.device)
+    ws = L.workspace(lib.ru_case_workspace_bytes(c, d, h, w), image.device)
+    L.check(lib.ru_case_stats(L.f32(image), L.ptr(stats), c, d, h, w, _ints(lo), _ints(size), L.ptr(ws), ws.numel(), L.stream()), "ru_case_stats")
+    return stats
+
+
+def case_prepare(image, stats, lo, size, pad_left, padded, flip_axes):
+    """[K,C,*padded] = the K test-time flips of the crop, zero-padded and z-scored (test.py:85-120) -- the batch the network takes."""
+    image = _prep(image)
+    c, d, h, w = (int(v) for v in image.shape)
+    k = len(flip_axes)
+    batch = torch.empty((k, c) + tuple(int(v) for v in padded), dtype=torch.float32, device=image.device)
+    L.check(L.load().ru_case_prepare(L.f32(image), L.ptr(stats), L.f32(batch), c, d, h, w, _ints(lo), _ints(size), _ints(pad_left), _ints(padded),
+                                     k, _flip_bits(flip_axes), L.stream()), "ru_case_prepare")
+    return batch
+
+
+def tta_merge_box(probs, flip_axes, lo, size, want_mean=False):
+    """tta_merge restricted to the box [lo, lo+size) of the padded prediction (test.py:134-144 with the padding removed):
+    (mask uint8 [C,*size], counts int64 [C], mean or None)."""
+    probs = _prep(probs)
+    k, c, d, h, w = [int(v) for v in probs.shape]
+    size = tuple(int(v) for v in size)
+    mask = torch.empty((c,) + size, dtype=torch.uint8, device=probs.device)
+    counts = torch.empty(c, dtype=torch.int64, device=probs.device)
+    mean = torch.empty((c,) + size, dtype=torch.float32, device=probs.device) if want_mean else None
+    L.check(L.load().ru_tta_merge_box(L.f32(probs), k, _flip_bits(flip_axes), L.ptr(mean, True), L.ptr(mask), L.ptr(counts), c, d, h, w,
+                                      _ints(lo), _ints(size), L.stream()), "ru_tta_merge_box")
+    return mask, counts, mean
+
+
+def cc_reject(labels, ratio=0.1):
+    """test.py:162-164 in place on a uint8 device label volume [D,H,W]: 26-connected components of labels > 0, components smaller than
+    ratio * (voxels - most frequent label's voxels) are zeroed (test.py:51-62)."""
+    if not (labels.is_cuda and labels.is_contiguous() and labels.dtype == torch.uint8 and labels.dim() == 3):
+        raise ValueError("cc_reject: contiguous uint8 device tensor [D,H,W]")
+    d, h, w = (int(v) for v in labels.shape)
+    lib = L.load()
+    ws = L.workspace(lib.ru_cc_workspace_bytes(d, h, w), labels.device)
+    L.check(lib.ru_cc_reject(L.ptr(labels), d, h, w, float(ratio), L.ptr(ws), ws.numel(), L.stream()), "ru_cc_reject")
+    return labels
+
+
+def paste_labels(lab, full_shape, lo):
+    """test.py:167-168: uint8 device volume `full_shape`, zero except the box at `lo`, which holds `lab`."""
+    if not (lab.is_cuda and lab.is_contiguous() and lab.dtype == torch.uint8 and lab.dim() == 3):
+        raise ValueError("paste_labels: contiguous uint8 device tensor [d,h,w]")
+    full = torch.empty(tuple(int(v) for v in full_shape), dtype=torch.uint8, device=lab.device)
+    d, h, w = (int(v) for v in full.shape)
+    L.check(L.load().ru_paste_labels(L.ptr(lab), L.ptr(full), d, h, w, _ints(lo), _ints(lab.shape), L.stream()), "ru_paste_labels")
+    return full
+
+
 def dice_counts(pred, target):
     """metrics.Dice.update counting step (metrics.py:116-127): int64 device tensor [N,C,2] = (#(p>.5 & g>.5), #(p>.5) + #(g>.5))."""
     pred, target = _prep(pred), _prep(target)

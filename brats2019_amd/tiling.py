@@ -1,11 +1,14 @@
-"""Sliding-window helpers with the semantics of loader_helper.py:34-97 (`get_indices`, `copy`, `copy_back`),
-kept on whatever device the tensors live on (torch slicing = device memory plumbing; no host round trips,
-unlike the reference's per-tile .cuda()/.cpu(), train.py:165-171)."""
+"""Sliding-window helpers with the semantics of loader_helper.py:34-97 (`get_indices`, `copy`, `copy_back`) as device kernels:
+`copy_tiles` cuts T zero-padded tiles straight into the batch tensor of one forward (ru_tile_gather), `copy_back_tiles` pastes their
+centre blocks (ru_tile_scatter) -- one launch each per batch of tiles, no host round trips (the reference does .cuda()/.cpu() per tile,
+train.py:165-171) and no per-tile slice copies.  `copy` / `copy_back` keep the reference's single-tile signatures on top of them."""
 from __future__ import annotations
 
 import math
 
 import torch
+
+from . import ops
 
 
 def get_indices(position, center_shape, border):
@@ -15,27 +18,26 @@ def get_indices(position, center_shape, border):
     return lo, hi
 
 
+def copy_tiles(data, tile_shape, index_mins):
+    """T tiles of `data` [N,C,D,H,W] in one launch -> [T*N, C, *tile_shape] (rows t*N .. t*N+N-1 = tile t, i.e. torch.cat of the
+    reference's per-tile `copy` results along the batch axis)."""
+    return ops.tile_gather(data, tile_shape, [tuple(int(v) for v in lo) for lo in index_mins])
+
+
+def copy_back_tiles(data, tiles, center_shape, index_mins, border):
+    """paste the centre blocks of T tiles (layout of `copy_tiles`) into `data` in place, clipped at the volume end."""
+    return ops.tile_scatter(data, tiles, [tuple(int(v) for v in lo) for lo in index_mins], border, center_shape)
+
+
 def copy(data, tile_shape, index_min, index_max):
     """loader_helper.py:42-60: zero-padded extract data[:, :, min:max] -> [N,C,*tile_shape]."""
-    tile = torch.zeros(tuple(data.shape[:2]) + tuple(tile_shape), dtype=torch.float32, device=data.device)
-    src, dst = [], []
-    for a in range(3):
-        lo, hi = max(int(index_min[a]), 0), min(int(index_max[a]), int(data.shape[2 + a]))
-        src.append(slice(lo, hi))
-        dst.append(slice(lo - int(index_min[a]), hi - int(index_min[a])))
-    tile[:, :, dst[0], dst[1], dst[2]] = data[:, :, src[0], src[1], src[2]]
-    return tile
+    assert all(int(b) - int(a) == int(t) for a, b, t in zip(index_min, index_max, tile_shape))
+    return copy_tiles(data, tile_shape, [index_min])
 
 
 def copy_back(data, tile, center_shape, index_min, index_max, border):
     """loader_helper.py:82-97: paste the tile's centre block into `data`, clipped at the volume end."""
-    src, dst = [], []
-    for a in range(3):
-        lo = int(index_min[a]) + int(border[a])
-        hi = min(int(index_max[a]) - int(border[a]), int(data.shape[2 + a]))
-        dst.append(slice(lo, hi))
-        src.append(slice(int(border[a]), int(border[a]) + (hi - lo)))
-    data[:, :, dst[0], dst[1], dst[2]] = tile[:, :, src[0], src[1], src[2]].to(data.device)
+    copy_back_tiles(data, tile.to(data.device), center_shape, [index_min], border)
 
 
 def grid_for(shape, center_shape):

@@ -288,6 +288,7 @@ class Trainer(object):
         self.model.eval()
         if batch_tiles is None:
             batch_tiles = self._auto_batch_tiles(tile_shape, int(inp.shape[0]))
+        inp = inp.contiguous().float()
         output = torch.zeros(output_shape, dtype=torch.float32, device=inp.device)
         grid = tiling.grid_for(inp.shape[2:], center_shape)
         positions = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
@@ -295,11 +296,10 @@ class Trainer(object):
         with torch.no_grad():
             for s0 in range(0, len(positions), max(1, int(batch_tiles))):
                 chunk = positions[s0:s0 + max(1, int(batch_tiles))]
-                idx = [tiling.get_indices(pos, center_shape, border) for pos in chunk]
-                tiles = torch.cat([tiling.copy(inp, tile_shape, lo, hi) for lo, hi in idx], dim=0)
+                los = [tiling.get_indices(pos, center_shape, border)[0] for pos in chunk]
+                tiles = tiling.copy_tiles(inp, tile_shape, los)                  # one gather launch straight into the batch tensor
                 out = self.model([tiles])[0]
-                for t, (lo, hi) in enumerate(idx):
-                    tiling.copy_back(output, out[t * nvol:(t + 1) * nvol], center_shape, lo, hi, border)
+                tiling.copy_back_tiles(output, out, center_shape, los, border)   # one scatter launch
         return [output.cpu()]
 
     def _evaluate_and_save(self, loader, split_into_tiles, val_metrics, track_metric, results, epoch, comparator):

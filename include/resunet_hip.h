@@ -239,6 +239,40 @@ int ru_tta_merge(const float* probs, int K, unsigned flips, float* mean_out, uns
 int ru_compose_labels(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels,
                       size_t V, ru_stream_t stream);
 
+/* ---------------------------------------------------------------- inference driver on the device (csrc/inference.hip)
+ * Sliding window (loader_helper.py:34-97, train.py:158-174).  `origins` = T x 3 HOST ints, index_min of each tile (get_indices: centre
+ * block position * centre - border; may be negative).  ru_tile_gather is loader_helper.copy for T tiles in one launch: tiles
+ * [(t*N + n), C, td, th, tw] = data[n, :, origin + (z, y, x)], zero outside the volume (tw % 4 == 0).  ru_tile_scatter is
+ * loader_helper.copy_back: the centre block [border, border + center) of every tile is pasted at origin + border, clipped at the end
+ * of the volume.  Centre blocks of different tiles do not overlap, so the order of the tiles does not matter.  */
+int ru_tile_gather(const float* data, float* tiles, int N, int C, int D, int H, int W, int T, const int* origins,
+                   int td, int th, int tw, ru_stream_t stream);
+int ru_tile_scatter(const float* tiles, float* out, int N, int C, int D, int H, int W, int T, const int* origins,
+                    int td, int th, int tw, const int* border, const int* center, ru_stream_t stream);
+/* Case preparation (test.py:47-49,85-120).  ru_case_bbox: box[c*6 .. c*6+5] (DEVICE ints) = {min z, y, x, max z, y, x} of the non-zero
+ * voxels of modality c of image [C][D][H][W]; {INT_MAX x3, -1 x3} for an all-zero modality (the host applies test.py:47-49's union and
+ * its rule for empty modalities).  ru_case_stats: per channel over the crop box [lo, lo + size): stats[c*3..] = count(x > 0), sum x,
+ * sum x^2 (float64, DEVICE).  ru_case_prepare: batch [K][C][padded] = the K test-time flips (3 bits per copy, bit0 D, bit1 H, bit2 W,
+ * as ru_tta_merge) of the crop zero-padded by pad_left to `padded` and z-scored with the moments in `stats` -- every voxel,
+ * padding included, (x - mean) / std in float64 as the reference's numpy does (test.py:103-113).  lo / size / pad_left / padded: HOST.  */
+int ru_case_bbox(const float* image, int* box, int C, int D, int H, int W, ru_stream_t stream);
+size_t ru_case_workspace_bytes(int C, int D, int H, int W);
+int ru_case_stats(const float* image, double* stats, int C, int D, int H, int W, const int* lo, const int* size,
+                  void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_case_prepare(const float* image, const double* stats, float* batch, int C, int D, int H, int W, const int* lo, const int* size,
+                    const int* pad_left, const int* padded, int K, unsigned flips, ru_stream_t stream);
+/* ru_tta_merge restricted to the box [lo, lo + size) of the padded prediction (test.py:140-144 removes the padding before the masks are
+ * counted): mean_out / mask are [C][size], counts[C] the voxels set inside the box.  */
+int ru_tta_merge_box(const float* probs, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts,
+                     int C, int D, int H, int W, const int* lo, const int* size, ru_stream_t stream);
+/* Post-processing (test.py:51-62,162-164): 26-connected components of labels > 0 by union-find on the device, every component smaller
+ * than ratio * (V - size of the most frequent label, background included) is zeroed in place.  Only component sizes enter the rule, so
+ * the result equals skimage.morphology.label + reject_small_regions whatever the numbering.  ru_paste_labels (test.py:167-168):
+ * full [D][H][W] = 0 outside the box, lab [size] inside.  */
+size_t ru_cc_workspace_bytes(int D, int H, int W);
+int ru_cc_reject(unsigned char* labels, int D, int H, int W, double ratio, void* ws, size_t ws_bytes, ru_stream_t stream);
+int ru_paste_labels(const unsigned char* lab, unsigned char* full, int D, int H, int W, const int* lo, const int* size, ru_stream_t stream);
+
 /* ---------------------------------------------------------------- voxel-major working layout ("C16")
  * Between the first and the last convolution the split-bf16 engine keeps activations as [N][C/16][D][H][W][16]
  * (16 channels of a voxel contiguous; C % 16 == 0): a halo tile of a 3x3x3 convolution is then a few long contiguous

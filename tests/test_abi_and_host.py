@@ -139,20 +139,7 @@ def test_tiling_helpers_match_reference(golden):
                 lo, hi = tiling.get_indices((i, j, k), g["center"], g["border"])
                 assert lo == list(g["index_min"][idx]) and hi == list(g["index_max"][idx])
                 idx += 1
-    data = T(g["small_data"])
-    res = torch.zeros_like(data)
-    c, b, tl = (8, 8, 8), (4, 4, 4), (16, 16, 16)
-    g2 = tiling.grid_for(data.shape[2:], c)
-    n = 0
-    for i in range(g2[0]):
-        for j in range(g2[1]):
-            for k in range(g2[2]):
-                lo, hi = tiling.get_indices((i, j, k), c, b)
-                tile = tiling.copy(data, tl, lo, hi)
-                assert np.array_equal(tile.numpy(), g["small_tiles"][n])
-                tiling.copy_back(res, tile, c, lo, hi, b)
-                n += 1
-    assert np.array_equal(res.numpy(), g["small_result"])
+    # (the tile extract / centre paste themselves are device kernels: tests/test_inference.py::test_tile_gather_scatter_match_reference)
 
 
 def test_shard_assignment():

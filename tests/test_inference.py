@@ -201,3 +201,135 @@ def test_sliding_window_240x240x155_matches_reference_fixture(golden, tmp_path, 
     assert int(diff.sum()) <= (int(g["near_half_1e_3"]) if band >= 1e-3 else int(g["near_half_1e_5"]) + 8)
     d = O.dice_metric(mask.astype(np.float32), ref_mask.astype(np.float32))    # metrics.Dice yardstick (BASELINE.json "Dice vs reference")
     assert (d > 1.0 - 1e-4).all()
+
+
+# ---------------------------------------------------------------------- device kernels of the inference driver (csrc/inference.hip)
+@pytest.mark.gpu
+def test_tile_gather_scatter_match_reference(golden):
+    """ru_tile_gather / ru_tile_scatter against the tiles and the pasted result the REFERENCE's loader_helper.copy / copy_back produced
+    (tests/golden/tiling.npz), one tile at a time through the reference-named wrappers and all tiles of the volume in ONE launch each."""
+    from brats2019_amd import tiling
+    g = golden("tiling")
+    data = T(g["small_data"]).cuda()
+    c, b, tl = (8, 8, 8), (4, 4, 4), (16, 16, 16)
+    g2 = tiling.grid_for(data.shape[2:], c)
+    res = torch.zeros_like(data)
+    los, n = [], 0
+    for i in range(g2[0]):
+        for j in range(g2[1]):
+            for k in range(g2[2]):
+                lo, hi = tiling.get_indices((i, j, k), c, b)
+                tile = tiling.copy(data, tl, lo, hi)
+                assert np.array_equal(tile.cpu().numpy(), g["small_tiles"][n])
+                tiling.copy_back(res, tile, c, lo, hi, b)
+                los.append(lo)
+                n += 1
+    assert np.array_equal(res.cpu().numpy(), g["small_result"])
+    tiles = tiling.copy_tiles(data, tl, los)
+    nvol = int(data.shape[0])
+    assert np.array_equal(tiles.cpu().numpy().reshape((n, nvol) + tuple(tiles.shape[1:])), np.stack(g["small_tiles"][:n]).reshape((n, nvol) + tuple(tiles.shape[1:])))
+    res2 = torch.zeros_like(data)
+    tiling.copy_back_tiles(res2, tiles, c, los, b)
+    assert np.array_equal(res2.cpu().numpy(), g["small_result"])
+
+
+@pytest.mark.gpu
+def test_tile_kernels_ragged_volume_vs_oracle():
+    """odd extents (21 x 19 x 13, two volumes, three channels), 70 tiles (more than one launch holds): bit-exact vs the oracle's tiling"""
+    from brats2019_amd import tiling
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((2, 3, 21, 19, 13)).astype(np.float32)
+    tile, centre, border = (8, 8, 8), (4, 4, 4), (2, 2, 2)
+    grid = tiling.grid_for(vol.shape[2:], centre)
+    pos = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
+    assert len(pos) > 64
+    los = [tiling.get_indices(p, centre, border)[0] for p in pos]
+    tiles = tiling.copy_tiles(T(vol).cuda(), tile, los)
+    want = np.concatenate([O.tile_copy(vol, tile, *O.tile_indices(p, centre, border)) for p in pos], axis=0)
+    assert np.array_equal(tiles.cpu().numpy(), want)
+    out = torch.full((2, 3, 21, 19, 13), -7.0, device="cuda")
+    tiling.copy_back_tiles(out, tiles, centre, los, border)
+    ref = np.full((2, 3, 21, 19, 13), -7.0, np.float32)
+    for t, p in enumerate(pos):
+        lo, hi = O.tile_indices(p, centre, border)
+        O.tile_copy_back(ref, want[2 * t:2 * t + 2], centre, lo, hi, border)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(ref, vol)                       # the centre blocks tile the volume exactly once
+
+
+@pytest.mark.gpu
+def test_case_preparation_on_device_matches_host_restatement(golden):
+    """bbox / crop / pad / z-score / the four flips on the device (ru_case_bbox, ru_case_stats, ru_case_prepare) against the numpy
+    restatement of test.py:85-120 (pinned to the reference's helpers by test_oracle_helpers_match_reference)."""
+    from brats2019_amd import inference as I, ops
+    rng = np.random.default_rng(8)
+    img = np.zeros((4, 40, 44, 37), np.float32)
+    img[:, 4:33, 6:39, 3:30] = rng.random((4, 29, 33, 27)).astype(np.float32) * 3 - 0.4       # negative values too: counted only when > 0
+    img[1, 2, 41, 35] = 5.0                                                                     # one modality widens the union box
+    for image in (g_img for g_img in (img, golden("inference")["img"].astype(np.float32))):
+        dev = T(np.ascontiguousarray(image)).cuda()
+        boxes = ops.case_bbox(dev)
+        want_boxes = np.stack([np.concatenate(list(O.bbox3(d))) for d in image])
+        assert np.array_equal(boxes, want_boxes)
+        x, bbox, left, right = I.prepare_case(image)
+        batch, lo, size, pl, padded = I.prepare_case_device(dev)
+        assert np.array_equal(lo, bbox[0]) and np.array_equal(lo + size, bbox[1]) and np.array_equal(pl, left) and tuple(padded) == x.shape[1:]
+        stats = ops.case_stats(dev, lo, size).cpu().numpy()
+        crop = image[:, bbox[0, 0]:bbox[1, 0], bbox[0, 1]:bbox[1, 1], bbox[0, 2]:bbox[1, 2]].astype(np.float64)
+        assert np.array_equal(stats[:, 0], (crop > 0).sum(axis=(1, 2, 3)))
+        np.testing.assert_allclose(stats[:, 1], crop.sum(axis=(1, 2, 3)), rtol=1e-12)
+        np.testing.assert_allclose(stats[:, 2], (crop ** 2).sum(axis=(1, 2, 3)), rtol=1e-12)
+        got = batch.cpu().numpy()
+        for k, xi in enumerate(O.tta_inputs(x)):
+            np.testing.assert_allclose(got[k], xi, rtol=0, atol=1e-6, err_msg="flip %d" % k)
+        assert (got[0] != x).mean() < 1e-3                  # float64 moments summed in another order: a last-bit difference is rare
+
+
+@pytest.mark.gpu
+def test_tta_merge_box_equals_merge_then_crop():
+    from brats2019_amd import ops
+    rng = np.random.default_rng(4)
+    probs = torch.from_numpy(rng.random((4, 3, 16, 24, 20)).astype(np.float32)).cuda()
+    mask, counts, mean = ops.tta_merge(probs, O.TTA_FLIPS, want_mean=True)
+    lo, size = (1, 4, 3), (13, 17, 15)
+    mb, cb, meanb = ops.tta_merge_box(probs, O.TTA_FLIPS, lo, size, want_mean=True)
+    sl = (slice(None),) + tuple(slice(a, a + s) for a, s in zip(lo, size))
+    assert torch.equal(mb, mask[sl]) and torch.equal(meanb, mean[sl])
+    assert cb.tolist() == mask[sl].sum(dim=(1, 2, 3)).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,density", [((37, 41, 29), 0.03), ((37, 41, 29), 0.08), ((37, 41, 29), 0.2), ((96, 100, 80), 0.06),
+                                           ((30, 30, 30), 0.9), ((155, 240, 240), 0.04)])
+def test_component_rejection_on_device_bit_exact(shape, density):
+    """ru_cc_reject (union-find on the device) against scipy's 26-connected labelling + test.py:51-62, bit for bit: sparse noise (thousands of
+    small components), densities around the percolation threshold (one giant component beside many small ones), a foreground larger than
+    the background (counts.max() is then a COMPONENT, test.py:55), and one BraTS-native 155 x 240 x 240 volume."""
+    from brats2019_amd import inference as I, ops
+    rng = np.random.default_rng(hash((shape, density)) % (2 ** 31))
+    u = rng.random(shape)
+    lab = np.where(u < density, rng.choice(np.array([1, 2, 4], np.uint8), size=shape), 0).astype(np.uint8)
+    if shape[0] == 155:                                    # blobs: a few large regions + noise, like a real prediction
+        zz, yy, xx = np.ogrid[:shape[0], :shape[1], :shape[2]]
+        for cz, cy, cx, r in ((70, 120, 100, 30), (40, 60, 180, 9), (120, 200, 60, 5)):
+            lab[(zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = 2
+    want = I.postprocess_labels(lab)
+    got = ops.cc_reject(T(lab.copy()).cuda(), 0.1).cpu().numpy()
+    assert np.array_equal(got, want), "%d voxels differ" % int((got != want).sum())
+    assert (want != lab).any() or density >= 0.9           # the rule removed something (except in the all-foreground case)
+
+
+@pytest.mark.gpu
+def test_component_rejection_edge_cases_and_paste():
+    from brats2019_amd import inference as I, ops
+    for lab in (np.zeros((9, 8, 12), np.uint8), np.full((9, 8, 12), 2, np.uint8)):
+        assert np.array_equal(ops.cc_reject(T(lab.copy()).cuda()).cpu().numpy(), I.postprocess_labels(lab))
+    lab = np.zeros((6, 6, 6), np.uint8)
+    lab[0, 0, 0] = 1; lab[1, 1, 1] = 1; lab[2, 2, 2] = 4            # diagonal chain: ONE component under 26-connectivity
+    lab[5, 5, 5] = 2                                                  # isolated voxel: 1 of 4 foreground voxels >= 0.1 * 4 -> stays
+    assert np.array_equal(ops.cc_reject(T(lab.copy()).cuda()).cpu().numpy(), I.postprocess_labels(lab))
+    small = T(np.arange(2 * 3 * 4, dtype=np.uint8).reshape(2, 3, 4)).cuda()
+    full = ops.paste_labels(small, (5, 6, 7), (1, 2, 3)).cpu().numpy()
+    want = np.zeros((5, 6, 7), np.uint8)
+    want[1:3, 2:5, 3:7] = small.cpu().numpy()
+    assert np.array_equal(full, want)
