@@ -302,7 +302,8 @@ def trainer_step_probe(backend, flat, x, g, steps, warmup=2):
         for (name, p), (_n, v) in zip(net.named_parameters(), backend.engine.layout.views(flat).items()):
             assert name == _n
             p.copy_(v)
-    with tempfile.TemporaryDirectory() as root:
+    import contextlib
+    with tempfile.TemporaryDirectory() as root, contextlib.redirect_stdout(sys.stderr):      # (the loop prints its epoch metrics: stdout carries ONE JSON line)
         tr = TR.Trainer(name="bench", models_root=root, model=net, rewrite=True, connect_tb=False)
         criterion = [LS.Dice_loss_joint(index=0, priority=1), LS.BCE_Loss(index=0, bg_weight=1e-2)]
         opt, sched = tr._make_optimizer(torch.optim.Adam, {"lr": 2e-5, "weight_decay": 1e-6, "amsgrad": True},

@@ -248,8 +248,10 @@ class DataParallelStep:
 def all_reduce_coalesced(tensors, group=None):
     """SUM all-reduce of several tensors as one coalesced collective (ProcessGroup.allreduce_coalesced: one ncclGroup'd launch on RCCL,
     one flattened ring on gloo); every rank must pass the same number of tensors of the same sizes."""
-    if len(tensors) == 1:
-        dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=group)
+    if len(tensors) == 1 or (tensors[0].is_cuda and dist.get_backend(group) == "gloo"):
+        # (ProcessGroupGloo has no coalesced all-reduce for device tensors -- the shared-GPU plumbing tests: one collective per run)
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return
     with dist._coalescing_manager(group=group):
         for t in tensors:
