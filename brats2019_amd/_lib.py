@@ -57,6 +57,7 @@ SIGNATURES = {
     "ru_unet_set_fusion": (_i, [_vp, C.c_uint]),
     "ru_unet_probe": (_i, [_vp, _i]),
     "ru_unet_probe_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i)]),
+    "ru_unet_probe_read_families": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_i), _i]),
     "ru_unet_param_count": (_i, [_vp]),
     "ru_unet_param_name": (C.c_char_p, [_vp, _i]),
     "ru_unet_param_ndim": (_i, [_vp, _i]),

@@ -12,6 +12,7 @@
 // i.e. the GroupNorm-apply + LeakyReLU between the two convolutions never touches HBM.
 #include "ru_common.h"
 
+#include <vector>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -79,11 +80,51 @@ static int trace_sync(const char* what, hipStream_t s) {
     return RU_OK;
 }
 
+// ru_unet_probe(h, 2): every launch of the executor is bracketed by a HIP event pair on the launch stream and booked to a kernel FAMILY
+// (bench.py's `roofline_families`): the family follows from the launcher's name, the level (16-channel level or deeper) from a hint the
+// block walkers set.  Thread-local: the sink of the handle whose ru_unet_forward / ru_unet_backward is executing on this thread.
+enum { FAM_CONV_L0 = 0, FAM_CONV_DEEP, FAM_WGRAD_L0, FAM_WGRAD_DEEP, FAM_GN, FAM_PW, FAM_OTHER, FAM_COUNT };
+struct FamilySink {
+    std::vector<hipEvent_t> ev;            // pairs, reused
+    std::vector<int> fam;                  // family of pair i
+    size_t used = 0;
+    ~FamilySink() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+static thread_local FamilySink* t_sink = nullptr;
+static thread_local int t_hint_c = 16;     // channel count of the level being walked (conv / weight-gradient family split)
+static int family_of(const char* call) {
+    auto has = [&](const char* k) { return strstr(call, k) != nullptr; };
+    if (has("wgrad3_launch")) return t_hint_c <= 16 ? FAM_WGRAD_L0 : FAM_WGRAD_DEEP;
+    if (has("conv3_launch") || has("conv3_sb_launch")) return t_hint_c <= 16 ? FAM_CONV_L0 : FAM_CONV_DEEP;
+    if (has("gn_")) return FAM_GN;
+    if (has("conv1_") || has("wgrad1_launch") || has("up2_") || has("s2d_launch") || has("d2s_launch") || has("lrelu_bwd_launch")) return FAM_PW;
+    return FAM_OTHER;
+}
+static void sink_begin(const char* call, hipStream_t s) {
+    FamilySink& k = *t_sink;
+    while (k.ev.size() < k.used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        k.ev.push_back(e);
+    }
+    if (k.fam.size() < k.ev.size() / 2) k.fam.resize(k.ev.size() / 2);
+    k.fam[k.used / 2] = family_of(call);
+    (void)hipEventRecord(k.ev[k.used], s);
+}
+static void sink_end(hipStream_t s) {
+    FamilySink& k = *t_sink;
+    if (k.ev.size() < k.used + 2) return;
+    (void)hipEventRecord(k.ev[k.used + 1], s);
+    k.used += 2;
+}
+
 #define RU_RUN(call)                      \
     do {                                  \
         if (!A.dry) {                     \
             if (A.failed) { set_error("workspace too small"); return RU_ENOMEM; } \
+            if (t_sink) sink_begin(#call, s); \
             const int rc__ = (call);      \
+            if (t_sink) sink_end(s);      \
             if (rc__ != RU_OK) return rc__; \
             if (trace_on()) { const int rt__ = trace_sync(#call, s); if (rt__ != RU_OK) return rt__; } \
         }                                 \
@@ -190,9 +231,11 @@ struct ru_unet {
     std::vector<GNSave> gn_order;
     // ru_unet_probe: HIP event pairs around the launches of the dominant kernel (3x3x3 conv 16->16 at the input resolution, forward)
     bool probe_on = false;
+    bool probe_families = false;           // ru_unet_probe(h, 2): every launch, booked per kernel family
+    ru::FamilySink* sink = nullptr;        // (owned; created on demand)
     std::vector<hipEvent_t> probe_ev;      // pairs (begin, end), created on demand, reused
     size_t probe_used = 0;                 // events recorded since the last read
-    ~ru_unet() { for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e); }
+    ~ru_unet() { for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e); delete sink; }
 };
 
 static int add_param(ru_unet* h, const std::string& name, std::initializer_list<int> dims, bool dead = false) {
@@ -321,8 +364,28 @@ extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
 }
 extern "C" int ru_unet_probe(ru_unet_t h, int enable) {
     RU_REQUIRE(h, "ru_unet_probe: null handle");
-    h->probe_on = enable != 0;
+    h->probe_on = enable == 1;
+    h->probe_families = enable == 2;
     h->probe_used = 0;
+    if (h->probe_families && !h->sink) h->sink = new ru::FamilySink();
+    if (h->sink) h->sink->used = 0;
+    return RU_OK;
+}
+extern "C" int ru_unet_probe_read_families(ru_unet_t h, double* ms, int* launches, int nfam) {
+    RU_REQUIRE(h && ms && launches && nfam == ru::FAM_COUNT, "ru_unet_probe_read_families: %d families", (int)ru::FAM_COUNT);
+    for (int f = 0; f < nfam; ++f) { ms[f] = 0.0; launches[f] = 0; }
+    if (!h->sink) return RU_OK;
+    ru::FamilySink& k = *h->sink;
+    for (size_t i = 0; i + 1 < k.used; i += 2) {
+        hipError_t e = hipEventSynchronize(k.ev[i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(family probe)");
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, k.ev[i], k.ev[i + 1]);
+        if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(family probe)");
+        ms[k.fam[i / 2]] += t;
+        launches[k.fam[i / 2]] += 1;
+    }
+    k.used = 0;
     return RU_OK;
 }
 extern "C" int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches) {
@@ -409,6 +472,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
                     const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W, bool x_c16 = true,
                     bool x_c4 = false) {
     const int nblk = h->c16 ? conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
+    t_hint_c = Cout;
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
     out_gn.mean = A.alloc_keep((size_t)N * kGroups);
     out_gn.rstd = A.alloc_keep((size_t)N * kGroups);
@@ -619,6 +683,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     }
     // head: conv_output + bias + sigmoid (model.py:429-431)
     h->head_in = cur;
+    t_hint_c = C0;
     // training: the sigmoid backward reads the probabilities from the CALLER's buffer (kept valid until ru_unet_backward, see the header)
     float* pdst = probs_out;
     h->probs = probs_out;
@@ -730,6 +795,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (joined) *joined = false;
     const BlockP& bp = *sv.bp;
     const int N = sv.N, C = sv.C, D = sv.D, H = sv.H, W = sv.W;
+    t_hint_c = C;
     const size_t V = (size_t)D * H * W;
     float* dy2 = A.alloc((size_t)N * C * V);
     const bool c16 = h->c16;
@@ -816,6 +882,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
     auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
     const int C0 = h->ch[0];
+    t_hint_c = C0;
     RU_RUN(fill_launch(grads, 0.f, h->total, s));     // dead parameters keep zero gradient
     // head
     const bool c16 = h->c16;
@@ -961,6 +1028,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         pfirst = nx.part; nfirst = nx.nblk;
     }
     // norm_input (no activation: slope 1) and conv_input
+    t_hint_c = C0;
     float* dy0 = A.alloc((size_t)N * C0 * Vl(0));
     // voxel-major engine, no d/d(input) wanted: the gradient w.r.t. the stem conv's output is consumed by the stem's weight gradient alone, so
     // the GroupNorm-backward apply of norm_input is computed in that kernel's staging (wgrad3_tz<1,1,3>) and never written
@@ -1007,6 +1075,7 @@ extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int 
     ru_unet tmp = *h;            // dry walk on a copy: does not disturb a live forward state
     tmp.probe_ev.clear();        // (the copy must not own the handle's HIP events: its destructor would destroy them)
     tmp.probe_on = false;
+    tmp.sink = nullptr;
     tmp.N = N; tmp.D = D; tmp.H = H; tmp.W = W; tmp.training = training != 0;
     Arena A;
     A.dry = true;
@@ -1027,7 +1096,9 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     h->ws = (char*)ws; h->ws_bytes = ws_bytes;
     Arena A;
     A.dry = false; A.base = (char*)ws; A.cap = ws_bytes;
+    ru::t_sink = h->probe_families ? h->sink : nullptr;
     rc = unet_forward_impl(h, params, x, probs, A, (hipStream_t)stream);
+    ru::t_sink = nullptr;
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_forward: workspace too small (%zu bytes given)", ws_bytes); return RU_ENOMEM; }
     h->fwd_end = A.off;
@@ -1041,7 +1112,9 @@ extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* d
     if (!h->have_fwd || !h->training) { set_error("ru_unet_backward: needs a preceding training-mode ru_unet_forward"); return RU_ESTATE; }
     Arena A;
     A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end; A.keep = h->fwd_keep;
+    ru::t_sink = h->probe_families ? h->sink : nullptr;
     int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream);
+    ru::t_sink = nullptr;
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_backward: workspace too small"); return RU_ENOMEM; }
     return RU_OK;

@@ -92,9 +92,20 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
         self._ws_key = None                    # the backward's workspace layout depends on it
 
+    FAMILIES = ("conv3_l0", "conv3_deep", "wgrad3_l0", "wgrad3_deep", "groupnorm", "pointwise_1x1_s2_up", "other")
+
     def probe(self, enable=True):
-        """In-situ timing of the dominant kernel (ru_unet_probe): HIP event pairs around the 16->16 3x3x3 convolutions of the forward."""
-        L.check(L.load().ru_unet_probe(self.h, int(bool(enable))), "ru_unet_probe")
+        """In-situ timing (ru_unet_probe): True / 1 = HIP event pairs around the 16->16 3x3x3 convolutions of the forward (the dominant
+        kernel); 2 = around EVERY launch, booked per kernel family (probe_read_families)."""
+        L.check(L.load().ru_unet_probe(self.h, int(enable)), "ru_unet_probe")
+
+    def probe_read_families(self):
+        """-> {family: (total_ms, launches)} since the last read (ru_unet_probe_read_families); waits for the recorded events."""
+        import ctypes
+        n = len(self.FAMILIES)
+        ms, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
+        L.check(L.load().ru_unet_probe_read_families(self.h, ms, cnt, n), "ru_unet_probe_read_families")
+        return {f: (ms[i], cnt[i]) for i, f in enumerate(self.FAMILIES)}
 
     def probe_read(self):
         """-> (total_ms, launches) since the last read; waits for the recorded events (ru_unet_probe_read)."""

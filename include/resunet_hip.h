@@ -179,6 +179,14 @@ int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
  * the number of launches since the last read, and clears the record.  Off by default; costs two event records per probed launch. */
 int ru_unet_probe(ru_unet_t h, int enable);
 int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches);
+/* ru_unet_probe(h, 2): EVERY launch of ru_unet_forward / ru_unet_backward is bracketed and booked to one of RU_PROBE_FAMILIES kernel
+ * families (bench.py's `roofline_families`): 0 3x3x3 conv fwd + data gradient at the 16-channel level (stem and head included), 1 the
+ * same at the deeper levels, 2 / 3 3x3x3 weight gradients likewise, 4 GroupNorm passes (apply, backward reduce / apply, finalizes),
+ * 5 1x1 / 2x2x2 convolutions, their weight gradients and the trilinear kernels, 6 everything else (weight packing, fills, head
+ * gradient, partial-sum reductions of the weight gradients).  ms[f] = summed duration, launches[f] = count since the last read.
+ * The event records cost ~1 us per launch: use it in probe steps, not in a timed region. */
+#define RU_PROBE_FAMILIES 7
+int ru_unet_probe_read_families(ru_unet_t h, double* ms, int* launches, int nfam);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
 int ru_unet_param_ndim(ru_unet_t h, int i);
