@@ -321,12 +321,15 @@ def power_probe(fn, seconds=1.2, device_index=0):
     if not os.path.exists(smi):
         return None
     rows, limit, stop = [], [None], threading.Event()
+    # the sampler is a child process of a GPU-initialised (possibly profiled) process: it gets an environment without the profiler's
+    # preload / tool variables, so that nothing initialises the GPU inside it before its own interpreter starts
+    env = {k: v for k, v in os.environ.items() if not (k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "ROCPROFILER")))}
 
     def sampler():
         while not stop.is_set():
             try:
                 d = json.loads(subprocess.run([smi, "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower", "--json"],
-                                              capture_output=True, text=True, timeout=5).stdout)
+                                              capture_output=True, text=True, timeout=5, env=env).stdout)
                 c = d[sorted(d.keys())[0]]
                 w = [float(v) for k, v in c.items() if "Current Socket" in k or "Average Graphics Package Power" in k]
                 clk = [int(re.sub(r"[^0-9]", "", v)) for k, v in c.items() if k.startswith("sclk clock speed")]

@@ -288,6 +288,12 @@ class Trainer(object):
         self.model.eval()
         if batch_tiles is None:
             batch_tiles = self._auto_batch_tiles(tile_shape, int(inp.shape[0]))
+            rank, world = world_info()
+            if world > 1:                      # sized from each rank's free memory: every replica takes the smallest, so all run the same kernels
+                import torch.distributed as dist
+                t = torch.tensor([int(batch_tiles)], dtype=torch.int64, device=inp.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                batch_tiles = int(t.item())
         inp = inp.contiguous().float()
         output = torch.zeros(output_shape, dtype=torch.float32, device=inp.device)
         grid = tiling.grid_for(inp.shape[2:], center_shape)
@@ -322,7 +328,16 @@ class Trainer(object):
                 val = m.get()
             _log_metric(self.tb_writer, m, "val/", epoch)
             results[m.name].append(m.get())
-        if comparator(val, self.state.best_val):                             # train.py:315-318
+        better = bool(comparator(val, self.state.best_val))                  # train.py:315-318
+        rank, world = world_info()
+        if world > 1:
+            # every rank validates the whole set on its own replica; a mask voxel on the threshold could make the ranks disagree, and
+            # `_save` contains a barrier: rank 0 decides for everybody (and its metric value is the one recorded)
+            import torch.distributed as dist
+            box = [better, val]
+            dist.broadcast_object_list(box, src=0)
+            better, val = bool(box[0]), box[1]
+        if better:
             self.state.best_val = val
             self._save(suffix="best_model")
             print("model saved")
