@@ -199,7 +199,7 @@ struct ru_unet {
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
-    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY;
+    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM;
     int grad_precision = RU_PREC_BF16X3;   // ru_unet_set_grad_precision: RU_PREC_BF16 = one MFMA product in the 3x3x3 data / weight gradients
     int grad_products() const { return (precision == RU_PREC_BF16X3 && grad_precision == RU_PREC_BF16) ? 1 : 3; }
     int wgrad_mode() const { return precision | (grad_products() == 1 ? kOneProduct : 0); }   // `mode` argument of wgrad3_run
@@ -235,7 +235,17 @@ struct ru_unet {
     ru::FamilySink* sink = nullptr;        // (owned; created on demand)
     std::vector<hipEvent_t> probe_ev;      // pairs (begin, end), created on demand, reused
     size_t probe_used = 0;                 // events recorded since the last read
-    ~ru_unet() { for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e); delete sink; }
+    // RU_FUSE_SIDE_STREAM: the 3x3x3 weight gradients of the levels below the first (nobody reads them before the optimizer) go to a second,
+    // lower-priority HIP stream, event-ordered behind the kernel that produces their dy; ru_unet_backward joins it before it returns
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_ev;       // created on demand (no timing), reused every step
+    size_t fork_used = 0;
+    ~ru_unet() {
+        for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : fork_ev) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+        delete sink;
+    }
 };
 
 static int add_param(ru_unet* h, const std::string& name, std::initializer_list<int> dims, bool dead = false) {
@@ -304,6 +314,7 @@ extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const 
         }
     }
     ru_unet* h = new ru_unet();
+    if (const char* e = getenv("RU_SIDE_STREAM")) { if (*e == '0') h->fusion &= ~(unsigned)RU_FUSE_SIDE_STREAM; }    // same-box A/B of the side stream
     h->depth = depth;
     h->nout = number_of_outputs;
     h->enc.assign(encoder_layers, encoder_layers + depth);
@@ -357,7 +368,7 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
 }
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
 extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
-    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY)) == 0, "ru_unet_set_fusion: bad argument");
+    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM)) == 0, "ru_unet_set_fusion: bad argument");
     h->fusion = mask;
     h->have_fwd = false;            // the workspace layout of the backward depends on it
     return RU_OK;
@@ -782,6 +793,44 @@ static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, 
     return RU_OK;
 }
 
+// Side stream (RU_FUSE_SIDE_STREAM).  side_fork: everything enqueued on `main` so far happens-before what is enqueued on the side stream
+// next; side_join: everything enqueued on the side stream so far happens-before what is enqueued on `main` next.  Events only, no host
+// synchronisation; the pattern (fork ... join back into the origin stream) is capturable in a hipGraph.
+static int side_event(ru_unet* h, hipEvent_t* out) {
+    if (h->fork_used == h->fork_ev.size()) {
+        hipEvent_t e;
+        const hipError_t er = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (er != hipSuccess) return hip_fail(er, "hipEventCreateWithFlags(side)");
+        h->fork_ev.push_back(e);
+    }
+    *out = h->fork_ev[h->fork_used++];
+    return RU_OK;
+}
+static int side_fork(ru_unet* h, hipStream_t main) {
+    if (!h->side) {
+        int lo = 0, hi = 0;                                      // lowest priority: the chain on `main` is the critical path
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const hipError_t er = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo);
+        if (er != hipSuccess) return hip_fail(er, "hipStreamCreateWithPriority(side)");
+    }
+    hipEvent_t e;
+    int rc = side_event(h, &e);
+    if (rc) return rc;
+    hipError_t er = hipEventRecord(e, main);
+    if (er == hipSuccess) er = hipStreamWaitEvent(h->side, e, 0);
+    return er == hipSuccess ? RU_OK : hip_fail(er, "side_fork");
+}
+static int side_join(ru_unet* h, hipStream_t main) {
+    if (!h->side || h->fork_used == 0) return RU_OK;
+    hipEvent_t e;
+    int rc = side_event(h, &e);
+    if (rc) return rc;
+    hipError_t er = hipEventRecord(e, h->side);
+    if (er == hipSuccess) er = hipStreamWaitEvent(main, e, 0);
+    h->fork_used = 0;                                            // the events are free again after this step's join
+    return er == hipSuccess ? RU_OK : hip_fail(er, "side_join");
+}
+
 // Residual backward: dout -> d(xprev); parameter gradients into `grads`
 // `join`: a second gradient arriving at the block input (the skip connection of a down block); *joined tells whether it was added here
 // part2 / nblk2: the GroupNorm-backward sums of norm2 were taken by the kernel that produced `dout` (Conv3Args::bst_*)
@@ -810,7 +859,13 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
                     fa ? &coef2 : nullptr);
     if (rc) return rc;
     const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
-    rc = wgrad3_run(A, s, h->wgrad_mode(), sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
+    // weight gradients whose dy has no other producer role (no fused apply: dy2 / dy1 are complete when gn_bwd returns) leave the chain:
+    // on the side stream they run beside the data-gradient convs and the GroupNorm passes of the chain (a 188-register weight-gradient
+    // workgroup leaves a third wave's registers free on its CU: the memory-bound passes fit beside it)
+    const bool aside = !A.dry && (h->fusion & RU_FUSE_SIDE_STREAM) && c16 && h->precision == RU_PREC_BF16X3 && !fa && !trace_on();
+    hipStream_t sw = s;
+    if (aside) { rc = side_fork(h, s); if (rc) return rc; sw = h->side; }
+    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
@@ -831,7 +886,8 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
                 fa ? &coef1 : nullptr);
     if (rc) return rc;
     const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
-    rc = wgrad3_run(A, s, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
+    if (aside) { rc = side_fork(h, s); if (rc) return rc; }
+    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
@@ -1060,6 +1116,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         di.x = dy0; di.wp = wpd; di.y = dx_in; di.N = N; di.Cin = C0; di.Cout = kInCh; di.D = Dl[0]; di.H = Hl[0]; di.W = Wl[0];
         RU_RUN(conv3_launch(di, s));
     }
+    if (!A.dry) { rc = side_join(h, s); if (rc) return rc; }     // the caller's stream sees every gradient
     return RU_OK;
 }
 
@@ -1076,6 +1133,8 @@ extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int 
     tmp.probe_ev.clear();        // (the copy must not own the handle's HIP events: its destructor would destroy them)
     tmp.probe_on = false;
     tmp.sink = nullptr;
+    tmp.side = nullptr;          // (nor its side stream / events)
+    tmp.fork_ev.clear();
     tmp.N = N; tmp.D = D; tmp.H = H; tmp.W = W; tmp.training = training != 0;
     Arena A;
     A.dry = true;

@@ -85,10 +85,10 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_grad_precision(self.h, L.GRAD_PRECISIONS[grad_precision]), "ru_unet_set_grad_precision")
         self.grad_precision = grad_precision
 
-    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True):
+    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True, side_stream=True):
         """Backward-pass fusions of the voxel-major engine (ru_unet_set_fusion; both on by default, tests switch them off to hold the
         fused kernels to the separate passes)."""
-        mask = (L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0)
+        mask = (L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0) | (L.FUSE_SIDE_STREAM if side_stream else 0)
         L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
         self._ws_key = None                    # the backward's workspace layout depends on it
 

@@ -172,6 +172,10 @@ int ru_unet_get_grad_precision(ru_unet_t h);
  *   RU_FUSE_GN_BWD_APPLY  16-channel level: the GroupNorm-backward apply is computed in the weight gradient's dy staging (no apply pass). */
 #define RU_FUSE_GN_BWD_STATS 1
 #define RU_FUSE_GN_BWD_APPLY 2
+/*   RU_FUSE_SIDE_STREAM   the 3x3x3 weight gradients below the 16-channel level run on a second (library-owned, lower-priority) HIP stream,
+ *                         event-ordered behind the kernel that produces their dy and joined before ru_unet_backward returns: same kernels,
+ *                         same arithmetic, bit-identical gradients; the memory-bound passes of the chain run in their shadow.  */
+#define RU_FUSE_SIDE_STREAM 4
 int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
 /* In-situ timing of the dominant kernel (bench.py's roofline line): while enabled, every forward brackets its launches of
  * the 3x3x3 convolution 16 -> 16 at the input resolution (voxel-major split-bf16 engine; the forward of the shipped net has four) with a

@@ -422,6 +422,26 @@ def test_fused_and_unfused_backward_agree_tightly():
     assert worst_v[0] < 2e-3, worst_v
 
 
+def test_side_stream_weight_gradients_are_bit_identical():
+    """RU_FUSE_SIDE_STREAM only moves the deep-level 3x3x3 weight gradients to a second HIP stream (event-ordered, joined before
+    ru_unet_backward returns): same kernels on the same operands -- every gradient must be bit-identical with it on and off, twice in a row
+    (the second backward reuses the events and must not race with the first)."""
+    net, _ = build_model(O.DEFAULT_CFG, 2024, "bf16x3")
+    x = T(O.make_input(2, 64, 64, 64, seed=3)).cuda()
+    w = torch.randn(2, 3, 64, 64, 64, generator=torch.Generator().manual_seed(1)).cuda() * 1e-3
+    runs = []
+    for side in (True, False, True, True):
+        net._get_engine().set_fusion(True, True, side)
+        net.zero_grad()
+        p = net([x])[0]
+        (p * w).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None})
+    for other in runs[1:]:
+        for k, v in runs[0].items():
+            assert torch.equal(v, other[k]), k
+
+
 WIDE = dict(depth=3, encoder_layers=[1, 1, 2], decoder_layers=[1, 1, 1], number_of_channels=[32, 64, 128], number_of_outputs=3)
 
 
