@@ -22,7 +22,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
   train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
   fwd          : forward-only volumes/s at batch 1 in the precision of the run (at every N: N independent replicas),
-  fwd_f32      : the same in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
+  fwd_batch    : forward-only volumes/s at the per-GPU batch of the training configuration (batch 4),
+  fwd_f32      : the batch-1 forward in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
   trainer_step : the same training step driven through the reference surface (train.Trainer._train_one_epoch set up as main.py:126-142),
   roofline_families : ms per step of every kernel family (3x3x3 conv / weight gradient at the 16-channel level and deeper, GroupNorm passes,
                  1x1 / stride-2 / up-sampling kernels) timed in place, next to the family's algorithmic FLOPs / bytes and its roofline bound.
@@ -575,6 +576,14 @@ def main():
                       "roofline_frac": round(step_roofline_ms(1, args.size, args.precision, forward_only=True) / (1e3 * dtf / it), 4)}
     if rank == 0 and world == 1 and not args.no_extras:
         backend.engine.freeze_params(True)
+        # forward throughput at the batch of the training configuration (BASELINE configs[2]: batch 4): the same kernels with the deep
+        # levels filled; `fwd` above is the batch-1 latency figure of configs[1]
+        fwdb = lambda: backend.forward(flat, x, training=False)
+        for _ in range(2):
+            fwdb()
+        dtb = time_region(fwdb, it, False)
+        out["fwd_batch"] = {"value": round(args.batch * it / dtb, 3), "unit": "volumes/s", "batch": args.batch, "ms": round(1e3 * dtb / it, 3), "precision": args.precision,
+                            "roofline_frac": round(step_roofline_ms(args.batch, args.size, args.precision, forward_only=True) / (1e3 * dtb / it), 4)}
         if args.precision != "f32":
             # BASELINE configs[1]: fp32 forward, batch 1 -- exact-f32 MFMA arithmetic, its own engine and workspace
             be32 = P.HipBackend(device=dev, precision="f32")
