@@ -941,7 +941,7 @@ int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, uns
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * C, s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counts)");
     const size_t V = (size_t)D * H * W;
-    hipLaunchKernelGGL(tta_merge_kernel, dim3(grid1d(V, 256, 4096), C), dim3(256), 0, s, p, K, flips, mean_out, mask, counts, C, D, H, W);
+    hipLaunchKernelGGL(tta_merge_kernel, dim3(grid1d(V, 256 * 8, 512), C), dim3(256), 0, s, p, K, flips, mean_out, mask, counts, C, D, H, W);
     RU_CHECK_LAUNCH("tta_merge_kernel");
     return RU_OK;
 }
@@ -1039,26 +1039,45 @@ int pad_to_c4_launch(const float* src, float* dst, int N, int C, size_t V, hipSt
 
 // ------------------------------------------------------------------ evaluation metric (metrics.py:108-133)
 // per (sample, channel): counts[row] = { sum(p>0.5 & g>0.5), sum(p>0.5) + sum(g>0.5) } as integers (order independent)
+// ONE atomic pair per workgroup and at most 64 workgroups per row: the 2 x rows counters share two cache lines, and same-line atomics
+// serialise at ~12 ns each -- the first version (one pair per WAVE of a 1024 x rows grid: 98 000 atomics) took 1.0 ms per call, 6 % of a
+// training step through Trainer (metrics.Dice is updated every iteration, train.py:224-225)
 __global__ __launch_bounds__(256) void dice_counts_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                           unsigned long long* __restrict__ counts, size_t V) {
+    __shared__ unsigned int sm[4][2];
     const size_t row = blockIdx.y;
+    const float* pp = p + row * V;
+    const float* gp = g + row * V;
     unsigned int inter = 0, uni = 0;
-    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
-        const bool a = p[row * V + v] > 0.5f, b = g[row * V + v] > 0.5f;
-        inter += (a && b) ? 1u : 0u;
-        uni += (a ? 1u : 0u) + (b ? 1u : 0u);
+    if ((V & 3) == 0) {
+        const size_t V4 = V >> 2;
+        for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V4; v += (size_t)gridDim.x * 256) {
+            const float4 a = reinterpret_cast<const float4*>(pp)[v], b = reinterpret_cast<const float4*>(gp)[v];
+            const bool a0 = a.x > 0.5f, a1 = a.y > 0.5f, a2 = a.z > 0.5f, a3 = a.w > 0.5f;
+            const bool b0 = b.x > 0.5f, b1 = b.y > 0.5f, b2 = b.z > 0.5f, b3 = b.w > 0.5f;
+            inter += (unsigned)(a0 && b0) + (unsigned)(a1 && b1) + (unsigned)(a2 && b2) + (unsigned)(a3 && b3);
+            uni += (unsigned)a0 + (unsigned)a1 + (unsigned)a2 + (unsigned)a3 + (unsigned)b0 + (unsigned)b1 + (unsigned)b2 + (unsigned)b3;
+        }
+    } else {
+        for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (size_t)gridDim.x * 256) {
+            const bool a = pp[v] > 0.5f, b = gp[v] > 0.5f;
+            inter += (a && b) ? 1u : 0u;
+            uni += (a ? 1u : 0u) + (b ? 1u : 0u);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { inter += __shfl_xor(inter, o); uni += __shfl_xor(uni, o); }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&counts[row * 2], (unsigned long long)inter);
-        atomicAdd(&counts[row * 2 + 1], (unsigned long long)uni);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = inter; sm[threadIdx.x >> 6][1] = uni; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&counts[row * 2], (unsigned long long)sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0]);
+        atomicAdd(&counts[row * 2 + 1], (unsigned long long)sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1]);
     }
 }
 int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s) {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned long long) * 2 * rows, s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(dice counts)");
-    hipLaunchKernelGGL(dice_counts_kernel, dim3(grid1d(V, 256 * 8, 1024), rows), dim3(256), 0, s, p, g, counts, V);
+    hipLaunchKernelGGL(dice_counts_kernel, dim3(grid1d(V, 256 * 4 * 8, 64), rows), dim3(256), 0, s, p, g, counts, V);
     RU_CHECK_LAUNCH("dice_counts_kernel");
     return RU_OK;
 }
