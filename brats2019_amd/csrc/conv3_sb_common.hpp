@@ -315,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
     };
 
     if (producer) {
+        if constexpr ((dbg & 65536) != 0) __builtin_amdgcn_s_setprio(3);     // devtools: static priority for the staging waves
         // ---------------------------------------------------------------- producers
         // Work items of one (tile, 16-channel chunk):
         //   interior: halo row x 4 aligned float4 segments [x0+4q, +4)  -> NROW*4 items, every lane has 4 valid voxels
@@ -604,6 +605,10 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // (917 KB of ds_read_b128 per item and CU next to 139 KB of producer writes, on a 256 B/clk array).  Same MFMAs (336), same
         // weights in registers.  Tile i is complete after row i + 2 and stored while the next rows compute (one store per row).
         static_assert(MT == TY && MT == 8 && TZ == 4, "one output plane per consumer wave");
+        // devtools bit 32768: static priority for the matrix waves (65536: for the staging waves).  Measured round 3, same box: conv probe
+        // -2..3 % at 32 / 128 channels and nothing at 16 with 32768, +10 % at the 16-channel level with 65536; the whole step does not move
+        // (16.44-16.77 vs 16.43-16.75 ms) -- not enabled.
+        if constexpr ((dbg & 32768) != 0) __builtin_amdgcn_s_setprio(3);
         const int mz = rw, my0 = 0;
         const int kg = lane >> 4;
         int fbase[6];                                   // packet offset of each fragment form at halo row 0 (hi plane; lo plane = + 2*HVOLP)
