@@ -155,8 +155,8 @@ def test_argument_errors_are_reported_not_thrown(lib):
     from brats2019_amd import _lib as L
     from brats2019_amd.engine import ParamLayout
     lay = ParamLayout(**O.DEFAULT_CFG)
-    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0
-    assert lib.ru_unet_set_fusion(lay.handle, 4) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
+    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0 and lib.ru_unet_set_fusion(lay.handle, 7) == 0
+    assert lib.ru_unet_set_fusion(lay.handle, 8) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
     assert lib.ru_unet_set_precision(lay.handle, 7) < 0
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 12, 16, 16, 0) == 0            # extents must be divisible by 2^(depth-1)
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 1) > lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 0) > 0
@@ -165,6 +165,23 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ru_comm_init(C.byref(h), None, 0, 1) < 0 and lib.ru_comm_init(None, None, 0, 0) < 0
     assert lib.ru_comm_destroy(None) == 0 and lib.ru_comm_rank(None) == -1 and lib.ru_comm_world(None) == 0
     assert lib.ru_criterion_value_device(None, 3, 1.0, 1.0, 0.5, 0.5, None, None) < 0
+    # round-3 entries: inference driver kernels, optimizer, family probe (argument checks come before any launch)
+    i3 = lambda *v: (C.c_int * len(v))(*v)
+    one = C.c_void_p(64)                                  # any non-null pointer: never dereferenced by a failing check
+    assert lib.ru_tile_gather(None, None, 1, 1, 8, 8, 8, 1, None, 8, 8, 8, None) < 0 and b"ru_tile_gather" in lib.ru_last_error()
+    assert lib.ru_tile_gather(one, one, 1, 1, 8, 8, 8, 1, i3(0, 0, 0), 8, 8, 6, None) < 0 and b"multiple of 4" in lib.ru_last_error()
+    assert lib.ru_tile_scatter(one, one, 1, 1, 8, 8, 8, 1, i3(0, 0, 0), 8, 8, 8, i3(2, 2, 2), i3(8, 8, 8), None) < 0 and b"centre block outside" in lib.ru_last_error()
+    assert lib.ru_tile_scatter(one, one, 1, 1, 8, 8, 8, 1, i3(-4, 0, 0), 8, 8, 8, i3(2, 2, 2), i3(4, 4, 4), None) < 0 and b"before the volume start" in lib.ru_last_error()
+    assert lib.ru_case_bbox(None, None, 4, 8, 8, 8, None) < 0
+    assert lib.ru_case_stats(one, one, 4, 8, 8, 8, i3(0, 0, 0), i3(9, 8, 8), one, 1 << 20, None) < 0 and b"inside the volume" in lib.ru_last_error()
+    assert lib.ru_case_prepare(one, one, one, 4, 8, 8, 8, i3(0, 0, 0), i3(8, 8, 8), i3(1, 0, 0), i3(8, 16, 16), 4, 0, None) < 0 and b"does not fit" in lib.ru_last_error()
+    assert lib.ru_tta_merge_box(one, 9, 0, None, one, one, 3, 8, 8, 8, i3(0, 0, 0), i3(8, 8, 8), None) < 0
+    assert lib.ru_cc_reject(one, 8, 8, 8, 0.1, one, 16, None) < 0 and b"workspace too small" in lib.ru_last_error()
+    assert lib.ru_cc_workspace_bytes(8, 8, 8) >= 2 * 512 * 4 and lib.ru_case_workspace_bytes(4, 8, 8, 8) > 0
+    assert lib.ru_paste_labels(one, one, 8, 8, 8, i3(4, 0, 0), i3(8, 8, 8), None) < 0
+    assert lib.ru_adam_step(None, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) < 0 and b"ru_adam_step" in lib.ru_last_error()
+    ms, cnt = (C.c_double * 7)(), (C.c_int * 7)()
+    assert lib.ru_unet_probe_read_families(lay.handle, ms, cnt, 6) < 0 and lib.ru_unet_probe_read_families(lay.handle, ms, cnt, 7) == 0 and sum(cnt) == 0
 
 
 def test_default_precision_rule():
