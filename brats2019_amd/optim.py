@@ -125,7 +125,7 @@ class Adam(torch.optim.Optimizer):
                     g = g.to(device=p.device, dtype=torch.float32).contiguous()
                     p.grad = g
                 st = self.state[p]
-                if "exp_avg" not in st or "step" not in st:
+                if "step" not in st or any(k not in st for k in plan["keys"]):      # lazy init; also a state loaded without `max_exp_avg_sq` under amsgrad
                     st = self._init_state(plan, p)
                 stp = st["step"]
                 k = int(stp.item() if isinstance(stp, torch.Tensor) else stp) + 1

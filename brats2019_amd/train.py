@@ -250,10 +250,18 @@ class Trainer(object):
         self._pending_scalars = []
 
     # ------------------------------------------------------------------ inference (train.py:129-176)
+    def _freeze_for_eval(self):
+        """Evaluation runs many forwards on constant weights: the executor packs them once (dropped again by model.train() and by
+        load_state_dict, model.UNet.freeze_params)."""
+        net = self.model.module if hasattr(self.model, "module") else self.model
+        if hasattr(net, "freeze_params") and self.state.cuda:
+            net.freeze_params(True)
+
     def predict(self, batch):
         self.model.eval()
         if self.state.cuda:
             self.model.cuda()
+        self._freeze_for_eval()
         with torch.no_grad():
             assert isinstance(batch[0], list)
             return self.model(self._to_device(batch[0]))
@@ -286,6 +294,7 @@ class Trainer(object):
             self.model.cuda()
             inp = inp.cuda(non_blocking=True)
         self.model.eval()
+        self._freeze_for_eval()
         if batch_tiles is None:
             batch_tiles = self._auto_batch_tiles(tile_shape, int(inp.shape[0]))
             rank, world = world_info()
