@@ -34,8 +34,12 @@ struct C3 {
 };
 
 template <int TZ, int TY, int KC, int NT>
-__global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, int ntz, int nty, int ntx) {
+__global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a0, int ntz, int nty, int ntx) {
     using P = C3<TZ, TY, KC, NT>;
+    // split-K (Conv3Args::ksplit = gridDim.z): this workgroup sums input channels [c_begin, c_end) into partial tensor blockIdx.z
+    Conv3Args a = a0;
+    const int c_span = a0.CinP / (int)gridDim.z, c_begin = (int)blockIdx.z * c_span, c_end = c_begin + c_span;
+    a.y = a0.y + (size_t)blockIdx.z * a0.N * a0.Cout * ((size_t)a0.D * a0.H * a0.W);
     constexpr int MT = P::MT, CS = P::CS, WS = P::WS, HY = P::HY, HX = P::HX, HVOL = P::HVOL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;
@@ -101,8 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv3_f32_kernel(const Conv3Args a, in
     const bool xform = a.in_scale != nullptr;
     const float slope = xform ? a.in_slope : 1.f;    // neutral constants (1, 0, 1) make the fused transform branch-free and exact
 
-    for (int c0 = 0; c0 < a.CinP; c0 += KC) {
-        if (c0) __syncthreads();
+    for (int c0 = c_begin; c0 < c_end; c0 += KC) {
+        if (c0 != c_begin) __syncthreads();
         // ---- stage the input halo tile (zero padding AFTER the fused transform: the reference pads the activated tensor)
         if (vec) {
             float4 v[KC][NSV];
@@ -214,8 +218,22 @@ static C3Choice conv3_choose(int N, int Cin, int Cout, int D, int H, int W) {
     return {2, 4, kc, nt};
 }
 
+// Split-K factor of an exact-f32 conv: shapes with fewer than two workgroups per CU walk all their input-channel chunks in sequence with
+// every chunk's global-load latency exposed (one wave per SIMD, no double buffer: the 128-channel level of a batch-1 forward ran at 26 %
+// of the f32 MFMA peak) -- the chunks are spread over up to four co-resident workgroups per CU.
+int conv3_f32_ksplit(int N, int Cin, int Cout, int D, int H, int W) {
+    const C3Choice c = conv3_choose(N, Cin, Cout, D, H, W);
+    if (c.kc != 8) return 1;
+    const long blocks = (long)N * cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * cdiv(conv3_cout_pad(Cout), 16 * c.nt);
+    const int nchunk = conv3_cin_pad(Cin) / 8;
+    int ks = 1;
+    while (nchunk % (ks * 2) == 0 && nchunk / (ks * 2) >= 2 && blocks * (ks * 2) <= 1024) ks *= 2;
+    return ks;
+}
+
 int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int mode) {
     if (conv3_effective_mode(mode, W) == RU_PREC_BF16X3) return conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W);
+    if (conv3_f32_ksplit(N, Cin, Cout, D, H, W) > 1) return gn_stats_tiles((size_t)D * H * W);      // (the engine's split path: gn_stats_launch takes them)
     const C3Choice c = conv3_choose(N, Cin, Cout, D, H, W);
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16);
 }
@@ -236,7 +254,10 @@ static int launch_cfg(const Conv3Args& a, hipStream_t s) {
         attr_done.set();
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
-    dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.CoutP, NT * 16));
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    RU_REQUIRE(ks == 1 || ((a.CinP / KC) % ks == 0 && !a.stat_partials && !a.bias && !a.add && !a.sigmoid),
+               "conv3_f32: split-K divides the input-channel chunks and has a plain epilogue");
+    dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.CoutP, NT * 16), (unsigned)ks);
     hipLaunchKernelGGL((conv3_f32_kernel<TZ, TY, KC, NT>), grid, dim3(256), lds, s, a, ntz, nty, ntx);
     RU_CHECK_LAUNCH("conv3_f32_kernel");
     return RU_OK;

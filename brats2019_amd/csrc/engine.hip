@@ -507,7 +507,19 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
         }
         (void)hipEventRecord(h->probe_ev[h->probe_used], s);
     }
-    RU_RUN(conv3_launch(a, s));
+    // exact-f32 engine, small shapes (the deep levels of a batch-1 forward): input-channel chunks split over co-resident workgroups, the
+    // partial output tensors summed in a fixed order and the GroupNorm statistics taken by the stand-alone pass
+    const int ksplit = (!h->c16 && conv3_effective_mode(h->precision, W) == RU_PREC_F32) ? conv3_f32_ksplit(N, Cin, Cout, D, H, W) : 1;
+    if (ksplit > 1) {
+        const size_t nel = (size_t)N * Cout * D * H * W;
+        float* part = A.alloc((size_t)ksplit * nel);
+        a.y = part; a.stat_partials = nullptr; a.ksplit = ksplit;
+        RU_RUN(conv3_launch(a, s));
+        RU_RUN(sum_partials_launch(part, ksplit, nel, y, s));
+        RU_RUN(gn_stats_launch(y, partials, N, Cout, (size_t)D * H * W, s));
+    } else {
+        RU_RUN(conv3_launch(a, s));
+    }
     if (probed) {
         (void)hipEventRecord(h->probe_ev[h->probe_used + 1], s);
         h->probe_used += 2;

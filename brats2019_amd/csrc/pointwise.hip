@@ -541,6 +541,30 @@ int lrelu_bwd_launch(const float* yv, const float* dy, float* dx, size_t n, floa
 int sigmoid_launch(const float* x, float* y, size_t n, hipStream_t s) { return ew_launch<EW_SIGMOID>(x, nullptr, y, n, 0.f, s, "sigmoid"); }
 int sigmoid_bwd_launch(const float* p, const float* dp, float* dz, size_t n, hipStream_t s) { return ew_launch<EW_SIGMOID_BWD>(p, dp, dz, n, 0.f, s, "sigmoid_bwd"); }
 int add_launch(const float* a, const float* b, float* y, size_t n, hipStream_t s) { return ew_launch<EW_ADD>(a, b, y, n, 0.f, s, "add"); }
+// split-K partial tensors -> y, summed in z order (deterministic)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int ksplit, size_t n, float* __restrict__ y) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<const float4*>(part)[i];
+        for (int z = 1; z < ksplit; ++z) {
+            const float4 t = reinterpret_cast<const float4*>(part + (size_t)z * n)[i];
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        reinterpret_cast<float4*>(y)[i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {                  // ragged tail
+        const size_t i = (n4 << 2) + threadIdx.x;
+        float acc = part[i];
+        for (int z = 1; z < ksplit; ++z) acc += part[(size_t)z * n + i];
+        y[i] = acc;
+    }
+}
+int sum_partials_launch(const float* part, int ksplit, size_t n, float* y, hipStream_t s) {
+    RU_REQUIRE(part && y && ksplit >= 1, "sum_partials: bad argument");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(grid1d(n, 256 * 4, 2048)), dim3(256), 0, s, part, ksplit, n, y);
+    RU_CHECK_LAUNCH("sum_partials_kernel");
+    return RU_OK;
+}
 int fill_launch(float* p, float v, size_t n, hipStream_t s) { return ew_launch<EW_FILL>(nullptr, nullptr, p, n, v, s, "fill"); }
 
 // ------------------------------------------------------------------ trilinear x2, align_corners=False (model.py:12-14)

@@ -105,7 +105,14 @@ struct Conv3Args {
     // MFMA products per operand pair in split-bf16 mode: 0 / 3 = hi*hi + lo*hi + hi*lo; 1 = hi*hi only (plain bf16 operands: the engine's
     // gradient precision RU_PREC_BF16).  Honoured by the persistent voxel-major kernel; every other kernel keeps three products.
     int products;
+    // Split-K of the exact-f32 kernel (small shapes: fewer workgroups than two per CU, each walking ALL input-channel chunks with the
+    // load latency of every chunk exposed): ksplit > 1 workgroups share a (tile, cout block), each sums CinP / ksplit input channels and
+    // writes its partial OUTPUT tensor to y + z * N * Cout * D * H * W (z = 0 .. ksplit-1; plain epilogue: no statistics, bias, residual,
+    // activation); sum_partials_launch adds them in z order.  0 / 1 = off.
+    int ksplit;
 };
+int conv3_f32_ksplit(int N, int Cin, int Cout, int D, int H, int W);     // split factor the engine uses for an exact-f32 conv of this shape (1 = none)
+int sum_partials_launch(const float* part, int ksplit, size_t n, float* y, hipStream_t s);    // y[i] = part[0][i] + part[1][i] + ... (fixed order)
 int conv3_cin_pad(int Cin);                       // CinP for a given Cin
 static inline int conv3_cout_pad(int Cout) { return round_up(Cout, 16); }
 // effective mode for a shape (the split-bf16 kernel needs W % 4 == 0; otherwise the f32 kernel runs)
