@@ -580,6 +580,55 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (st_chain) dispatch(std::integral_constant<int, CR>{});
             else dispatch(std::integral_constant<int, 0>{});
         };
+        // ---- split-form input, multi-chunk shapes (the deep-level data-gradient convs): the staging is a COPY of 16-byte packets, so it goes
+        // global -> LDS directly (`buffer_load_dwordx4 ... lds`: lane l's 16 bytes land at M0 + 16 l; an out-of-range offset writes the zero
+        // padding) -- no VGPR round trip, no ds_write, 17 instructions per staging wave and item instead of 18 loads + 36 LDS stores.  Staging
+        // wave q owns plane q of the image (hi / lo x channel half); chunk c of a plane = its positions 64 c .. 64 c + 63 (the last chunk's
+        // lanes beyond the image fall into the padding of the plane, HVOLP - NPOS = 8 packets).  The image of item w+1 is requested when
+        // item w starts (its buffer was last read during item w-1) and has landed -- vmcnt(0), then the barrier -- before anybody reads it.
+        constexpr bool kDma = MULTI && !(dbg & 131072);
+        if (kDma && s16) {
+            constexpr int NCH = (NPOS + 63) / 64;
+            static_assert(NCH * 64 <= HVOLP, "the last chunk must stay inside the plane's padding");
+            const int plane = rw;                                        // 0: hi half 0, 1: hi half 1, 2: lo half 0, 3: lo half 1
+            const bool live_plane = NP == 3 || plane < 2;                // one product: the lo planes are never read
+            int dpk[NCH], ddl[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int p = c * 64 + lane;
+                const int row = p / HX, xc = p - row * HX;
+                const int hz = row / HY, hy = row - hz * HY;
+                dpk[c] = (p < NPOS) ? (hz | (hy << 8) | (xc << 16)) : 0x00ffffff;       // (beyond the image: coordinates that fail every test)
+                ddl[c] = ((hz * H + hy) * W + xc) * 64 + plane * 16;
+            }
+            auto dma = [&](int item, u32x4* buf) __attribute__((always_inline)) {
+                if (!live_plane) return;
+                const int step = item / nchunk;
+                const int tile = tile_of(step), chunk = item % nchunk;
+                int n, z0, y0, x0, tis;
+                tile_origin(tile, n, z0, y0, x0, tis);
+                const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
+                const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
+                const int base = ((zm1 * H + ym1) * W + xm1) * 64;
+                u32x4* dst = buf + plane * HVOLP;
+                static_for<NCH>([&](auto C) __attribute__((always_inline)) {
+                    constexpr int c = decltype(C)::value;
+                    const int gz = zm1 + (dpk[c] & 0xff), gy = ym1 + ((dpk[c] >> 8) & 0xff), gx = xm1 + ((dpk[c] >> 16) & 0xff);
+                    const bool ok = ((unsigned)gz < (unsigned)D) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+                    const unsigned ofs = ok ? (unsigned)(base + ddl[c]) : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + c * 64), 16, ofs, 0, 0, 0);
+                });
+            };
+            if (nitems > 0) dma(0, lds);
+            __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), expcnt and lgkmcnt left alone: the image has landed in LDS
+            __syncthreads();
+            for (int w = 0; w < nitems; ++w) {
+                if (w + 1 < nitems) dma(w + 1, lds + ((w + 1) & 1) * BUF);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+            }
+        } else {
         if (nitems > 0) {
             issue(0);
             store(0, lds);
@@ -592,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 if (w + 2 < nitems) issue(w + 2);
             }
             __syncthreads();
+        }
         }
         }
     } else {

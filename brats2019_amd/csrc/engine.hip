@@ -1519,6 +1519,8 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     if (rc) return rc;
     a.mode = RU_PREC_BF16X3; a.wfrag = wf;
     a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
+    a.in_s16 = (flags >> 3) & 1;                                 // x is voxel-major in SPLIT form (hi / lo bf16 packets, as gn_bwd_apply16 publishes it)
+    RU_REQUIRE(!a.in_s16 || a.in_c16, "ru_conv3d_fwd_l: the split form is a voxel-major layout");
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     if (flags & 4) {                                             // x NCDHW with Cin <= 4: 4-channel copy + tap-pair kernel
         RU_REQUIRE(!(flags & 1) && conv3_sb4_usable(N, Cin, Cout, D, H, W), "ru_conv3d_fwd_l: shape does not fit the 4-channel kernel");
