@@ -22,9 +22,14 @@ w = torch.randn(c, c, 3, 3, 3, device=dev) * 0.05
 y = torch.empty_like(x)
 ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, c, c, size, size, size, 3), dev)
 buf = (ctypes.c_ulonglong * 8)()
+ms = 0.0
 for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), n, c, c, size, size, size, 3, L.ptr(ws), ws.numel(), L.stream()), "fwd_l")
+    e1.record()
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)                 # (includes the ~2 us weight-pack kernel)
     fn(ctypes.addressof(buf))
 v = list(buf)
 items, wgs = max(v[5], 1), max(v[7], 1)
@@ -34,3 +39,6 @@ print("C=%d size=%d N=%d: %d workgroups, %.1f items each; cycles per item (consu
 for i, nm in enumerate(names):
     print("  %-12s %8.0f  (%4.1f %%)" % (nm, v[i] / items, 100.0 * v[i] / tot))
 print("  %-12s %8.0f ; ideal MFMA time per item 336 x 16 = 5376" % ("total", tot / items))
+per_wg = items / wgs
+print("  launch %.1f us for %.1f items per workgroup = %.2f us per item -> the consumer's %0.f cycles per item are %.2f GHz (s_memtime counts shader cycles)"
+      % (ms * 1e3, per_wg, ms * 1e3 / per_wg, tot / items, (tot / items) / (ms * 1e3 / per_wg) / 1e3))
