@@ -202,12 +202,15 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
     `steps` further training steps with a HIP event pair on the launch stream (ru_unet_probe(h, 2)) -- next to the family's roofline bound
     (family_bounds) both ways.  The event records add ~1 us per launch, so the families sum to slightly more than the un-probed step."""
     eng = backend.engine
+    eng.set_fusion(True, True, side_stream=False)      # attribution needs the kernels one after the other: the timed step overlaps the deep-level
+    one_step()                                          # weight gradients (side stream) with the chain, which stretches both in a per-launch timing
     eng.probe(2)
     for _ in range(steps):
         one_step()
     torch.cuda.synchronize()
     got = eng.probe_read_families()
     eng.probe(False)
+    eng.set_fusion(True, True, side_stream=True)
     bounds = family_bounds(batch, size, precision)
     out, total = [], 0.0
     for name in eng.FAMILIES:
@@ -227,8 +230,9 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
             row["frac_executed"] = round(b["bound_ms_executed"] / ms, 4) if ms > 0 else None
         out.append(row)
     return {"families": out, "sum_ms": round(total, 3), "step_ms_unprobed": round(step_ms, 3), "probe_steps": steps,
-            "measured": "HIP event pairs around every launch of ru_unet_forward / ru_unet_backward in %d training steps after the timed region (ru_unet_probe(h, 2)); "
-                        "criterion, Adam and collectives are outside the executor and not listed" % steps}
+            "measured": "HIP event pairs around every launch of ru_unet_forward / ru_unet_backward in %d training steps after the timed region (ru_unet_probe(h, 2)), "
+                        "with the side stream switched off so that no two kernels overlap (the timed step runs the deep-level weight gradients beside the chain: "
+                        "its ms_per_step is smaller than this sum); criterion, Adam and collectives are outside the executor and not listed" % steps}
 
 
 def roofline_probe(batch, size, precision, launches=20, insitu=None, power_index=None):
