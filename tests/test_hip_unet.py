@@ -614,3 +614,34 @@ def test_bf16_gradient_precision_training_trajectory():
     print("bf16 vs three-product gradients after 6 steps: losses %s / %s; weights differ by %.2e relative L2, the update itself is %.2e" %
           (["%.6f" % v for v in la], ["%.6f" % v for v in lb], rel, upd))
     assert 0 < rel < 5e-5 and rel < 0.2 * upd
+
+
+def test_forward_criterion_backward_capture_into_a_hip_graph():
+    """include/resunet_hip.h promises graph-capturable entry points (no allocation, no synchronisation, everything on the caller's stream; the
+    side stream forks from and joins back into it): forward + criterion + backward of DataParallelStep captured into ONE hipGraph
+    (torch.cuda.CUDAGraph) after an eager warm-up, replayed twice -- losses and the gradient bucket equal the eager run bit for bit."""
+    from brats2019_amd import parallel as P
+    be = P.HipBackend(cfg=O.DEFAULT_CFG)
+    flat = be.new_flat()
+    for k, v in be.engine.layout.views(flat).items():
+        v.copy_(T(O.make_params(3, **O.DEFAULT_CFG)[k]))
+    st = P.DataParallelStep(be, flat)
+    x = T(O.make_input(2, 64, 64, 64, seed=3)).cuda()
+    g = T(O.make_target(2, 64, 64, 64, seed=3)).cuda()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                   # eager warm-up on the capture stream (workspace, side stream, events exist afterwards)
+        for _ in range(2):
+            loss_e, _, _ = st.loss_and_grads(x, g)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    loss_eager, grads_eager = float(loss_e), st.grads.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss_c, _, _ = st.loss_and_grads(x, g)
+    for _ in range(2):
+        st.grads.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float(loss_c) == loss_eager
+        assert torch.equal(st.grads, grads_eager)
