@@ -236,7 +236,14 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) sb_out_tile<OUT16, NS>(a, out, y0 + my0 + i, acc[i], radd[i], s1, s2);
-    sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, tis * 4 + wave, tiles_per_sample * 4, lane);
+    // one partial per (tile, sample channel): the four waves' sums meet in LDS (free after the last K-step) and wave 0 publishes them
+    if (a.stat_partials) {
+        __syncthreads();
+        sb_stats_to_lds<OUT16>(s1, s2, smem + 4 + wave * 32, lane);
+        __syncthreads();
+        if (wave == 0) sb_stats_commit(a, smem + 4, n, cog, tis, tiles_per_sample, lane);
+    }
+    fin_tail(a.fin, a.stat_partials, smem + 4 + 128);    // RU_FUSE_TAIL_FINALIZE
 }
 
 // ------------------------------------------------------------------ few input channels (network input: 4; head gradient: 3)
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
             }
             __syncthreads();
         }
+        __syncthreads();                                // (the consumers' closing barrier: their last statistics flush)
     } else {
         const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
         const int kg = lane >> 4;
@@ -364,14 +372,23 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
         f32x4 s1, s2;                                   // whole vectors: the per-row update is 2 v_pk_add + 2 v_pk_fma, no packing moves
 #pragma unroll
         for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
-        const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
+        const int stat_blk = blockIdx.x, stat_nblk = G;   // one partial per (workgroup, sample): see sb_stats_to_lds / sb_stats_commit
         unsigned flushed = 0;
         int n_acc = -1;
+        float* stat_lds = smem + BUF * 8;                // behind the two image buffers
+        int pend_n = -1, pend_par = 0, par = 0;
         auto flush_stats = [&](int n) {
-            sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+            if (a.stat_partials) sb_stats_to_lds<OUT16>(s1, s2, stat_lds + (par * 4 + rw) * 32, lane);
+            pend_n = n; pend_par = par; par ^= 1;
             flushed |= 1u << (n & 31);
 #pragma unroll
             for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        };
+        auto commit_stats = [&]() {
+            if (pend_n >= 0) {
+                if (rw == 0 && a.stat_partials) sb_stats_commit(a, stat_lds + pend_par * 128, pend_n, cog, stat_blk, stat_nblk, lane);
+                pend_n = -1;
+            }
         };
         f32x4 acc[MT];
         __syncthreads();                                // item 0 is staged
@@ -388,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
         }
         for (int w = 0; w < nitems; ++w) {
             const u32x4* buf = lds + (w & 1) * BUF;
+            commit_stats();                              // (a flush of the previous item is complete in LDS since that item's barrier)
             // output rows of this tile; the per-row operand of the epilogue (residual, or BST: the forward tensor) is requested now and
             // lands under the MFMAs (it used to be loaded after them, with the stores waiting on it)
             const int n = cn, z0 = ctz * TZ, y0 = cty * TY, x0 = ctx * 16;
@@ -465,12 +483,16 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2c4_kernel(const Conv3Args a, 
             }
             __syncthreads();
         }
+        commit_stats();
         if (n_acc >= 0) flush_stats(n_acc);
-        if (a.stat_partials) {
+        __syncthreads();                                // (matched by the producers' closing barrier) the last flush is in LDS
+        commit_stats();
+        if (a.stat_partials && rw == 0) {                // zeros for the samples this workgroup did not touch
             for (int n = 0; n < a.N; ++n)
-                if (n >= 32 || !((flushed >> n) & 1u)) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+                if (n >= 32 || !((flushed >> n) & 1u)) sb_stats_commit(a, nullptr, n, cog, stat_blk, stat_nblk, lane);
         }
     }
+    fin_tail(a.fin, a.stat_partials, smem);              // RU_FUSE_TAIL_FINALIZE
 }
 
 // weight fragments of the 4-channel kernel: unit (cog*5 + ks)*2 + hl, lane (col, g): pair t = 4*ks + g, elements e < 4: channel e at
@@ -582,8 +604,8 @@ int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, in
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     (void)Cin;
     const SBChoice c = sb_choose(N, Cout, D, H, W);
-    if (sb_use_v2(c)) return (int)sb2_grid_x(N, Cout, D, H, W) * 4;    // persistent kernel: one per (workgroup, consumer wave)
-    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16) * 4;             // one-stage kernel: one per (tile, wave)
+    if (sb_use_v2(c)) return (int)sb2_grid_x(N, Cout, D, H, W);        // persistent kernel: one per workgroup
+    return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16);                 // one-stage kernel: one per tile
 }
 
 bool conv3_sb_bst_usable(int N, int Cout, int D, int H, int W) { return sb_use_v2(sb_choose(N, Cout, D, H, W)); }
@@ -599,6 +621,8 @@ static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.Cout, 16));
+    RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.kind == 1 && a.fin.nblk == ntz * nty * ntx && a.fin.N == a.N && a.fin.C == a.Cout),
+               "conv3_sb: tail descriptor does not match the launch");
     hipLaunchKernelGGL((conv3_sb_kernel<TZ, TY, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16));
     RU_CHECK_LAUNCH("conv3_sb_kernel");
     return RU_OK;
@@ -612,7 +636,7 @@ template <bool OUT16, bool BST = false>
 static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<4, 8>;
     static PerDevice attr_done;
-    constexpr int LDS = 2 * 2 * P::HVOLP * 16;
+    constexpr int LDS = 2 * 2 * P::HVOLP * 16 + SB_STAT_LDS_FLOATS * 4;
     if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2c4_kernel<OUT16, BST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2c4)");
@@ -620,6 +644,8 @@ static int sb2c4_cfg(const Conv3Args& a, hipStream_t s) {
     }
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_sb2c4: at most 32 samples per call when statistics are requested");
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
+    RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.nblk == (int)grid.x && a.fin.N == a.N && a.fin.C == a.Cout && fin_tail_lds_bytes(a.fin) <= (size_t)LDS),
+               "conv3_sb2c4: tail descriptor does not match the launch");
     hipLaunchKernelGGL((conv3_sb2c4_kernel<OUT16, BST>), grid, dim3(512), LDS, s, a, (const u32x4*)a.wfrag, cdiv(a.D, 4), cdiv(a.H, 8), cdiv(a.W, 16));
     RU_CHECK_LAUNCH("conv3_sb2c4_kernel");
     return RU_OK;

@@ -4,6 +4,7 @@
 // NCDHW-side variants of the op-level C-ABI and of the stem / head) so that the 20 variants compile in parallel.
 #pragma once
 #include "conv3_epilogue.hpp"
+#include "fin_tail.hpp"
 #include <stdlib.h>
 #include <utility>
 
@@ -154,10 +155,12 @@ __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut&
     s2 += dh * u;
     *reinterpret_cast<float4*>(a.y + sb_out_index<true>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
-// per-wave statistics partial of one tile: [N][Cout][nblk][2] at block tile_in_sample*4 + wave
-template <bool OUT16, int NS>
-__device__ __forceinline__ void sb_out_stats(const Conv3Args& a, f32x4& s1, f32x4& s2, int n, int cog, int blk, int nblk, int lane) {
-    if (!a.stat_partials) return;
+// Statistics partials: ONE per (workgroup, sample), [N][Cout][nblk][2].  A consumer wave folds its lanes and leaves its 16 channels'
+// (sum, sum2) in an LDS scratch row (sb_stats_to_lds: sc = this wave's 32 floats); after a workgroup barrier one wave adds the four
+// rows in wave order and publishes the pair (sb_stats_commit) -- a quarter of the per-wave partials the finalize used to read.
+constexpr int SB_STAT_LDS_FLOATS = 2 * 4 * 32;             // two generations (a flush may follow a flush one item later) x 4 waves x 16 channels x 2
+template <bool OUT16>
+__device__ __forceinline__ void sb_stats_to_lds(f32x4& s1, f32x4& s2, float* sc, int lane) {
     if constexpr (OUT16) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -166,19 +169,24 @@ __device__ __forceinline__ void sb_out_stats(const Conv3Args& a, f32x4& s1, f32x
         }
         if ((lane & 15) == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float* p = a.stat_partials + (((size_t)n * a.Cout + cog * 16 + 4 * (lane >> 4) + r) * nblk + blk) * 2;
-                p[0] = s1[r]; p[1] = s2[r];
-            }
+            for (int r = 0; r < 4; ++r) { sc[(4 * (lane >> 4) + r) * 2] = s1[r]; sc[(4 * (lane >> 4) + r) * 2 + 1] = s2[r]; }
         }
     } else {
-        const int co = cog * 16 + (lane & 15);
         s1[0] += __shfl_xor(s1[0], 16); s2[0] += __shfl_xor(s2[0], 16);
         s1[0] += __shfl_xor(s1[0], 32); s2[0] += __shfl_xor(s2[0], 32);
-        if (lane < 16 && co < a.Cout) {
-            float* p = a.stat_partials + (((size_t)n * a.Cout + co) * nblk + blk) * 2;
-            p[0] = s1[0]; p[1] = s2[0];
+        if (lane < 16) { sc[lane * 2] = s1[0]; sc[lane * 2 + 1] = s2[0]; }
+    }
+}
+// lanes 0..15 of one wave; sc4 = the four waves' rows of one generation (null: zeros -- a sample this workgroup never touched)
+__device__ __forceinline__ void sb_stats_commit(const Conv3Args& a, const float* sc4, int n, int cog, int blk, int nblk, int lane) {
+    const int co = cog * 16 + lane;
+    if (lane < 16 && co < a.Cout) {
+        float u1 = 0.f, u2 = 0.f;
+        if (sc4) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u1 += sc4[w * 32 + lane * 2]; u2 += sc4[w * 32 + lane * 2 + 1]; }
         }
+        stat_publish(a.stat_partials + (((size_t)n * a.Cout + co) * nblk + blk) * 2, u1, u2);
     }
 }
 
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         }
         }
         }
+        __syncthreads();                                // (the consumers' closing barrier: their last statistics flush)
     } else {
         // ---------------------------------------------------------------- consumers
         // Wave rw owns output plane z0 + rw: its 8 M-tiles are the 8 rows of that plane (tile i = row y0 + i), and the A fragment of
@@ -712,14 +721,25 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // GroupNorm statistics: ONE partial per (workgroup, consumer wave, sample) -- the tiles of a workgroup come in increasing
         // order, so a sample's tiles are consecutive; the partial is flushed when the sample changes and the samples this
         // workgroup never sees get zeros (the finalize kernel then reads gridDim.x*4 partials per channel instead of 4 per tile)
-        const int stat_blk = blockIdx.x * 4 + rw, stat_nblk = G * 4;
+        const int stat_blk = blockIdx.x, stat_nblk = G;
         unsigned flushed = 0;                           // bit n: sample n has been written
         int n_acc = -1;                                 // sample whose statistics are being accumulated
+        // flush: this wave's sums go to the LDS scratch (generation `par`); they are combined with the other consumer waves' and published
+        // by wave 0 behind the next workgroup barrier (commit_stats at the start of the next item, or after the loop)
+        float* stat_lds = smem + BUF * 8;                // behind the two image buffers (BUF packets of 16 bytes each)
+        int pend_n = -1, pend_par = 0, par = 0;
         auto flush_stats = [&](int n) {
-            sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+            if (a.stat_partials) sb_stats_to_lds<OUT16>(s1, s2, stat_lds + (par * 4 + rw) * 32, lane);
+            pend_n = n; pend_par = par; par ^= 1;
             flushed |= 1u << (n & 31);
 #pragma unroll
             for (int r = 0; r < NS; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        };
+        auto commit_stats = [&]() {
+            if (pend_n >= 0) {
+                if (rw == 0 && a.stat_partials) sb_stats_commit(a, stat_lds + pend_par * 128, pend_n, cog, stat_blk, stat_nblk, lane);
+                pend_n = -1;
+            }
         };
         __syncthreads();                                // item 0 is staged
         const bool prof = (dbg & 64) != 0;
@@ -752,6 +772,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             const int n = cn;                            // sample of this item's tile
             SbOut so{};
             int ybase = 0;
+            commit_stats();                              // (a flush of the previous item is complete in LDS since that item's barrier)
             if (last) {
                 so = sb_out_prepare<OUT16>(a, cn, ctz * TZ + mz, ctx * 16, cog, lane);
                 ybase = cty * TY + my0;
@@ -900,6 +921,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         }
         if (prof) t0 = __builtin_readcyclecounter();
         if ((dbg & 8) && dbg_sink == 12345.678f) a.y[0] = dbg_sink;
+        commit_stats();
         if (n_acc >= 0) flush_stats(n_acc);
         if (prof && rw == 0 && lane == 0) {
             pt[6] = __builtin_readcyclecounter() - t0;
@@ -907,11 +929,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             for (int i = 0; i < 7; ++i) atomicAdd(&sb2_prof[i], pt[i]);
             atomicAdd(&sb2_prof[7], 1ull);
         }
-        if (a.stat_partials && !(dbg & 8)) {            // zeros for the samples this workgroup did not touch (s1 = s2 = 0 here)
+        __syncthreads();                                // (matched by the producers' closing barrier) the last flush is in LDS
+        commit_stats();
+        if (a.stat_partials && rw == 0 && !(dbg & 8)) {  // zeros for the samples this workgroup did not touch
             for (int n = 0; n < a.N; ++n)
-                if (n >= 32 || !((flushed >> n) & 1u)) sb_out_stats<OUT16, NS>(a, s1, s2, n, cog, stat_blk, stat_nblk, lane);
+                if (n >= 32 || !((flushed >> n) & 1u)) sb_stats_commit(a, nullptr, n, cog, stat_blk, stat_nblk, lane);
         }
     }
+    fin_tail(a.fin, a.stat_partials, smem);              // RU_FUSE_TAIL_FINALIZE: the last workgroup of the launch finalizes the partials
 }
 
 
@@ -920,7 +945,7 @@ template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, b
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static PerDevice attr_done;
-    constexpr int LDS2 = 2 * P::LDS_BYTES;
+    constexpr int LDS2 = 2 * P::LDS_BYTES + SB_STAT_LDS_FLOATS * 4;
     if (!attr_done.get()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
@@ -932,6 +957,8 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
+    RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.nblk == (int)grid.x && a.fin.N == a.N && a.fin.C == a.Cout && fin_tail_lds_bytes(a.fin) <= (size_t)LDS2),
+               "conv3_sb2: tail descriptor does not match the launch");
     RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");
     hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");

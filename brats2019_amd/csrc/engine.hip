@@ -92,9 +92,15 @@ struct FamilySink {
 };
 static thread_local FamilySink* t_sink = nullptr;
 static thread_local int t_hint_c = 16;     // channel count of the level being walked (conv / weight-gradient family split)
+// RU_FUSE_BATCH_WREDUCE: the running backward's queues of weight-gradient reductions -- one per stream the partials are produced on
+// (the side stream's are flushed on the side stream before the join, in the shadow of the chain; the caller's stream's at the end)
+struct RedQueues { WgradRedList main, side; hipStream_t side_stream = nullptr; };
+static thread_local RedQueues* t_red = nullptr;
+static WgradRedList* red_for(hipStream_t s) { return t_red ? ((t_red->side_stream && s == t_red->side_stream) ? &t_red->side : &t_red->main) : nullptr; }
 static int family_of(const char* call) {
     auto has = [&](const char* k) { return strstr(call, k) != nullptr; };
     if (has("wgrad3_launch")) return t_hint_c <= 16 ? FAM_WGRAD_L0 : FAM_WGRAD_DEEP;
+    if (has("wgrad_reduce_flush")) return FAM_WGRAD_DEEP;
     if (has("conv3_launch") || has("conv3_sb_launch")) return t_hint_c <= 16 ? FAM_CONV_L0 : FAM_CONV_DEEP;
     if (has("gn_")) return FAM_GN;
     if (has("conv1_") || has("wgrad1_launch") || has("up2_") || has("s2d_launch") || has("d2s_launch") || has("lrelu_bwd_launch")) return FAM_PW;
@@ -199,7 +205,7 @@ struct ru_unet {
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
-    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM;
+    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE;     // (RU_FUSE_TAIL_FINALIZE: opt-in)
     int grad_precision = RU_PREC_BF16X3;   // ru_unet_set_grad_precision: RU_PREC_BF16 = one MFMA product in the 3x3x3 data / weight gradients
     int grad_products() const { return (precision == RU_PREC_BF16X3 && grad_precision == RU_PREC_BF16) ? 1 : 3; }
     int wgrad_mode() const { return precision | (grad_products() == 1 ? kOneProduct : 0); }   // `mode` argument of wgrad3_run
@@ -239,11 +245,20 @@ struct ru_unet {
     // lower-priority HIP stream, event-ordered behind the kernel that produces their dy; ru_unet_backward joins it before it returns
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_ev;       // created on demand (no timing), reused every step
+    ru::RedQueues red;                     // RU_FUSE_BATCH_WREDUCE: reductions queued by the running backward
+    // RU_FUSE_TAIL_FINALIZE: arrival tickets of the launches that finalize their own partial sums (FinTail).  256 words of device memory
+    // owned by the handle, zeroed once when they are created (first forward, outside any capture); the finisher of a launch resets
+    // its word, so a step -- eager or replayed from a hipGraph -- always finds zeros.  Every launch of a forward / backward pair takes its own.
+    unsigned* tickets = nullptr;
+    int ticket_next = 0;
+    unsigned* next_ticket() { return tickets ? tickets + (ticket_next++ & 255) : nullptr; }
+    bool tails() const { return c16 && (fusion & RU_FUSE_TAIL_FINALIZE) && tickets != nullptr; }
     size_t fork_used = 0;
     ~ru_unet() {
         for (hipEvent_t e : probe_ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : fork_ev) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
+        if (tickets) (void)hipFree(tickets);
         delete sink;
     }
 };
@@ -315,6 +330,8 @@ extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const 
     }
     ru_unet* h = new ru_unet();
     if (const char* e = getenv("RU_SIDE_STREAM")) { if (*e == '0') h->fusion &= ~(unsigned)RU_FUSE_SIDE_STREAM; }    // same-box A/B of the side stream
+    if (const char* e = getenv("RU_FUSION_OFF")) h->fusion &= ~(unsigned)strtoul(e, nullptr, 0);                   // same-box A/B of any fusion bit (RU_FUSE_*)
+    if (const char* e = getenv("RU_FUSION_ON")) h->fusion |= (unsigned)strtoul(e, nullptr, 0) & 31u;
     h->depth = depth;
     h->nout = number_of_outputs;
     h->enc.assign(encoder_layers, encoder_layers + depth);
@@ -368,7 +385,7 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
 }
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
 extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
-    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM)) == 0, "ru_unet_set_fusion: bad argument");
+    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE | RU_FUSE_TAIL_FINALIZE)) == 0, "ru_unet_set_fusion: bad argument");
     h->fusion = mask;
     h->have_fwd = false;            // the workspace layout of the backward depends on it
     return RU_OK;
@@ -510,6 +527,14 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     // exact-f32 engine, small shapes (the deep levels of a batch-1 forward): input-channel chunks split over co-resident workgroups, the
     // partial output tensors summed in a fixed order and the GroupNorm statistics taken by the stand-alone pass
     const int ksplit = (!h->c16 && conv3_effective_mode(h->precision, W) == RU_PREC_F32) ? conv3_f32_ksplit(N, Cin, Cout, D, H, W) : 1;
+    out_gn.k = (h->training && h->c16) ? A.alloc_keep((size_t)N * 3 * Cout) : nullptr;
+    // RU_FUSE_TAIL_FINALIZE: the conv's last workgroup turns the partials into mean / rstd / scale / shift (every split-bf16 kernel has the tail)
+    const bool tail = !A.dry && h->tails() && ksplit == 1;
+    if (tail) {
+        FinTail& f = a.fin;
+        f.ticket = h->next_ticket(); f.kind = 1; f.nblk = nblk; f.N = N; f.C = Cout; f.G = kGroups; f.V = (size_t)D * H * W; f.eps = kEps;
+        f.gamma = gamma; f.beta = beta; f.mean = out_gn.mean; f.rstd = out_gn.rstd; f.scale = out_gn.scale; f.shift = out_gn.shift; f.bst_k = out_gn.k;
+    }
     if (ksplit > 1) {
         const size_t nel = (size_t)N * Cout * D * H * W;
         float* part = A.alloc((size_t)ksplit * nel);
@@ -524,9 +549,8 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
         (void)hipEventRecord(h->probe_ev[h->probe_used + 1], s);
         h->probe_used += 2;
     }
-    out_gn.k = (h->training && h->c16) ? A.alloc_keep((size_t)N * 3 * Cout) : nullptr;
-    RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
-                              (size_t)D * H * W, kGroups, kEps, s, out_gn.k));
+    if (!tail) RU_RUN(gn_finalize_launch(partials, nblk, gamma, beta, out_gn.mean, out_gn.rstd, out_gn.scale, out_gn.shift, N, Cout,
+                                         (size_t)D * H * W, kGroups, kEps, s, out_gn.k));
     h->gn_order.push_back(out_gn);
     return RU_OK;
 }
@@ -722,20 +746,38 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
 // ---------------------------------------------------------------------- backward pieces
 // GroupNorm(+LeakyReLU) backward: d_act -> dy (gradient w.r.t. the raw conv output), dgamma/dbeta written
 // fused_part / fused_nblk: the partial sums were already taken by the conv that produced `dact` (Conv3Args::bst_*): no reduce pass
-static int gn_bwd(bool c16, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
-                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const float* fused_part = nullptr, int fused_nblk = 0,
+// pre: the caller allocated the coefficient buffer next to the fused partials (FusedSums) -- and when pre->done, the kernel that produced
+// the partials has already finalized them in its tail (RU_FUSE_TAIL_FINALIZE): no finalize launch here
+struct FusedSums { float* part = nullptr; int nblk = 0; float* coef = nullptr; bool done = false; };
+static void fill_bwd_tail(ru_unet* h, FinTail& f, const FusedSums& fs, const GNSave& g, const float* gamma, float* dgamma, float* dbeta, int N, int C, size_t V, int s2_sign) {
+    f.ticket = h->next_ticket(); f.kind = 2; f.nblk = fs.nblk; f.N = N; f.C = C; f.G = kGroups; f.V = V; f.eps = kEps; f.s2_sign = s2_sign;
+    f.gamma = gamma; f.mean = g.mean; f.rstd = g.rstd; f.coef = fs.coef; f.dgamma = dgamma; f.dbeta = dbeta;
+}
+static int gn_bwd(ru_unet* h, Arena& A, hipStream_t s, const float* yraw, const float* dact, const GNSave& g, const float* gamma, float slope,
+                  float* dy, float* dgamma, float* dbeta, int N, int C, size_t V, const FusedSums* pre = nullptr,
                   float** coef_out = nullptr /* non-null: stop after the finalize; the apply is fused into the weight gradient (Wgrad3Args::gb_*) */,
                   bool split = true /* voxel-major flow: publish dy as hi/lo bf16 packets (read by the transpose-read weight gradient and the
                                        persistent data-gradient conv) or as plain float32 C16 (the generic weight-gradient kernel) */) {
-    const bool fused = fused_nblk > 0;
-    const int nblk = fused ? fused_nblk : (c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V));
-    float* part = fused ? const_cast<float*>(fused_part) : A.alloc((size_t)N * C * nblk * 2);
-    float* coef = A.alloc((size_t)N * C * 3);
+    const bool c16 = h->c16;
+    const bool fused = pre && pre->nblk > 0;
+    const int nblk = fused ? pre->nblk : (c16 ? gn_bwd_tiles16(V) : gn_bwd_tiles(V));
+    float* part = fused ? pre->part : A.alloc((size_t)N * C * nblk * 2);
+    float* coef = fused ? pre->coef : A.alloc((size_t)N * C * 3);
+    bool done = fused && pre->done;
     if (!fused) {
-        if (c16) RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
-        else RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+        if (c16) {
+            FinTail f{};
+            if (!A.dry && h->tails()) {
+                FusedSums fs; fs.part = part; fs.nblk = nblk; fs.coef = coef;
+                fill_bwd_tail(h, f, fs, g, gamma, dgamma, dbeta, N, C, V, 0);
+                done = true;
+            }
+            RU_RUN(gn_bwd_reduce16_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s, &f));
+        } else {
+            RU_RUN(gn_bwd_reduce_launch(yraw, dact, g.scale, g.shift, g.mean, g.rstd, slope, part, N, C, V, kGroups, s));
+        }
     }
-    RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s, fused ? 1 : 0));
+    if (!done) RU_RUN(gn_bwd_finalize_launch(part, nblk, gamma, g.mean, g.rstd, coef, dgamma, dbeta, N, C, V, kGroups, s, fused ? 1 : 0));
     if (coef_out) { *coef_out = coef; return RU_OK; }
     if (c16) RU_RUN(gn_bwd_apply16_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, split ? 1 : 0, s));   // split form: read by MFMA kernels only
     else RU_RUN(gn_bwd_apply_launch(yraw, dact, g.scale, g.shift, coef, slope, dy, N, C, V, s));
@@ -761,7 +803,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         Wgrad3Args w{};
         w.x = x_c16 ? x : fewp; w.dy = x_c16 ? fewp : dy; w.dw = dw; w.mode = mode; w.x_c16 = 1; w.dy_c16 = 1;
         w.x_c4 = (!x_c16 && use4) ? 1 : 0; w.dy_c4 = (x_c16 && use4) ? 1 : 0; w.dy_s16 = (dy_s16 && !x_c16) ? 1 : 0;
-        w.products = products;
+        w.products = products; w.defer = red_for(s);
         // head (dy has 3 real channels, no fused transform on x): exchange the operands, so that the few-channel tensor is the 4-channel
         // x operand whose packet carries the three dx taps (a third of the matrix work); the result comes out transposed with mirrored taps
         const bool swap = x_c16 && use4 && !xg && !gb;
@@ -781,7 +823,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     }
     Wgrad3Args w{};
     w.x = x; w.dy = dy; w.dw = dw; w.mode = mode; w.x_c16 = x_c16; w.dy_c16 = dy_c16; w.dy_s16 = dy_s16 ? 1 : 0;
-    w.products = products;
+    w.products = products; w.defer = red_for(s);
     w.in_scale = xg ? xg->scale : nullptr; w.in_shift = xg ? xg->shift : nullptr; w.in_slope = xg ? xg->act_slope : kSlope;
     w.ws_bytes = wgrad3_workspace_bytes(N, Cin, Cout, D, H, W);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -797,7 +839,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
 static int wgrad1_run(Arena& A, hipStream_t s, const float* x, const float* dy, float* dw, int ldw, int N, int Cin, int Cout, size_t V,
                       bool c16 = false, int tap_split = 0) {
     Wgrad1Args w{};
-    w.x = x; w.dy = dy; w.dw = dw; w.ldw = ldw; w.c16 = c16; w.tap_split = tap_split;
+    w.x = x; w.dy = dy; w.dw = dw; w.ldw = ldw; w.c16 = c16; w.tap_split = tap_split; w.defer = red_for(s);
     w.ws_bytes = wgrad1_workspace_bytes(N, Cin, Cout, V);
     w.ws = A.alloc(w.ws_bytes / sizeof(float));
     w.N = N; w.Cin = Cin; w.Cout = Cout; w.V = V;
@@ -825,6 +867,7 @@ static int side_fork(ru_unet* h, hipStream_t main) {
         const hipError_t er = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo);
         if (er != hipSuccess) return hip_fail(er, "hipStreamCreateWithPriority(side)");
     }
+    h->red.side_stream = h->side;
     hipEvent_t e;
     int rc = side_event(h, &e);
     if (rc) return rc;
@@ -849,9 +892,13 @@ static int side_join(ru_unet* h, hipStream_t main) {
 // nx: the GroupNorm(+activation) the gradient this block produces (dx, for a block without down-sampling conv) enters NEXT -- norm2 of the
 //     previous block of the level, or norm_input: its backward sums are then taken in the epilogue of the data-gradient conv of conv1
 //     (which also adds the skip gradient) and handed back through nx->part / nx->nblk
-struct GNNext { const float* y; const float* k; float slope; float* part; int nblk; };
+struct GNNext {
+    const float* y; const float* k; float slope;
+    const GNSave* g; const float* gamma; float* dgamma; float* dbeta;     // the GroupNorm the produced gradient enters (tail finalize)
+    FusedSums out;                                                        // filled here: partials (+ coefficients) of that GroupNorm
+};
 static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hipStream_t s, const BlockSave& sv, const float* dout,
-                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr, const float* part2 = nullptr, int nblk2 = 0,
+                     const float** dxprev_out, const float* join = nullptr, bool* joined = nullptr, const FusedSums* sums2 = nullptr,
                      GNNext* nx = nullptr) {
     if (joined) *joined = false;
     const BlockP& bp = *sv.bp;
@@ -867,7 +914,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     // profiles/r02_notes.txt -- every input-channel group recomputes the apply while staging, and the producers become the slower side.)
     const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && (h->fusion & RU_FUSE_GN_BWD_APPLY);
     float *coef2 = nullptr, *coef1 = nullptr;
-    int rc = gn_bwd(c16, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, part2, nblk2,
+    int rc = gn_bwd(h, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, sums2,
                     fa ? &coef2 : nullptr);
     if (rc) return rc;
     const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
@@ -885,16 +932,20 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
     // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
     const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
-    float* part1 = nullptr;
-    int nblk1 = 0;
+    FusedSums sums1;
     if (fuse1) {
-        nblk1 = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
-        part1 = A.alloc((size_t)N * C * nblk1 * 2);
-        d2.bst_y = sv.y1; d2.bst_k = sv.g1.k; d2.bst_slope = kSlope; d2.stat_partials = part1;       // constants written by the forward finalize
+        sums1.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
+        sums1.part = A.alloc((size_t)N * C * sums1.nblk * 2);
+        sums1.coef = A.alloc((size_t)N * C * 3);
+        d2.bst_y = sv.y1; d2.bst_k = sv.g1.k; d2.bst_slope = kSlope; d2.stat_partials = sums1.part;  // constants written by the forward finalize
+        if (!A.dry && h->tails()) {                      // ... and the conv's last workgroup finalizes them (coefficients, dgamma, dbeta of norm1)
+            fill_bwd_tail(h, d2.fin, sums1, sv.g1, P(h, params, bp.n1w), G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, 1);
+            sums1.done = true;
+        }
     }
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
-    rc = gn_bwd(c16, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, part1, nblk1,
+    rc = gn_bwd(h, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, fuse1 ? &sums1 : nullptr,
                 fa ? &coef1 : nullptr);
     if (rc) return rc;
     const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
@@ -906,11 +957,16 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.products = h->grad_products(); d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
     d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = c16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
-    if (nx) { nx->part = nullptr; nx->nblk = 0; }
+    if (nx) nx->out = FusedSums();
     if (nx && fuse1 && bp.down < 0) {                   // same shape and kernel choice as d2: dx = dout + dgrad(conv1) IS the gradient entering nx
-        nx->nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
-        nx->part = A.alloc((size_t)N * C * nx->nblk * 2);
-        d1.bst_y = nx->y; d1.bst_k = nx->k; d1.bst_slope = nx->slope; d1.stat_partials = nx->part;
+        nx->out.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W);
+        nx->out.part = A.alloc((size_t)N * C * nx->out.nblk * 2);
+        nx->out.coef = A.alloc((size_t)N * C * 3);
+        d1.bst_y = nx->y; d1.bst_k = nx->k; d1.bst_slope = nx->slope; d1.stat_partials = nx->out.part;
+        if (!A.dry && h->tails() && nx->g) {
+            fill_bwd_tail(h, d1.fin, nx->out, *nx->g, nx->gamma, nx->dgamma, nx->dbeta, N, C, V, 1);
+            nx->out.done = true;
+        }
     }
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
@@ -918,7 +974,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const int Cp = bp.cin_down;
     {
         Wgrad1Args w{};
-        w.x = c16 ? sv.xprev : sv.xs2d; w.dy = dx; w.dw = G(h, grads, bp.down); w.ldw = 8 * Cp; w.c16 = c16; w.tap_split = c16 ? Cp : 0;
+        w.x = c16 ? sv.xprev : sv.xs2d; w.dy = dx; w.dw = G(h, grads, bp.down); w.ldw = 8 * Cp; w.c16 = c16; w.tap_split = c16 ? Cp : 0; w.defer = red_for(s);
         if (c16) { w.s2d = 1; w.Dc = D; w.Hc = H; w.Wc = W; }
         w.ws_bytes = wgrad1_workspace_bytes(N, 8 * Cp, C, V);
         w.ws = A.alloc(w.ws_bytes / sizeof(float));
@@ -983,12 +1039,17 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // the head's data gradient is the gradient entering norm2 of the last decoder block: its GroupNorm-backward sums are taken here
     const bool no_bst = !(h->fusion & RU_FUSE_GN_BWD_STATS);
     const BlockSave* hb = (depth >= 2 && !h->dec_s[0].empty()) ? &h->dec_s[0].back() : nullptr;
-    float* hpart = nullptr;
-    int hnblk = 0;
+    FusedSums hsums;
     if (head4 && hb && !no_bst && conv3_sb_bst_usable(N, C0, Dl[0], Hl[0], Wl[0])) {
-        hnblk = conv3_sb_tiles_per_sample(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);
-        hpart = A.alloc((size_t)N * C0 * hnblk * 2);
-        dh.bst_y = hb->y2; dh.bst_k = hb->g2.k; dh.bst_slope = kSlope; dh.stat_partials = hpart;
+        hsums.nblk = conv3_sb_tiles_per_sample(N, h->nout, C0, Dl[0], Hl[0], Wl[0]);
+        hsums.part = A.alloc((size_t)N * C0 * hsums.nblk * 2);
+        hsums.coef = A.alloc((size_t)N * C0 * 3);
+        dh.bst_y = hb->y2; dh.bst_k = hb->g2.k; dh.bst_slope = kSlope; dh.stat_partials = hsums.part;
+        if (!A.dry && h->tails()) {
+            const BlockP& lb = *hb->bp;
+            fill_bwd_tail(h, dh.fin, hsums, hb->g2, P(h, params, lb.n2w), G(h, grads, lb.n2w), G(h, grads, lb.n2b), N, C0, Vl(0), 1);
+            hsums.done = true;
+        }
     }
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
@@ -996,8 +1057,8 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // decoder stages, reverse of execution order (forward ran i = depth-2 .. 0)
     for (int i = 0; i <= depth - 2; ++i) {
         for (int j = (int)h->dec_s[i].size() - 1; j >= 0; --j) {
-            const bool fused2 = hnblk > 0 && i == 0 && j == (int)h->dec_s[i].size() - 1;
-            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur, nullptr, nullptr, fused2 ? hpart : nullptr, fused2 ? hnblk : 0);
+            const bool fused2 = hsums.nblk > 0 && i == 0 && j == (int)h->dec_s[i].size() - 1;
+            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur, nullptr, nullptr, fused2 ? &hsums : nullptr);
             if (rc) return rc;
         }
         const DecSave& ds = h->dstage[i];
@@ -1008,7 +1069,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         float* gdec = G(h, grads, h->dec1_w[i]);
         if (c16) {                                               // one pass over dcur for both halves of the (never materialised) concat
             Wgrad1Args w{};
-            w.x = ds.skip; w.x1 = ds.v; w.C0 = Ci; w.dy = dcur; w.dw = gdec; w.ldw = 2 * Ci; w.c16 = 1;
+            w.x = ds.skip; w.x1 = ds.v; w.C0 = Ci; w.dy = dcur; w.dw = gdec; w.ldw = 2 * Ci; w.c16 = 1; w.defer = red_for(s);
             w.ws_bytes = wgrad1_workspace_bytes(N, 2 * Ci, Ci, V);
             w.ws = A.alloc(w.ws_bytes / sizeof(float));
             w.N = N; w.Cin = 2 * Ci; w.Cout = Ci; w.V = V;
@@ -1068,15 +1129,20 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // encoder levels, deepest first; the skip gradient joins at each level's input
     for (int i = depth - 2; i >= 0; --i) {
         bool joined = false;
-        float* pnext = nullptr;                                  // sums of the NEXT block's norm2, taken by this block's last conv
-        int nnext = 0;
+        FusedSums snext;                                         // sums of the NEXT block's norm2, taken by this block's last conv
         for (int j = (int)h->enc_s[i].size() - 1; j >= 0; --j) {
-            GNNext nx{nullptr, nullptr, kSlope, nullptr, 0};
-            if (j >= 1 && h->enc_s[i][j - 1].g2.k) { nx.y = h->enc_s[i][j - 1].y2; nx.k = h->enc_s[i][j - 1].g2.k; }
-            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr, pnext, nnext,
+            GNNext nx{};
+            nx.slope = kSlope;
+            if (j >= 1 && h->enc_s[i][j - 1].g2.k) {
+                const BlockSave& pb = h->enc_s[i][j - 1];
+                nx.y = pb.y2; nx.k = pb.g2.k; nx.g = &pb.g2;
+                nx.gamma = P(h, params, pb.bp->n2w); nx.dgamma = G(h, grads, pb.bp->n2w); nx.dbeta = G(h, grads, pb.bp->n2b);
+            }
+            const FusedSums sin = snext;
+            rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr, sin.nblk > 0 ? &sin : nullptr,
                            (nx.y || A.dry) && j >= 1 ? &nx : nullptr);
             if (rc) return rc;
-            pnext = nx.part; nnext = nx.nblk;
+            snext = nx.out;
         }
         if (!joined) {
             float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
@@ -1084,16 +1150,23 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             dcur = sum;
         }
     }
-    float* pfirst = nullptr;
-    int nfirst = 0;
+    FusedSums sfirst;
     for (int j = (int)h->first_s.size() - 1; j >= 0; --j) {
         // the gradient a first-level block produces enters norm2 of the block before it, or (j = 0) norm_input (no activation: slope 1)
-        GNNext nx{nullptr, nullptr, j >= 1 ? kSlope : 1.0f, nullptr, 0};
-        if (j >= 1) { nx.y = h->first_s[j - 1].y2; nx.k = h->first_s[j - 1].g2.k; }
-        else { nx.y = h->y0; nx.k = h->g0.k; }
-        rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur, nullptr, nullptr, pfirst, nfirst, (nx.k || A.dry) ? &nx : nullptr);
+        GNNext nx{};
+        nx.slope = j >= 1 ? kSlope : 1.0f;
+        if (j >= 1) {
+            const BlockSave& pb = h->first_s[j - 1];
+            nx.y = pb.y2; nx.k = pb.g2.k; nx.g = &pb.g2;
+            nx.gamma = P(h, params, pb.bp->n2w); nx.dgamma = G(h, grads, pb.bp->n2w); nx.dbeta = G(h, grads, pb.bp->n2b);
+        } else {
+            nx.y = h->y0; nx.k = h->g0.k; nx.g = &h->g0;
+            nx.gamma = P(h, params, h->nin_w); nx.dgamma = G(h, grads, h->nin_w); nx.dbeta = G(h, grads, h->nin_b);
+        }
+        const FusedSums sin = sfirst;
+        rc = block_bwd(h, params, grads, A, s, h->first_s[j], dcur, &dcur, nullptr, nullptr, sin.nblk > 0 ? &sin : nullptr, (nx.k || A.dry) ? &nx : nullptr);
         if (rc) return rc;
-        pfirst = nx.part; nfirst = nx.nblk;
+        sfirst = nx.out;
     }
     // norm_input (no activation: slope 1) and conv_input
     t_hint_c = C0;
@@ -1107,7 +1180,7 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // a stem wider than 16 channels: its weight gradient is the generic mixed-layout kernel (x NCDHW, dy voxel-major float32), which does
     // not read the split form
     const bool split0 = c16 && C0 <= 16;
-    rc = gn_bwd(c16, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), pfirst, nfirst,
+    rc = gn_bwd(h, A, s, h->y0, dcur, h->g0, P(h, params, h->nin_w), 1.0f, dy0, G(h, grads, h->nin_w), G(h, grads, h->nin_b), N, C0, Vl(0), sfirst.nblk > 0 ? &sfirst : nullptr,
                 fuse0 ? &coef0 : nullptr, split0);
     if (rc) return rc;
     const GbApply gb0{h->y0, dcur, &h->g0, coef0};
@@ -1128,7 +1201,9 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
         di.x = dy0; di.wp = wpd; di.y = dx_in; di.N = N; di.Cin = C0; di.Cout = kInCh; di.D = Dl[0]; di.H = Hl[0]; di.W = Wl[0];
         RU_RUN(conv3_launch(di, s));
     }
+    if (t_red && !t_red->side.e.empty()) RU_RUN(wgrad_reduce_flush(t_red->side, h->side));   // (stream order on the side stream: behind its weight-gradient kernels)
     if (!A.dry) { rc = side_join(h, s); if (rc) return rc; }     // the caller's stream sees every gradient
+    if (t_red && !t_red->main.e.empty()) RU_RUN(wgrad_reduce_flush(t_red->main, s));         // every other queued partial-sum reduction, one launch
     return RU_OK;
 }
 
@@ -1145,7 +1220,8 @@ extern "C" size_t ru_unet_workspace_bytes(ru_unet_t h, int N, int D, int H, int 
     tmp.probe_ev.clear();        // (the copy must not own the handle's HIP events: its destructor would destroy them)
     tmp.probe_on = false;
     tmp.sink = nullptr;
-    tmp.side = nullptr;          // (nor its side stream / events)
+    tmp.side = nullptr;          // (nor its side stream / events / tickets)
+    tmp.tickets = nullptr;
     tmp.fork_ev.clear();
     tmp.N = N; tmp.D = D; tmp.H = H; tmp.W = W; tmp.training = training != 0;
     Arena A;
@@ -1167,6 +1243,12 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     h->ws = (char*)ws; h->ws_bytes = ws_bytes;
     Arena A;
     A.dry = false; A.base = (char*)ws; A.cap = ws_bytes;
+    if (!h->tickets && (h->fusion & RU_FUSE_TAIL_FINALIZE)) {    // once per handle (a warm-up call, like the side stream and the events)
+        hipError_t e = hipMalloc((void**)&h->tickets, 256 * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(h->tickets, 0, 256 * sizeof(unsigned));
+        if (e != hipSuccess) { h->tickets = nullptr; return hip_fail(e, "ru_unet_forward: ticket words"); }
+    }
+    h->ticket_next = 0;
     ru::t_sink = h->probe_families ? h->sink : nullptr;
     rc = unet_forward_impl(h, params, x, probs, A, (hipStream_t)stream);
     ru::t_sink = nullptr;
@@ -1184,8 +1266,16 @@ extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* d
     Arena A;
     A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end; A.keep = h->fwd_keep;
     ru::t_sink = h->probe_families ? h->sink : nullptr;
+    h->red.main.e.clear();
+    h->red.side.e.clear();
+    ru::t_red = (h->fusion & RU_FUSE_BATCH_WREDUCE) && !trace_on() ? &h->red : nullptr;
     int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream);
+    ru::t_red = nullptr;
     ru::t_sink = nullptr;
+    if (rc && h->side) {                                 // an error return must not leave the side stream running behind the caller's back
+        (void)side_join(h, (hipStream_t)stream);
+        h->fork_used = 0;
+    }
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_backward: workspace too small"); return RU_ENOMEM; }
     return RU_OK;

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }
 int sum_partials_launch(const float* part, int ksplit, size_t n, float* y, hipStream_t s) {
     RU_REQUIRE(part && y && ksplit >= 1, "sum_partials: bad argument");
+    RU_REQUIRE(ksplit == 1 || (n & 3) == 0, "sum_partials: partial tensors of %zu floats are not 16-byte aligned to each other", n);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(grid1d(n, 256 * 4, 2048)), dim3(256), 0, s, part, ksplit, n, y);
     RU_CHECK_LAUNCH("sum_partials_kernel");
     return RU_OK;

@@ -8,6 +8,7 @@
 // cb*16 + 4*(f&3) .. +3.  Grid strides are multiples of 4, so a thread keeps its channel quad and loads the per-channel
 // parameters once.
 #include "pw_helpers.hpp"
+#include "fin_tail.hpp"
 
 namespace ru {
 
@@ -76,8 +77,10 @@ int gn_bwd_tiles16(size_t V) { const int ch = gn16_chunk(V); return (int)((V + c
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk, int chunk) {
-    __shared__ float red[4][16][2];
+                                                              float slope, float* __restrict__ partials, int C, size_t V, int G, int nblk, int chunk,
+                                                              const FinTail fin) {
+    extern __shared__ __attribute__((aligned(16))) float red_dyn[];      // [4][16][2] floats, then the tail's scratch
+    float (*red)[16][2] = reinterpret_cast<float (*)[16][2]>(red_dyn);
     const int nb = blockIdx.y, CB = C >> 4;
     const int n = nb / CB, cb = nb - n * CB;
     const int q = threadIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,15 +121,20 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce16_kernel(const float* __res
     if (threadIdx.x < 16) {
         const int c = threadIdx.x;
         float* p = partials + (((size_t)n * C + cb * 16 + c) * nblk + blockIdx.x) * 2;
-        p[0] = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
-        p[1] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+        stat_publish(p, (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]), (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]));
     }
+    fin_tail(fin, partials, red_dyn + 128);              // RU_FUSE_TAIL_FINALIZE: the last workgroup writes coef / dgamma / dbeta
 }
 int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
-                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s) {
+                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s, const FinTail* fin) {
     RU_REQUIRE(C % 16 == 0 && C % G == 0, "gn_bwd_reduce16: bad channel count");
     const int nblk = gn_bwd_tiles16(V);
-    hipLaunchKernelGGL(gn_bwd_reduce16_kernel, dim3(nblk, N * (C / 16)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk, gn16_chunk(V));
+    FinTail f{};
+    if (fin) f = *fin;
+    RU_REQUIRE(!f.ticket || (f.kind == 2 && f.nblk == nblk && f.N == N && f.C == C && f.G == G), "gn_bwd_reduce16: tail descriptor does not match the launch");
+    const size_t lds = 512 + fin_tail_lds_bytes(f);
+    RU_REQUIRE(lds <= 64 * 1024, "gn_bwd_reduce16: batch x channels too large for the in-launch finalize");
+    hipLaunchKernelGGL(gn_bwd_reduce16_kernel, dim3(nblk, N * (C / 16)), dim3(256), lds, s, x, dy, scale, shift, mean, rstd, slope, partials, C, V, G, nblk, gn16_chunk(V), f);
     RU_CHECK_LAUNCH("gn_bwd_reduce16_kernel");
     return RU_OK;
 }

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <vector>
+
 #include "../../include/resunet_hip.h"
 
 namespace ru {
@@ -71,6 +73,33 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
+// ------------------------------------------------------------------ in-launch finalization of partial sums (fin_tail.hpp)
+// RU_FUSE_TAIL_FINALIZE: the kernel that writes the per-workgroup partial sums of a GroupNorm (forward statistics, or the two sums of its
+// backward) also finalizes them -- its LAST workgroup to finish (one integer ticket, agent scope, reset by the finisher so that the
+// launch can be replayed from a hipGraph) reads all partials back in a fixed order and writes what the separate finalize kernels
+// (gn_finalize_kernel / gn_bwd_finalize_kernel) wrote.  No float atomics: the result does not depend on who finishes last.
+// Partials are published with 8-byte agent-scope stores and read with agent-scope loads (per-XCD L2s are not coherent with each other).
+struct FinTail {
+    unsigned* ticket;        // null: no tail (the caller launches the finalize kernel)
+    int kind;                // 1: (sum, sumsq) -> mean / rstd / scale / shift (/ bst_k); 2: GroupNorm-backward sums -> coef / dgamma / dbeta
+    int nblk, N, C, G;       // partials [N][C][nblk][2]
+    size_t V;
+    float eps;
+    int s2_sign;             // kind 2: the second sum carries sign(gamma) (fused conv statistics, Conv3Args::bst_*)
+    const float* gamma;
+    const float* beta;       // kind 1
+    float* mean;             // kind 1: out; kind 2: in
+    float* rstd;
+    float* scale;            // kind 1
+    float* shift;
+    float* bst_k;            // kind 1, optional
+    float* coef;             // kind 2
+    float* dgamma;
+    float* dbeta;
+};
+// LDS scratch the tail needs at the pointer handed to fin_tail(): the flag, plus S[N][C][2] doubles for kind 2
+static inline size_t fin_tail_lds_bytes(const FinTail& f) { return 16 + ((f.ticket && f.kind == 2) ? (size_t)f.N * f.C * 16 : 0); }
+
 // ------------------------------------------------------------------ conv 3x3x3 (conv3_f32.hip)
 // Implicit GEMM on v_mfma_f32_16x16x4_f32.  Weights must be PACKED: wp[tap][CinP][CoutP] (K-major).
 struct Conv3Args {
@@ -110,6 +139,7 @@ struct Conv3Args {
     // writes its partial OUTPUT tensor to y + z * N * Cout * D * H * W (z = 0 .. ksplit-1; plain epilogue: no statistics, bias, residual,
     // activation); sum_partials_launch adds them in z order.  0 / 1 = off.
     int ksplit;
+    FinTail fin;             // split-bf16 kernels: finalize stat_partials in the launch (ticket null = off)
 };
 int conv3_f32_ksplit(int N, int Cin, int Cout, int D, int H, int W);     // split factor the engine uses for an exact-f32 conv of this shape (1 = none)
 int sum_partials_launch(const float* part, int ksplit, size_t n, float* y, hipStream_t s);    // y[i] = part[0][i] + part[1][i] + ... (fixed order)
@@ -174,12 +204,19 @@ struct Wgrad3Args {
     // so the result is stored transposed with the taps mirrored (dw_cout / dw_cin then name the real channel counts of dy / x).  Used
     // for the head, whose output gradient has 3 channels: as the 4-channel x operand it takes the packed-tap form (wgrad3_tz XS == 2).
     int swapped;
+    struct WgradRedList* defer;   // non-null: the reduction of the partials is queued there instead of launched (wgrad_reduce_flush)
 };
 size_t wgrad3_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);     // max over both precisions
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s);
 // sum of `nparts` partial gradients [nparts][taps][CoP][CiP] into dw (fixed order; wgrad_f32.hip)
+// Deferred form: nobody reads a weight gradient before the optimizer, so the engine's backward queues the ~35 reductions of a step
+// (`defer` non-null) and runs them as ONE launch behind the last weight-gradient kernel (wgrad_reduce_flush): same kernel body, same
+// summation order, bit-identical results -- 35 latency-bound launches of 5-30 us each become one that fills the chip.
+struct WgradRedEntry { const float* partials; float* dw; int nparts, taps, CoP, CiP, Cout, Cin, so, sc, split, flip, lo, blk0; };
+struct WgradRedList { std::vector<WgradRedEntry> e; };
 int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s,
-                        int flip_taps = 0);
+                        int flip_taps = 0, WgradRedList* defer = nullptr);
+int wgrad_reduce_flush(WgradRedList& l, hipStream_t s);
 size_t wgrad3_sb_workspace_bytes(int N, int Cin, int Cout, int D, int H, int W);
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s);
 // both tensors voxel-major: transpose-read kernel (wgrad_tr.hip); workspace 0 if the channel counts do not fit
@@ -202,6 +239,7 @@ struct Wgrad1Args {
     int tap_split;           // > 0: the Cin index is tap*tap_split + c of a 2x2x2 conv: written to dw[o*ldw + c*8 + tap]
     const float* x1;         // c16 only, optional: input channels C0 .. Cin-1 live in this second tensor (a channel concat that was never made)
     int C0;                  // channels of x when x1 is set (multiple of 16)
+    struct WgradRedList* defer;   // as Wgrad3Args::defer
 };
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s);
@@ -283,7 +321,7 @@ int gn_apply16_launch(const float* x, const float* scale, const float* shift, co
                       const float* rscale = nullptr, const float* rshift = nullptr, float rslope = 1.f);   // optional: residual = lrelu(res*rscale + rshift)
 int gn_bwd_tiles16(size_t V);
 int gn_bwd_reduce16_launch(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
-                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s);
+                           float slope, float* partials, int N, int C, size_t V, int G, hipStream_t s, const FinTail* fin = nullptr);
 // split = 1: dx is written in SPLIT form -- per voxel and 16-channel block 64 bytes = [hi bf16 ch 0-7 | hi ch 8-15 | lo ch 0-7 | lo ch 8-15]
 // (hi = bf16(v), lo = bf16(v - hi)): exactly the packets the split-bf16 conv and weight-gradient kernels stage, so their producer
 // waves copy instead of converting (the conversion VALU work was what bounded the weight gradient).  Only MFMA kernels read it.

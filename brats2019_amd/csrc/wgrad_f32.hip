@@ -282,50 +282,101 @@ __global__ __launch_bounds__(512, 4) void wgrad3_f32_kernel(const Wgrad3Args a, 
 // combined in a fixed order through LDS: deterministic), so a 512-partial reduction is 128 loads deep instead of 512.
 // LO outputs per workgroup, 256 / LO slices of the partial range per output: few outputs with many partials (a 16x16 1x1x1
 // gradient has 1024) want narrow blocks -- 64-wide blocks left a 256-load dependent chain per thread on 4 workgroups.
-template <int LO>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int nparts, int taps, int CoP, int CiP,
-                                                           int Cout, int Cin, float* __restrict__ dw, int so, int sc, int split, int flip_taps) {
+// One entry's share of the work: workgroup `blk` of the entry's workgroups (wgrad_reduce_blocks).  VEC = 4: an item is four consecutive
+// input channels (one 16-byte load per partial: the rows [o][c] are contiguous and 64-byte aligned) -- the reduction is a stream of
+// 7-14 MB per weight gradient and was latency-bound on 4-byte loads; the per-element summation order is the scalar kernel's.
+template <int LO, int VEC>
+__device__ __forceinline__ void wgrad_reduce_body(const WgradRedEntry& e, int blk, float* red /* [256 * VEC] */) {
     constexpr int NS = 256 / LO;
-    __shared__ float red[NS][LO];
     const int lane_o = threadIdx.x % LO, slice = threadIdx.x / LO;
-    const int i = blockIdx.x * LO + lane_o;
-    const int total = taps * Cout * Cin;
+    const int i = blk * LO + lane_o;
+    const int CQ = e.Cin / VEC;
+    const int total = e.taps * e.Cout * CQ;
     const bool ok = i < total;
     const int ii = ok ? i : 0;
-    const int c = ii % Cin;
-    const int o = (ii / Cin) % Cout;
-    const int tap = ii / (Cin * Cout);
-    const size_t stride = (size_t)taps * CoP * CiP;
-    const float* p = partials + ((size_t)tap * CoP + o) * CiP + c;
-    const int per = (nparts + NS - 1) / NS;
-    const int k0 = slice * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int c = (ii % CQ) * VEC;
+    const int o = (ii / CQ) % e.Cout;
+    const int tap = ii / (CQ * e.Cout);
+    const size_t stride = (size_t)e.taps * e.CoP * e.CiP;
+    const float* p = e.partials + ((size_t)tap * e.CoP + o) * e.CiP + c;
+    const int per = (e.nparts + NS - 1) / NS;
+    const int k0 = slice * per, k1 = (k0 + per < e.nparts) ? k0 + per : e.nparts;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    auto ld = [&](int k) -> vec_t {
+        if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p + (size_t)k * stride); return vec_t{t.x, t.y, t.z, t.w}; }
+        else return vec_t{p[(size_t)k * stride]};
+    };
+    vec_t s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = k0;
     for (; k + 7 < k1; k += 8) {
-        const float t0 = p[(size_t)k * stride], t1 = p[(size_t)(k + 1) * stride], t2 = p[(size_t)(k + 2) * stride], t3 = p[(size_t)(k + 3) * stride];
-        const float t4 = p[(size_t)(k + 4) * stride], t5 = p[(size_t)(k + 5) * stride], t6 = p[(size_t)(k + 6) * stride], t7 = p[(size_t)(k + 7) * stride];
+        const vec_t t0 = ld(k), t1 = ld(k + 1), t2 = ld(k + 2), t3 = ld(k + 3), t4 = ld(k + 4), t5 = ld(k + 5), t6 = ld(k + 6), t7 = ld(k + 7);
         s0 += t0; s1 += t1; s2 += t2; s3 += t3;
         s0 += t4; s1 += t5; s2 += t6; s3 += t7;
     }
-    for (; k < k1; ++k) s0 += p[(size_t)k * stride];
-    red[slice][lane_o] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    // split > 0: c = t*split + ci enumerates (tap t, channel ci) of a 2x2x2 conv whose gradient layout is [o][ci][8]
-    // flip_taps: the partials were computed with the operands exchanged (tap t there is tap taps-1-t of the convolution)
-    const size_t dst = split > 0 ? (size_t)o * so + (size_t)(c % split) * 8 + c / split : (size_t)o * so + (size_t)c * sc + (flip_taps ? taps - 1 - tap : tap);
-    if (slice == 0 && ok) {
-        float t = 0.f;
+    for (; k < k1; ++k) s0 += ld(k);
+    const vec_t sum = (s0 + s1) + (s2 + s3);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) t += red[j][lane_o];
-        dw[dst] = t;
+    for (int j = 0; j < VEC; ++j) red[(slice * LO + lane_o) * VEC + j] = sum[j];
+    __syncthreads();
+    if (slice == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) t += red[(q * LO + lane_o) * VEC + j];
+            const int cj = c + j;
+            // split > 0: c = t*split + ci enumerates (tap t, channel ci) of a 2x2x2 conv whose gradient layout is [o][ci][8]
+            // flip: the partials were computed with the operands exchanged (tap t there is tap taps-1-t of the convolution)
+            const size_t dst = e.split > 0 ? (size_t)o * e.so + (size_t)(cj % e.split) * 8 + cj / e.split
+                                           : (size_t)o * e.so + (size_t)cj * e.sc + (e.flip ? e.taps - 1 - tap : tap);
+            e.dw[dst] = t;
+        }
     }
 }
-// fixed summation order for a given (nparts, shape): deterministic
-int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s, int flip_taps) {
-    const int total = taps * Cout * Cin;
-    if (nparts >= 128) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(cdiv(total, 16)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split, flip_taps);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(cdiv(total, 64)), dim3(256), 0, s, partials, nparts, taps, CoP, CiP, Cout, Cin, dw, so, sc, split, flip_taps);
+static inline int wgrad_reduce_vec(const WgradRedEntry& e) { return (e.Cin % 4 == 0 && e.CiP % 4 == 0 && ((size_t)e.partials & 15) == 0) ? 4 : 1; }
+static inline int wgrad_reduce_blocks(const WgradRedEntry& e) { return cdiv(e.taps * e.Cout * (e.Cin / wgrad_reduce_vec(e)), e.lo); }
+__device__ __forceinline__ void wgrad_reduce_dispatch(const WgradRedEntry& e, int blk, float* red) {
+    const bool v4 = (e.Cin % 4 == 0 && e.CiP % 4 == 0 && ((size_t)e.partials & 15) == 0);       // (wgrad_reduce_vec)
+    if (e.lo == 16) { if (v4) wgrad_reduce_body<16, 4>(e, blk, red); else wgrad_reduce_body<16, 1>(e, blk, red); }
+    else { if (v4) wgrad_reduce_body<64, 4>(e, blk, red); else wgrad_reduce_body<64, 1>(e, blk, red); }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradRedEntry e) {
+    __shared__ float red[256 * 4];
+    wgrad_reduce_dispatch(e, blockIdx.x, red);
+}
+// the queued reductions of a backward pass in one launch: entry i owns workgroups [blk0_i, blk0_{i+1})
+constexpr int RU_RED_BATCH = 48;                     // 48 x 72 bytes of kernel arguments
+struct WgradRedBatch { WgradRedEntry e[RU_RED_BATCH]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradRedBatch b) {
+    __shared__ float red[256 * 4];
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.e[i + 1].blk0) ++i;          // (scalar loop over kernel arguments)
+    wgrad_reduce_dispatch(b.e[i], blockIdx.x - b.e[i].blk0, red);
+}
+// fixed summation order for a given (nparts, shape): deterministic.  LO outputs per workgroup: 16 for long partial lists, 64 otherwise.
+int wgrad_reduce_launch(const float* partials, int nparts, int taps, int CoP, int CiP, int Cout, int Cin, float* dw, int so, int sc, int split, hipStream_t s, int flip_taps,
+                        WgradRedList* defer) {
+    const WgradRedEntry e{partials, dw, nparts, taps, CoP, CiP, Cout, Cin, so, sc, split, flip_taps, nparts >= 128 ? 16 : 64, 0};
+    if (defer) { defer->e.push_back(e); return RU_OK; }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(e)), dim3(256), 0, s, e);
     RU_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return RU_OK;
+}
+int wgrad_reduce_flush(WgradRedList& l, hipStream_t s) {
+    for (size_t i0 = 0; i0 < l.e.size(); i0 += RU_RED_BATCH) {
+        WgradRedBatch b;
+        b.n = (int)(l.e.size() - i0 < (size_t)RU_RED_BATCH ? l.e.size() - i0 : (size_t)RU_RED_BATCH);
+        int blk = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.e[i] = l.e[i0 + i];
+            b.e[i].blk0 = blk;
+            blk += wgrad_reduce_blocks(b.e[i]);
+        }
+        for (int i = b.n; i < RU_RED_BATCH; ++i) b.e[i] = b.e[0];
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blk), dim3(256), 0, s, b);
+        RU_CHECK_LAUNCH("wgrad_reduce_batch_kernel");
+    }
+    l.e.clear();
     return RU_OK;
 }
 
@@ -374,7 +425,7 @@ static int wgrad3_cfg(const Wgrad3Args& a, const W3Choice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_f32_kernel<TZ, TY, OT, CT>), grid, dim3(512), lds, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, TY), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_f32_kernel");
-    return wgrad_reduce_launch((const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s);
+    return wgrad_reduce_launch((const float*)a.ws, (OT == 2 ? 1 : 2) * c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s, 0, a.defer);
 }
 
 int wgrad3_launch(const Wgrad3Args& a, hipStream_t s) {
@@ -722,7 +773,7 @@ static int wgrad1_cfg(const Wgrad1Args& a, const W1Choice& c, hipStream_t s) {
     const int CoP = round_up(a.Cout, 16), CiP = round_up(a.Cin, 16);
     hipLaunchKernelGGL((wgrad1_f32_kernel<OT, CT>), dim3(c.nbx, c.ngroups), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad1_f32_kernel");
-    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 1, CoP, CiP, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s);
+    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 1, CoP, CiP, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s, 0, a.defer);
 }
 
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
@@ -746,7 +797,7 @@ int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
         const int nbx = wgrad1_s2d_nbx(a.N, a.Cin, a.Cout, a.V), ncgb = a.Cin / (W1S_NG * 32);
         hipLaunchKernelGGL(wgrad1_s2d_kernel, dim3(nbx, (a.Cout / 32) * ncgb), dim3(256), lds, s, a, (float*)a.ws, c.nchunk, ncgb, a.Cout, a.Cin);
         RU_CHECK_LAUNCH("wgrad1_s2d_kernel");
-        return wgrad_reduce_launch((const float*)a.ws, nbx, 1, a.Cout, a.Cin, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s);
+        return wgrad_reduce_launch((const float*)a.ws, nbx, 1, a.Cout, a.Cin, a.Cout, a.Cin, a.dw, a.ldw, 1, a.tap_split, s, 0, a.defer);
     }
     if (c.ot == 2 && c.ct == 2) return wgrad1_cfg<2, 2>(a, c, s);
     if (c.ot == 2) return wgrad1_cfg<2, 1>(a, c, s);

@@ -367,7 +367,7 @@ static int wsb_cfg(const Wgrad3Args& a, const WSBChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_sb_kernel<TZ, 4, OT, X16, DY16>), dim3(c.nbx, c.ngroups), dim3(256), P::LDS_BYTES, s, a, (float*)a.ws,
                        cdiv(a.D, TZ), cdiv(a.H, 4), cdiv(a.W, 16), c.ncg, CoP, CiP);
     RU_CHECK_LAUNCH("wgrad3_sb_kernel");
-    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s);
+    return wgrad_reduce_launch((const float*)a.ws, c.nbx, 27, CoP, CiP, a.Cout, a.Cin, a.dw, a.Cin * 27, 27, 0, s, 0, a.defer);
 }
 
 int wgrad3_sb_launch(const Wgrad3Args& a, hipStream_t s) {

@@ -481,8 +481,8 @@ static int wtz_cfg(const Wgrad3Args& a, const WTRChoice& c, hipStream_t s) {
     hipLaunchKernelGGL((wgrad3_tz_kernel<OT, XS, DS, NP>), dim3(nbx, c.ngroups), dim3(512), P::LDS, s, a, (float*)a.ws, ntz, nty, ntx, c.ncg, a.Cout, a.Cin);
     RU_CHECK_LAUNCH("wgrad3_tz_kernel");
     const int co = a.dw_cout > 0 ? a.dw_cout : a.Cout, ci = a.dw_cin > 0 ? a.dw_cin : a.Cin;
-    if (a.swapped) return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, 27, co * 27, 0, s, 1);   // dw[cout = c'][cin = o'][26 - t]
-    return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s);
+    if (a.swapped) return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, 27, co * 27, 0, s, 1, a.defer);   // dw[cout = c'][cin = o'][26 - t]
+    return wgrad_reduce_launch((const float*)a.ws, nbx, 27, a.Cout, a.Cin, co, ci, a.dw, ci * 27, 27, 0, s, 0, a.defer);
 }
 
 int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {

@@ -85,10 +85,13 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_grad_precision(self.h, L.GRAD_PRECISIONS[grad_precision]), "ru_unet_set_grad_precision")
         self.grad_precision = grad_precision
 
-    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True, side_stream=True):
-        """Backward-pass fusions of the voxel-major engine (ru_unet_set_fusion; both on by default, tests switch them off to hold the
-        fused kernels to the separate passes)."""
-        mask = (L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0) | (L.FUSE_SIDE_STREAM if side_stream else 0)
+    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True, side_stream=True, batch_wreduce=True, tail_finalize=False):
+        """Fusions of the voxel-major engine (ru_unet_set_fusion; tests switch them off to hold the fused kernels to the separate
+        passes).  batch_wreduce: one launch sums the partials of every weight gradient of a backward pass; tail_finalize (opt-in: measured
+        slower than the finalize launches it replaces): GroupNorm statistics / backward coefficients are finalized
+        by the last workgroup of the producing kernel."""
+        mask = ((L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0) | (L.FUSE_SIDE_STREAM if side_stream else 0) |
+                (L.FUSE_BATCH_WREDUCE if batch_wreduce else 0) | (L.FUSE_TAIL_FINALIZE if tail_finalize else 0))
         L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
         self._ws_key = None                    # the backward's workspace layout depends on it
 

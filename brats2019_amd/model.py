@@ -318,6 +318,15 @@ class UNet(nn.Module):
             self.__dict__["_flat_buf"] = flat
         return flat
 
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel over SEVERAL devices replicates the module per step (main.py:61 with --gpus > 1).  The executor's state (flat
+        # parameter buffer, workspace, HIP handle) belongs to one device: data parallelism here is one process per GPU (INTEGRATION.md,
+        # "Data parallel").  A single-device wrap -- nn.DataParallel(net, device_ids=[0]), the reference's default --gpus 1, and what its
+        # checkpoints pickle -- never replicates and works unchanged.
+        raise RuntimeError("brats2019_amd.model.UNet: nn.DataParallel over several devices is replaced by one process per GPU "
+                           "(python -m torch.distributed.run --nproc-per-node N ...; INTEGRATION.md 'Data parallel'); "
+                           "a single-device wrap (device_ids=[0]) works as in the reference")
+
     def __getstate__(self):
         state = self.__dict__.copy()
         for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads"):     # never pickle the ctypes handle / the alias buffer

@@ -54,7 +54,7 @@ class Adam(torch.optim.Optimizer):
         the moments become views of flat buffers covering the same span at the same offsets (existing state is copied in)."""
         plan = self._flat.get(gi)
         params = [p for p in group["params"]]
-        sig = tuple(p.data_ptr() for p in params)
+        sig = (bool(group["amsgrad"]),) + tuple((p.data_ptr(), p.dtype, p.device) for p in params)     # (a flipped amsgrad flag needs the third buffer)
         if plan is not None and plan["sig"] == sig:
             return plan
         for p in params:

@@ -141,8 +141,10 @@ class RcclComm:
         try:
             for t in tensors:
                 self.all_reduce(t)
-        finally:
-            L.check(lib.ru_comm_group_end(), "ru_comm_group_end")
+        except BaseException:
+            lib.ru_comm_group_end()              # close the group, but let the ORIGINAL error travel (its message names the failing call)
+            raise
+        L.check(lib.ru_comm_group_end(), "ru_comm_group_end")
 
     def close(self):
         from . import _lib as L
@@ -175,6 +177,7 @@ class DataParallelStep:
         self.group = process_group
         self.global_step = 0
         self.comm = comm                       # RcclComm: the collectives go through ru_allreduce on the kernels' stream
+        self.comm_probe = None                 # bench.py: a list -> every collective of a step is bracketed by an event pair on the current stream
         if comm is not None:
             self.distributed, self.world, self.rank = True, comm.world, comm.rank
         else:
@@ -217,17 +220,29 @@ class DataParallelStep:
         self.last_probs = probs
         return loss, dice, bce
 
+    def _probed(self, what, fn):
+        """comm_probe: (name, begin, end) event triples around the collective on the stream of the kernels.  With torch.distributed the
+        collective runs on the process group's own stream, which waits for this one and which this one waits for: the pair spans
+        exactly the collective (plus the two stream hand-offs)."""
+        if self.comm_probe is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.comm_probe.append((what, e0, e1))
+
     def _all_reduce(self, t):
         if self.comm is not None:
-            self.comm.all_reduce(t)
+            self._probed("criterion_sums" if t.numel() < 64 else "gradients", lambda: self.comm.all_reduce(t))
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._probed("criterion_sums" if t.numel() < 64 else "gradients", lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
 
     def _all_reduce_many(self, tensors):
         if self.comm is not None:
-            self.comm.all_reduce_many(tensors)
+            self._probed("gradients", lambda: self.comm.all_reduce_many(tensors))
         else:
-            all_reduce_coalesced(tensors, self.group)
+            self._probed("gradients", lambda: all_reduce_coalesced(tensors, self.group))
 
     def step(self, x_shard, target_shard):
         loss, dice, bce = self.loss_and_grads(x_shard, target_shard)
@@ -253,9 +268,19 @@ def all_reduce_coalesced(tensors, group=None):
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return
-    with dist._coalescing_manager(group=group):
-        for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    cm = getattr(dist, "_coalescing_manager", None)      # private API (its signature moved between torch 2.x releases): optional
+    if cm is not None:
+        try:
+            ctx = cm(group=group)
+        except TypeError:
+            ctx = None
+        if ctx is not None:
+            with ctx:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return
+    for t in tensors:                                    # fall-back: one collective per run (same result)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def world_info(group=None):

@@ -29,15 +29,39 @@ def copy_back_tiles(data, tiles, center_shape, index_mins, border):
     return ops.tile_scatter(data, tiles, [tuple(int(v) for v in lo) for lo in index_mins], border, center_shape)
 
 
+def _device_kernels_apply(data, tile_shape):
+    # ru_tile_gather / ru_tile_scatter move float4 pieces of device rows: a host tensor or a tile width that is not a multiple of 4
+    # takes the index arithmetic of loader_helper.py:42-97 on torch slices instead (host-side helper use, e.g. a CPU label volume)
+    return data.is_cuda and data.dtype == torch.float32 and int(tile_shape[-1]) % 4 == 0
+
+
 def copy(data, tile_shape, index_min, index_max):
     """loader_helper.py:42-60: zero-padded extract data[:, :, min:max] -> [N,C,*tile_shape]."""
     assert all(int(b) - int(a) == int(t) for a, b, t in zip(index_min, index_max, tile_shape))
-    return copy_tiles(data, tile_shape, [index_min])
+    if _device_kernels_apply(data, tile_shape):
+        return copy_tiles(data, tile_shape, [index_min])
+    out = data.new_zeros(tuple(data.shape[:2]) + tuple(int(t) for t in tile_shape))
+    src, dst = [slice(None), slice(None)], [slice(None), slice(None)]
+    for a, b, n in zip(index_min, index_max, data.shape[2:]):
+        lo, hi = max(int(a), 0), min(int(b), int(n))
+        src.append(slice(lo, hi))
+        dst.append(slice(lo - int(a), hi - int(a)))
+    out[tuple(dst)] = data[tuple(src)]
+    return out
 
 
 def copy_back(data, tile, center_shape, index_min, index_max, border):
     """loader_helper.py:82-97: paste the tile's centre block into `data`, clipped at the volume end."""
-    copy_back_tiles(data, tile.to(data.device), center_shape, [index_min], border)
+    if _device_kernels_apply(data, tile.shape[2:]):
+        copy_back_tiles(data, tile.to(data.device), center_shape, [index_min], border)
+        return
+    src, dst = [slice(None), slice(None)], [slice(None), slice(None)]
+    for a, c, b, n in zip(index_min, center_shape, border, data.shape[2:]):
+        lo = int(a) + int(b)                                 # first voxel of the centre block in the volume
+        hi = min(lo + int(c), int(n))
+        dst.append(slice(lo, hi))
+        src.append(slice(int(b), int(b) + hi - lo))
+    data[tuple(dst)] = tile.to(data.device)[tuple(src)]
 
 
 def grid_for(shape, center_shape):

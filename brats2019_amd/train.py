@@ -155,10 +155,14 @@ class Trainer(object):
             # main.py:134 passes the CLASS torch.optim.Adam: on the HIP path it is instantiated as brats2019_amd.optim.Adam -- the same
             # torch.optim.Optimizer surface and state_dict() layout (a checkpoint of either resumes under the other, train.py:92-94),
             # with the update as one ru_adam_step launch per contiguous run of the flat parameter buffer.  `hip_optimizer = False` keeps torch's.
+            made = None
             if optimizer is torch.optim.Adam and self.hip_optimizer and self.state.cuda:
                 from . import optim as hip_optim
-                optimizer = hip_optim.Adam
-            optimizer = optimizer(params=self.model.parameters(), **optimizer_params)
+                try:
+                    made = hip_optim.Adam(params=self.model.parameters(), **optimizer_params)
+                except NotImplementedError:              # options only torch's own Adam takes (fused=, foreach=, ...): keep the caller's class
+                    made = None
+            optimizer = made if made is not None else optimizer(params=self.model.parameters(), **optimizer_params)
         if scheduler is not None and isinstance(scheduler, type):
             scheduler = scheduler(optimizer=optimizer, **scheduler_params)
         assert isinstance(optimizer, torch.optim.Optimizer)
@@ -370,13 +374,22 @@ class Trainer(object):
         s = torch.load(self._ckpt(suffix), map_location=torch.device("cpu"), weights_only=False)
         self.state = s["state"]
         if self.model is None:
-            self.model = s["model"]
+            self.model = s["model"]                    # train.py:329-330: the pickled module, wrapper included
+            if isinstance(self.model, torch.nn.DataParallel) and len(self.model.device_ids or []) > 1:
+                # saved by the reference under --gpus > 1 (main.py:61): the several-device wrapper would scatter over GPUs this process
+                # does not own -- data parallelism is one process per GPU here -- so the module itself is kept (a single-device wrapper
+                # stays as pickled)
+                print("checkpoint holds nn.DataParallel over %d devices: using its .module (one process per GPU)" % len(self.model.device_ids))
+                self.model = self.model.module
         else:
             src = s["model"].state_dict()
             want = self.model.state_dict().keys()
-            # a DataParallel-saved checkpoint carries the `module.` prefix (export_onnx_group_norm.py:28-32)
-            if not any(k.startswith("module.") for k in want):
+            # a DataParallel-saved checkpoint carries the `module.` prefix (export_onnx_group_norm.py:28-32); either side may be wrapped
+            want_pref, src_pref = any(k.startswith("module.") for k in want), any(k.startswith("module.") for k in src)
+            if src_pref and not want_pref:
                 src = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in src.items()}
+            elif want_pref and not src_pref:
+                src = {"module." + k: v for k, v in src.items()}
             self.model.load_state_dict(src)
 
     def load_latest(self):

@@ -165,7 +165,7 @@ int ru_unet_get_precision(ru_unet_t h);
  * the 4-channel stem / head data paths keep three products. */
 int ru_unet_set_grad_precision(ru_unet_t h, int precision);
 int ru_unet_get_grad_precision(ru_unet_t h);
-/* Backward-pass fusions of the voxel-major split-bf16 engine (both on by default; same arithmetic either way up to summation order --
+/* Backward-pass fusions of the voxel-major split-bf16 engine (on by default unless noted; same arithmetic either way up to summation order --
  * the separate passes stay available so that tests can hold the fused kernels to them):
  *   RU_FUSE_GN_BWD_STATS  the GroupNorm-backward sums are taken in the epilogue of the data-gradient conv that produces the incoming
  *                         gradient (no reduce pass over (y, d));
@@ -176,6 +176,17 @@ int ru_unet_get_grad_precision(ru_unet_t h);
  *                         event-ordered behind the kernel that produces their dy and joined before ru_unet_backward returns: same kernels,
  *                         same arithmetic, bit-identical gradients; the memory-bound passes of the chain run in their shadow.  */
 #define RU_FUSE_SIDE_STREAM 4
+/*   RU_FUSE_BATCH_WREDUCE the per-workgroup partials of every weight gradient of a backward pass are summed by ONE launch behind the last
+ *                         weight-gradient kernel (nobody reads a weight gradient before the optimizer) instead of one small launch each:
+ *                         same summation order, bit-identical gradients.
+ *   RU_FUSE_TAIL_FINALIZE the GroupNorm statistics (forward) and the GroupNorm-backward coefficients are finalized by the LAST workgroup of
+ *                         the kernel that produces their partial sums (one integer ticket per launch, reset by the finisher; partials
+ *                         published with agent-scope stores and read back in the same fixed order: deterministic, no float atomics)
+ *                         instead of by a finalize launch behind it.  OFF by default: built, verified and measured (round 4) -- the
+ *                         serial tail (ticket + reading the partials back through the fabric) costs what the finalize launch and its
+ *                         boundary cost.  */
+#define RU_FUSE_BATCH_WREDUCE 8
+#define RU_FUSE_TAIL_FINALIZE 16
 int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
 /* In-situ timing of the dominant kernel (bench.py's roofline line): while enabled, every forward brackets its launches of
  * the 3x3x3 convolution 16 -> 16 at the input resolution (voxel-major split-bf16 engine; the forward of the shipped net has four) with a

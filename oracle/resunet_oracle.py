@@ -107,6 +107,13 @@ def make_params(seed=1337, **cfg):
     return out
 
 
+def projection_vectors(name, numel, count=3):
+    """Seeded random directions r_j ~ N(0, I) for the gradient-projection pins of the golden fixtures (tests/golden/make_golden.py stores
+    <g, r_j> of every parameter gradient of the reference; the GPU tests form the same inner products): data generation only."""
+    import zlib
+    return [np.random.default_rng([zlib.crc32(name.encode()), j]).standard_normal(numel).astype(np.float32) for j in range(count)]
+
+
 def make_input(n, d, h, w, seed=1337):
     """x ~ N(0,1) float32 ``[n,4,d,h,w]`` (real inputs are per-channel z-scored, test.py:103-113)."""
     rng = np.random.default_rng(seed + 1)

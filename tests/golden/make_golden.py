@@ -248,7 +248,7 @@ def gn_stats_hooks(net, store):
     return hooks
 
 
-def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16, full_grads=()):
+def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16, full_grads=(), projections=False):
     out = {"seed": np.int64(seed), "shape": np.asarray((n,) + dhw, np.int64)}
     net, params = load_ref_unet(cfg, seed)
     x = O.make_input(n, *dhw, seed=seed)
@@ -272,6 +272,9 @@ def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16, full_
             gflat = p.grad.numpy().ravel()
             out["gnorm_" + k] = np.float64(np.sqrt((gflat.astype(np.float64) ** 2).sum()))
             out["gsamp_" + k] = gflat[:: max(1, gflat.size // nsamp)][:nsamp].copy()
+            if projections:                                                    # <g, r_j> for three seeded random directions: pins EVERY element of
+                g64 = gflat.astype(np.float64)                                 # every gradient (a mirrored tap or swapped channel pair moves them by O(|g|))
+                out["gproj_" + k] = np.asarray([float(np.dot(g64, r.astype(np.float64))) for r in O.projection_vectors(k, gflat.size)])
             if gflat.size <= 4096:
                 out["gfull_" + k] = p.grad.numpy().copy()
             if k in full_grads:                                                # whole convolution-weight gradients: elementwise parity of the
@@ -427,7 +430,7 @@ def gen_checkpoint():
         import train as ref_train
     cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
     net, params = load_ref_unet(cfg, 23)
-    wrapped = torch.nn.DataParallel(module=net, device_ids=[0]) if False else net   # CPU-only image: no DataParallel devices
+    wrapped = torch.nn.DataParallel(module=net)        # main.py:61 (on this GPU-less image the wrapper has no device ids; the pickle layout is the same)
     tmp = tempfile.mkdtemp()
     tr = ref_train.Trainer(name="tiny", models_root=tmp, model=wrapped, rewrite=True, connect_tb=False)
     tr.state.cuda = False
@@ -517,7 +520,8 @@ if __name__ == "__main__":
         # ~15 s and ~10 GB for it): train.py:201-210 around the imported model / loss modules
         gen_unet("unet128_train", full, 2, (128, 128, 128), 2024, full_output=False, with_backward=True, nsamp=64,
                  full_grads=("conv_first.0.conv1.conv1.weight", "encoder_convs.0.1.conv2.conv1.weight", "encoder_convs.2.3.conv1.conv1.weight",
-                             "decoder_convs.0.0.conv2.conv1.weight"))
+                             "decoder_convs.0.0.conv2.conv1.weight", "encoder_convs.1.1.conv1.conv1.weight", "encoder_convs.1.0.downsample.0.weight",
+                             "encoder_convs.2.0.downsample.0.weight"), projections=True)
     if want("sliding240"):
         gen_sliding240()
     if want("adam"):

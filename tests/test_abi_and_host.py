@@ -99,14 +99,33 @@ def test_reference_checkpoint_unpickles_into_host_mirror(golden, tmp_path):
         tr = TR.Trainer(name="tiny", models_root=str(tmp_path), model=None, rewrite=False, connect_tb=False)
         assert tr.resume_training
         tr.load_best()
-        assert isinstance(tr.model, M.UNet) and isinstance(tr.state, TR.TrainingState)
+        # the fixture is what the reference really writes: main.py:61 wraps the net, so the pickle is DataParallel(UNet) and its keys
+        # carry the `module.` prefix (export_onnx_group_norm.py:28-32); a wrapper without several devices stays as pickled
+        assert isinstance(tr.model, torch.nn.DataParallel) and isinstance(tr.model.module, M.UNet) and isinstance(tr.state, TR.TrainingState)
         assert (tr.state.epoch, tr.state.global_step, tr.state.best_val, tr.state.cuda) == (3, 77, 1.25, False)
         cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
         params = O.make_params(23, **cfg)
         sd = tr.model.state_dict()
-        assert list(sd.keys()) == list(params.keys())
+        assert list(sd.keys()) == ["module." + k for k in params.keys()]
         for k, v in params.items():
-            assert np.array_equal(sd[k].numpy(), v), k
+            assert np.array_equal(sd["module." + k].numpy(), v), k
+        # several devices in the wrapper (the reference under --gpus 8): the module itself is kept -- one process per GPU here
+        many = torch.nn.DataParallel(module=M.UNet(**cfg))
+        many.device_ids = [0, 1]
+        os.makedirs(tmp_path / "many", exist_ok=True)
+        torch.save({"state": tr.state, "model": many}, tmp_path / "many" / "manybest_model.pth")
+        trm = TR.Trainer(name="many", models_root=str(tmp_path), model=None, rewrite=False, connect_tb=False)
+        trm.load_best()
+        assert isinstance(trm.model, M.UNet)
+        with pytest.raises(RuntimeError, match="one process per GPU"):
+            M.UNet(**cfg)._replicate_for_data_parallel()
+        # a wrapped mirror takes an un-wrapped checkpoint and the reverse (state-dict route, train.py:331-333)
+        plain = M.UNet(**cfg)
+        plain.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        torch.save({"state": tr.state, "model": plain}, tmp_path / "many" / "manylast_model.pth")
+        trw = TR.Trainer(name="many", models_root=str(tmp_path), model=torch.nn.DataParallel(module=M.UNet(**cfg)), rewrite=False, connect_tb=False)
+        trw.load_latest()
+        assert all(np.array_equal(trw.model.module.state_dict()[k].numpy(), v) for k, v in params.items())
         # state-dict route into a freshly constructed mirror, incl. the DataParallel `module.` prefix
         net = M.UNet(**cfg)
         tr2 = TR.Trainer(name="tiny", models_root=str(tmp_path), model=net, rewrite=False, connect_tb=False)
@@ -155,8 +174,8 @@ def test_argument_errors_are_reported_not_thrown(lib):
     from brats2019_amd import _lib as L
     from brats2019_amd.engine import ParamLayout
     lay = ParamLayout(**O.DEFAULT_CFG)
-    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0 and lib.ru_unet_set_fusion(lay.handle, 7) == 0
-    assert lib.ru_unet_set_fusion(lay.handle, 8) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
+    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0 and lib.ru_unet_set_fusion(lay.handle, 31) == 0
+    assert lib.ru_unet_set_fusion(lay.handle, 32) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
     assert lib.ru_unet_set_precision(lay.handle, 7) < 0
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 12, 16, 16, 0) == 0            # extents must be divisible by 2^(depth-1)
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 1) > lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 0) > 0
@@ -220,3 +239,37 @@ def test_inference_workspace_recycles_block_temporaries():
     assert abs(ws(8, 128, 0) - 2 * ws(4, 128, 0)) < 0.05 * ws(8, 128, 0)
     assert ws(8, 192, 0) < 26 * 2 ** 30
     assert ws(1, 36, 0) == 0                      # extents must be divisible by 8 (three stride-2 levels): size query says 0
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/model.py"), reason="needs the reference sources (build container only; the GPU box has none)")
+def test_checkpoint_written_here_loads_into_the_reference_unet(tmp_path):
+    """The reverse direction of test_reference_checkpoint_unpickles_into_host_mirror: `<name>best_model.pth` written by THIS Trainer._save,
+    read the way the reference's Trainer._load reads it (train.py:326-333: torch.load, then `model.load_state_dict(s['model'].state_dict())`)
+    into the reference's own model.UNet -- un-wrapped and, as main.py:61 builds it, wrapped in nn.DataParallel."""
+    import contextlib
+    import importlib.util
+    import io
+    from brats2019_amd import train as TR, model as M
+    cfg = dict(depth=2, encoder_layers=[1, 1], decoder_layers=[1, 1], number_of_channels=[8, 16], number_of_outputs=3)
+    params = O.make_params(29, **cfg)
+    spec = importlib.util.spec_from_file_location("_reference_model_py", "/root/reference/model.py")
+    ref = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(ref)
+        mk_ref = lambda: ref.UNet(cfg["depth"], cfg["encoder_layers"], cfg["decoder_layers"], cfg["number_of_channels"], cfg["number_of_outputs"])
+        ref_plain, ref_wrapped = mk_ref(), torch.nn.DataParallel(module=mk_ref())
+    for tag, wrap in (("plain", False), ("wrapped", True)):
+        net = M.UNet(**cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        mine = torch.nn.DataParallel(module=net) if wrap else net
+        tr = TR.Trainer(name="rev" + tag, models_root=str(tmp_path), model=mine, rewrite=True, connect_tb=False)
+        tr.state.epoch, tr.state.global_step = 5, 123
+        tr._save("best_model")
+        s = torch.load(tmp_path / ("rev" + tag) / ("rev" + tag + "best_model.pth"), map_location=torch.device("cpu"), weights_only=False)   # train.py:327
+        assert (s["state"].epoch, s["state"].global_step) == (5, 123)
+        target = ref_wrapped if wrap else ref_plain
+        target.load_state_dict(s["model"].state_dict())                                    # train.py:333 (strict: names, order and shapes)
+        got = (target.module if wrap else target).state_dict()
+        assert list(got.keys()) == list(params.keys())
+        for k, v in params.items():
+            assert np.array_equal(got[k].numpy(), v), (tag, k)

@@ -46,7 +46,7 @@ def run_train_step(cfg, n, dhw, seed, precision="f32", fusion=None, grad_precisi
     return net, out[0].detach(), loss, vals
 
 
-def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, loss_tol=5e-6, flip_band=1e-5, conv_rel=None):
+def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, loss_tol=5e-6, flip_band=1e-5, conv_rel=None, proj_rel=None, small_rel=None):
     p = probs.cpu().numpy()
     if "probs" in g:
         err = np.abs(p - g["probs"]).max()
@@ -61,6 +61,7 @@ def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, lo
     assert abs(float(loss) - float(g["loss"])) < loss_tol
     assert abs(float(vals[0]) - float(g["loss_dice"])) < loss_tol and abs(float(vals[1]) - float(g["loss_bce"])) < loss_tol
     dead = set(g["dead_params"].tolist())
+    worst_proj, worst_small = [0.0], [0.0]
     for k, prm in net.named_parameters():
         if k in dead:
             assert prm.grad is None, k                       # never-executed modules keep grad=None (model.py:420)
@@ -73,8 +74,9 @@ def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, lo
         if "gfull_" + k in g:
             # small tensors (GroupNorm gamma/beta, bias) are sums of ~1e5 signed terms that cancel to ~1e-3 of their
             # magnitude: the fp32 CPU reference itself carries ~1e-3 relative noise there, hence 4x the norm tolerance
-            np.testing.assert_allclose(gr, g["gfull_" + k].ravel().astype(np.float64), rtol=0, atol=4 * grad_rel * np.abs(g["gfull_" + k]).max() + 1e-9,
-                                       err_msg=k)
+            rf = g["gfull_" + k].ravel().astype(np.float64)
+            worst_small[0] = max(worst_small[0], float(np.abs(gr - rf).max() / np.abs(rf).max()))
+            np.testing.assert_allclose(gr, rf, rtol=0, atol=(small_rel if small_rel is not None else 4 * grad_rel) * np.abs(rf).max() + 1e-9, err_msg=k)
         if "gconv_" + k in g:
             # whole convolution-weight gradients of the full-size step against the REFERENCE, elementwise: relative L2 of the difference
             # (a wrong halo term on one face of a tile, a mirrored tap or a transposed channel pair cannot hide in a norm)
@@ -82,9 +84,19 @@ def check_against_fixture(g, net, probs, loss, vals, grad_rel, prob_tol=2e-5, lo
             rel = float(np.linalg.norm(gr - r) / np.linalg.norm(r))
             print("  full gradient %-42s relative L2 vs reference %.2e" % (k, rel))
             assert rel <= (conv_rel if conv_rel is not None else 2 * grad_rel), (k, rel)
+        if "gproj_" + k in g:
+            # <g, r_j> for three seeded random directions (tests/golden/make_golden.py): every element of EVERY parameter gradient is pinned
+            # against the reference -- the error of a projection has the size of the L2 error of the whole tensor
+            pr = np.asarray([float(np.dot(gr, r.astype(np.float64))) for r in O.projection_vectors(k, gr.size)])
+            perr = float(np.abs(pr - g["gproj_" + k]).max() / ref)
+            worst_proj[0] = max(worst_proj[0], perr)
+            assert perr <= (proj_rel if proj_rel is not None else 4 * grad_rel), (k, perr)
         ns = int(g["gsamp_" + k].size)
         samp = gr[:: max(1, gr.size // ns)][:ns]
         np.testing.assert_allclose(samp, g["gsamp_" + k].astype(np.float64), rtol=0, atol=10 * grad_rel * ref / np.sqrt(gr.size) + 1e-9, err_msg=k)
+    print("  worst small-tensor (GroupNorm / bias) gradient error, max |dg| / max |g|: %.2e" % worst_small[0])
+    if worst_proj[0] > 0:
+        print("  worst projection error |<g - g_ref, r>| / |g_ref| over all parameters: %.2e" % worst_proj[0])
 
 
 def test_unet32_train_step_matches_reference_fixture(golden):
@@ -253,6 +265,19 @@ def test_unet32_train_step_bf16x3_within_1e3(golden):
         worst = max(worst, abs(got - ref) / ref)
     print("bf16x3 unet32: worst relative gradient-norm error %.2e" % worst)
     assert worst < 5e-3
+    # ... and ELEMENTWISE against the oracle's gradients (pinned to the reference by tests/test_oracle_golden.py): relative L2 of the
+    # difference per tensor.  Split-bf16 against fp32 at this size and seed measures 2.0e-3 (LeakyReLU kinks: DESIGN section 2); bar 6e-3
+    _, _, ref_grads = O.forward_backward(O.make_params(1337, **O.DEFAULT_CFG), O.make_input(1, 32, 32, 32, seed=1337), O.make_target(1, 32, 32, 32, seed=1337), **O.DEFAULT_CFG)
+    worst_el = 0.0
+    for k, prm in net.named_parameters():
+        if ref_grads[k] is None:
+            assert prm.grad is None, k
+            continue
+        r = ref_grads[k].astype(np.float64)
+        rel = float(np.linalg.norm(prm.grad.double().cpu().numpy() - r) / np.linalg.norm(r))
+        worst_el = max(worst_el, rel)
+        assert rel <= 6e-3, (k, rel)
+    print("bf16x3 unet32: worst elementwise relative L2 gradient error vs the oracle %.2e" % worst_el)
 
 
 def test_unet128_forward_bf16x3_mask_and_probs(golden):
@@ -379,7 +404,8 @@ def _grad_report(g, net):
 def test_unet128_train_step_f32_matches_reference_fixture(golden):
     g = golden("unet128_train")
     net, probs, loss, vals = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "f32")
-    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-4)
+    # bars <= 3x the measured errors (round 4, MI355X): full conv-weight gradients 1.4e-4, small tensors 4.5e-4 of the max, projections 5.0e-4
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-4, conv_rel=4e-4, small_rel=1.5e-3, proj_rel=1.5e-3)
     print("f32 unet128_train: worst relative gradient-norm error %.2e (%s)" % _grad_report(g, net))
 
 
@@ -392,7 +418,9 @@ def test_unet128_train_step_bf16x3_matches_reference_fixture(golden, fusion):
     g = golden("unet128_train")
     net, probs, loss, vals = run_train_step(O.DEFAULT_CFG, 2, (128, 128, 128), 2024, "bf16x3", fusion)
     assert net._get_engine().precision == "bf16x3"
-    check_against_fixture(g, net, probs, loss, vals, grad_rel=5e-3, prob_tol=2e-4, loss_tol=5e-5, flip_band=1e-3)
+    # gradient bars <= 3.5x the measured errors (round 4): norms 2.8e-4, full conv-weight gradients 5.7e-4, small tensors 1.8e-3 of the max,
+    # projections of every parameter gradient 1.2e-3
+    check_against_fixture(g, net, probs, loss, vals, grad_rel=1e-3, prob_tol=2e-4, loss_tol=5e-5, flip_band=1e-3, conv_rel=2e-3, small_rel=5e-3, proj_rel=4e-3)
     print("bf16x3 unet128_train %s: worst relative gradient-norm error %.2e (%s)" % ((fusion,) + _grad_report(g, net)))
 
 
@@ -645,3 +673,36 @@ def test_forward_criterion_backward_capture_into_a_hip_graph():
         torch.cuda.synchronize()
         assert float(loss_c) == loss_eager
         assert torch.equal(st.grads, grads_eager)
+
+
+def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
+    """RU_FUSE_TAIL_FINALIZE (the last workgroup of a conv / reduce launch finalizes the GroupNorm partials it produced: one integer ticket,
+    agent-scope publish, fixed read order) and RU_FUSE_BATCH_WREDUCE (one launch sums the partials of every weight gradient) against the
+    separate finalize / reduce launches on the same inputs: the batched reduce is bit-identical (same summation order); the tails sum the
+    same partials in another fixed order (float64), so statistics agree to float rounding.  Two runs with the tails on are bit-identical
+    (no float atomics; the ticket words are reset by the finisher), sizes at which persistent, 4-channel and one-stage kernels all occur."""
+    res = {}
+    for key, (batch, tail) in {"plain": (False, False), "batch": (True, False), "tail": (True, True), "tail2": (True, True)}.items():
+        net, _ = build_model(O.DEFAULT_CFG, 77, "bf16x3")
+        net._get_engine().set_fusion(True, True, True, batch, tail)
+        x = T(O.make_input(2, 64, 64, 64, seed=77)).cuda()
+        g = T(O.make_target(2, 64, 64, 64, seed=77)).cuda()
+        from brats2019_amd import loss as L
+        net.train()
+        for _ in range(2):                                   # second step: the tickets of the first were reset by their finishers
+            for p in net.parameters():
+                p.grad = None
+            out = net([x])
+            L.FusedCriterion()(out, [g]).backward()
+        res[key] = (out[0].detach().clone(), {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None})
+    assert torch.equal(res["plain"][0], res["batch"][0])
+    for k in res["plain"][1]:
+        assert torch.equal(res["plain"][1][k], res["batch"][1][k]), k
+    assert torch.equal(res["tail"][0], res["tail2"][0])
+    for k in res["tail"][1]:
+        assert torch.equal(res["tail"][1][k], res["tail2"][1][k]), k
+    dp = float((res["tail"][0] - res["plain"][0]).abs().max())
+    worst = max(float(torch.linalg.vector_norm(res["tail"][1][k].double() - res["plain"][1][k].double()) / torch.linalg.vector_norm(res["plain"][1][k].double()))
+                for k in res["plain"][1])
+    print("tail finalize vs finalize launches: max |dp| %.2e, worst relative L2 gradient difference %.2e" % (dp, worst))
+    assert dp <= 1e-6 and worst <= 1e-4, (dp, worst)
