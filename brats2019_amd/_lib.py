@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RU_LIB_PATH") or os.path.join(_PKG, "lib", "libresune
 _lib = None
 PRECISIONS = {"f32": 0, "bf16x3": 1}      # RU_PREC_F32 / RU_PREC_BF16X3
 GRAD_PRECISIONS = {"bf16x3": 1, "bf16": 2}   # ru_unet_set_grad_precision: RU_PREC_BF16X3 / RU_PREC_BF16
-FUSE_GN_BWD_STATS, FUSE_GN_BWD_APPLY, FUSE_SIDE_STREAM, FUSE_BATCH_WREDUCE, FUSE_TAIL_FINALIZE = 1, 2, 4, 8, 16   # RU_FUSE_*
+FUSE_GN_BWD_STATS, FUSE_GN_BWD_APPLY, FUSE_SIDE_STREAM, FUSE_BATCH_WREDUCE, FUSE_TAIL_FINALIZE, FUSE_PW_DGRAD = 1, 2, 4, 8, 16, 32   # RU_FUSE_*
 
 _vp, _f, _d, _i, _sz = C.c_void_p, C.c_float, C.c_double, C.c_int, C.c_size_t
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "ru_unet_workspace_bytes": (_sz, [_vp] + [_i] * 5),
     "ru_unet_forward": (_i, [_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp, _sz, _vp]),
     "ru_unet_backward": (_i, [_vp] * 6),
+    "ru_unet_backward_criterion": (_i, [_vp, _vp, _vp, _vp, _d, _f, _f, _f, _f, _vp, _vp, _vp]),
     "ru_unet_gn_stats": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ru_comm_unique_id": (_i, [_vp]),
     "ru_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),

@@ -205,7 +205,7 @@ struct ru_unet {
     size_t pk_in = 0, pk_out = 0, pk_out_d = 0, pk_total = 0;
     size_t fk_in = 0, fk_out = 0, fk_out_d = 0, fk_total = 0;
     int precision = RU_PREC_F32;
-    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE;     // (RU_FUSE_TAIL_FINALIZE: opt-in)
+    unsigned fusion = RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE | RU_FUSE_PW_DGRAD;     // (RU_FUSE_TAIL_FINALIZE: opt-in)
     int grad_precision = RU_PREC_BF16X3;   // ru_unet_set_grad_precision: RU_PREC_BF16 = one MFMA product in the 3x3x3 data / weight gradients
     int grad_products() const { return (precision == RU_PREC_BF16X3 && grad_precision == RU_PREC_BF16) ? 1 : 3; }
     int wgrad_mode() const { return precision | (grad_products() == 1 ? kOneProduct : 0); }   // `mode` argument of wgrad3_run
@@ -331,7 +331,7 @@ extern "C" ru_unet_t ru_unet_create(int depth, const int* encoder_layers, const 
     ru_unet* h = new ru_unet();
     if (const char* e = getenv("RU_SIDE_STREAM")) { if (*e == '0') h->fusion &= ~(unsigned)RU_FUSE_SIDE_STREAM; }    // same-box A/B of the side stream
     if (const char* e = getenv("RU_FUSION_OFF")) h->fusion &= ~(unsigned)strtoul(e, nullptr, 0);                   // same-box A/B of any fusion bit (RU_FUSE_*)
-    if (const char* e = getenv("RU_FUSION_ON")) h->fusion |= (unsigned)strtoul(e, nullptr, 0) & 31u;
+    if (const char* e = getenv("RU_FUSION_ON")) h->fusion |= (unsigned)strtoul(e, nullptr, 0) & 63u;
     h->depth = depth;
     h->nout = number_of_outputs;
     h->enc.assign(encoder_layers, encoder_layers + depth);
@@ -385,7 +385,7 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
 }
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
 extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
-    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE | RU_FUSE_TAIL_FINALIZE)) == 0, "ru_unet_set_fusion: bad argument");
+    RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE | RU_FUSE_TAIL_FINALIZE | RU_FUSE_PW_DGRAD)) == 0, "ru_unet_set_fusion: bad argument");
     h->fusion = mask;
     h->have_fwd = false;            // the workspace layout of the backward depends on it
     return RU_OK;
@@ -990,6 +990,14 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
         c1.y = dxp; c1.s2d = 2; c1.Dc = D; c1.Hc = H; c1.Wc = W;
         c1.add = join;                                           // the skip gradient joins in the store
         if (joined) *joined = true;                              // (decided by structure, not by the pointer: the dry walk has null pointers)
+        if (nx && (h->fusion & RU_FUSE_GN_BWD_STATS) && conv1_16_bst_nblk(c1) > 0) {
+            // the scattered gradient (+ skip gradient) IS what enters nx (norm2 of the last block one level up): its GroupNorm-backward sums
+            // are taken in this store pass -- no reduce pass over (y, d) at the finer level
+            nx->out.nblk = conv1_16_bst_nblk(c1);
+            nx->out.part = A.alloc((size_t)N * Cp * nx->out.nblk * 2);
+            nx->out.coef = A.alloc((size_t)N * Cp * 3);
+            c1.bst_y = nx->y; c1.bst_k = nx->k; c1.bst_slope = nx->slope; c1.stat_partials = nx->out.part;
+        }
         RU_RUN(conv1_16_launch(c1, s));
     } else {
         c1.wT = P(h, params, bp.down); c1.ldw = 8 * Cp;
@@ -1000,7 +1008,10 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     return RU_OK;
 }
 
-static int unet_backward_impl(ru_unet* h, const float* params, const float* dprobs, float* grads, float* dx_in, Arena& A, hipStream_t s) {
+// crit: the incoming gradient is the criterion's (ru_unet_backward_criterion): formed inside the head's first pass where that pass exists
+// (4-channel head path), else materialised into the workspace first
+static int unet_backward_impl(ru_unet* h, const float* params, const float* dprobs, float* grads, float* dx_in, Arena& A, hipStream_t s,
+                              const CritGradArgs* crit = nullptr) {
     const int N = h->N, depth = h->depth;
     std::vector<int> Dl(depth), Hl(depth), Wl(depth);
     for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
@@ -1018,7 +1029,15 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     float* dlog = need_dlog ? A.alloc((size_t)N * h->nout * Vl(0)) : nullptr;
     const size_t wsb = bias_grad_workspace_bytes(N, h->nout, Vl(0));
     float* wsp = A.alloc(wsb / sizeof(float) + 1);
-    if (head4) {                                                 // sigmoid backward, 4-channel copy and bias gradient in one pass
+    const bool crit_fused = crit && head4 && !need_dlog;
+    float* dpb = (!(head4 && !need_dlog) && (crit || A.dry)) ? A.alloc((size_t)N * h->nout * Vl(0)) : nullptr;      // (the dry walk sizes for either entry point)
+    if (crit && !crit_fused) {                                   // no pass to ride on: the criterion's gradient is written out like a caller would
+        RU_RUN(crit_grad_launch(h->probs, crit->target, crit->sums, crit->count, crit->w_dice, crit->w_bce, crit->bgw, crit->priority, dpb, N, h->nout, Vl(0), s));
+        dprobs = dpb;
+    }
+    if (crit_fused) {                                            // criterion gradient, sigmoid backward, 4-channel copy and bias gradient in one pass
+        RU_RUN(head_grad_c4_crit_launch(h->probs, *crit, d4, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
+    } else if (head4) {                                          // sigmoid backward, 4-channel copy and bias gradient in one pass
         RU_RUN(head_grad_c4_launch(h->probs, dprobs, d4, G(h, grads, h->conv_out_b), N, h->nout, Vl(0), wsp, wsb, s));
         if (need_dlog) RU_RUN(sigmoid_bwd_launch(h->probs, dprobs, dlog, (size_t)N * h->nout * Vl(0), s));
     } else {
@@ -1054,25 +1073,35 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     RU_RUN(conv3_launch(dh, s));
     const float* dcur = dcur_buf;
     std::vector<const float*> dskip(depth - 1, nullptr);
+    FusedSums carry = hsums;                                     // sums of the norm2 the current gradient enters, taken by the kernel that produced it
     // decoder stages, reverse of execution order (forward ran i = depth-2 .. 0)
     for (int i = 0; i <= depth - 2; ++i) {
         for (int j = (int)h->dec_s[i].size() - 1; j >= 0; --j) {
-            const bool fused2 = hsums.nblk > 0 && i == 0 && j == (int)h->dec_s[i].size() - 1;
-            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur, nullptr, nullptr, fused2 ? &hsums : nullptr);
+            const bool fused2 = carry.nblk > 0 && j == (int)h->dec_s[i].size() - 1;
+            const FusedSums sin = carry;
+            rc = block_bwd(h, params, grads, A, s, h->dec_s[i][j], dcur, &dcur, nullptr, nullptr, fused2 ? &sin : nullptr);
             if (rc) return rc;
         }
+        carry = FusedSums();
         const DecSave& ds = h->dstage[i];
         const int Ci = h->ch[i], Cc = h->ch[i + 1];
         const size_t V = Vl(i);
         // decoder_convs1x1[i] over cat([skip, v]) (model.py:424-425)
         const float* wdec = P(h, params, h->dec1_w[i]);          // [Ci][2Ci]
         float* gdec = G(h, grads, h->dec1_w[i]);
+        float* dsk = A.alloc((size_t)N * Ci * V);
+        float* dv = A.alloc((size_t)N * Ci * V);
+        float* dpre = A.alloc((size_t)N * Ci * V);
+        // Ci <= 32: the weight-gradient kernel of the concat 1x1 also forms its DATA gradient from the dy tile it has staged (both halves,
+        // LeakyReLU backward of the up-sampled half from the staged v): one pass over dcur / skip / v instead of two
+        const bool dg_fused = c16 && Ci <= 32 && (h->fusion & RU_FUSE_PW_DGRAD);
         if (c16) {                                               // one pass over dcur for both halves of the (never materialised) concat
             Wgrad1Args w{};
             w.x = ds.skip; w.x1 = ds.v; w.C0 = Ci; w.dy = dcur; w.dw = gdec; w.ldw = 2 * Ci; w.c16 = 1; w.defer = red_for(s);
             w.ws_bytes = wgrad1_workspace_bytes(N, 2 * Ci, Ci, V);
             w.ws = A.alloc(w.ws_bytes / sizeof(float));
             w.N = N; w.Cin = 2 * Ci; w.Cout = Ci; w.V = V;
+            if (dg_fused) { w.dg_w = wdec; w.dg_ldw = 2 * Ci; w.dg_y0 = dsk; w.dg_y1 = dpre; w.dg_mask_slope = kSlope; }
             RU_RUN(wgrad1_launch(w, s));
         } else {
             rc = wgrad1_run(A, s, ds.skip, dcur, gdec, 2 * Ci, N, Ci, Ci, V, c16);
@@ -1080,14 +1109,13 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             rc = wgrad1_run(A, s, ds.v, dcur, A.dry ? nullptr : gdec + Ci, 2 * Ci, N, Ci, Ci, V, c16);
             if (rc) return rc;
         }
-        float* dsk = A.alloc((size_t)N * Ci * V);
-        float* dv = A.alloc((size_t)N * Ci * V);
         Conv1Args a1{};
         a1.x0 = dcur; a1.C0 = Ci; a1.y = dsk; a1.out_slope = 1.f; a1.N = N; a1.Cout = Ci; a1.V = V;
         Conv1Args a2 = a1;
         a2.y = dv;
-        float* dpre = A.alloc((size_t)N * Ci * V);
-        if (c16) {                                               // [out][in] = the transposed pack [2Ci][Ci]: rows 0..Ci-1 skip half, Ci.. up half
+        if (dg_fused) {
+            // (written by the weight-gradient launch above)
+        } else if (c16) {                                               // [out][in] = the transposed pack [2Ci][Ci]: rows 0..Ci-1 skip half, Ci.. up half
             a1.wT = h->pack + h->pk_decT[i]; a1.ldw = Ci;
             a2.wT = h->pack + h->pk_decT[i] + (size_t)Ci * Ci; a2.ldw = Ci;
             a2.y = dpre; a2.mask = ds.v; a2.mask_slope = kSlope; // LeakyReLU backward (model.py:422) fused into the store
@@ -1114,6 +1142,17 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             if (rc) return rc;
             a3.x0 = dzc; a3.y = dz; a3.V = Vl(i + 1);
             a3.wT = h->pack + h->pk_upT[i]; a3.ldw = Ci;          // [Cc][Ci] = [out][in]
+            // dz is the gradient entering norm2 of the block that produced z (the last block of the next decoder stage, or of the deepest
+            // encoder level): its GroupNorm-backward sums are taken in this launch's store pass
+            carry = FusedSums();
+            const BlockSave* zb = (i + 1 <= depth - 2 && !h->dec_s[i + 1].empty()) ? &h->dec_s[i + 1].back()
+                                  : (!h->enc_s[depth - 2].empty() ? &h->enc_s[depth - 2].back() : nullptr);
+            if (zb && (zb->g2.k || A.dry) && (h->fusion & RU_FUSE_GN_BWD_STATS) && conv1_16_bst_nblk(a3) > 0) {
+                carry.nblk = conv1_16_bst_nblk(a3);
+                carry.part = A.alloc((size_t)N * Cc * carry.nblk * 2);
+                carry.coef = A.alloc((size_t)N * Cc * 3);
+                a3.bst_y = zb->y2; a3.bst_k = zb->g2.k; a3.bst_slope = kSlope; a3.stat_partials = carry.part;
+            }
             RU_RUN(conv1_16_launch(a3, s));
         } else {
             rc = wgrad1_run(A, s, ds.u, dpre, G(h, grads, h->up_w[i]), Cc, N, Cc, Ci, V, false);
@@ -1129,28 +1168,34 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
     // encoder levels, deepest first; the skip gradient joins at each level's input
     for (int i = depth - 2; i >= 0; --i) {
         bool joined = false;
-        FusedSums snext;                                         // sums of the NEXT block's norm2, taken by this block's last conv
+        FusedSums snext = carry;                                 // sums of the NEXT block's norm2, taken by the kernel that produced its incoming gradient
+        carry = FusedSums();
         for (int j = (int)h->enc_s[i].size() - 1; j >= 0; --j) {
             GNNext nx{};
             nx.slope = kSlope;
-            if (j >= 1 && h->enc_s[i][j - 1].g2.k) {
-                const BlockSave& pb = h->enc_s[i][j - 1];
-                nx.y = pb.y2; nx.k = pb.g2.k; nx.g = &pb.g2;
-                nx.gamma = P(h, params, pb.bp->n2w); nx.dgamma = G(h, grads, pb.bp->n2w); nx.dbeta = G(h, grads, pb.bp->n2b);
+            // the gradient this block produces enters norm2 of the block before it -- for the level's first (down-sampling) block that is the
+            // last block one level up (its stride-2 transpose scatters into that level and adds the skip gradient there)
+            const BlockSave* pb = j >= 1 ? &h->enc_s[i][j - 1] : (i >= 1 ? (h->enc_s[i - 1].empty() ? nullptr : &h->enc_s[i - 1].back())
+                                                                        : (h->first_s.empty() ? nullptr : &h->first_s.back()));
+            if (pb && pb->g2.k) {
+                nx.y = pb->y2; nx.k = pb->g2.k; nx.g = &pb->g2;
+                nx.gamma = P(h, params, pb->bp->n2w); nx.dgamma = G(h, grads, pb->bp->n2w); nx.dbeta = G(h, grads, pb->bp->n2b);
             }
             const FusedSums sin = snext;
             rc = block_bwd(h, params, grads, A, s, h->enc_s[i][j], dcur, &dcur, j == 0 ? dskip[i] : nullptr, j == 0 ? &joined : nullptr, sin.nblk > 0 ? &sin : nullptr,
-                           (nx.y || A.dry) && j >= 1 ? &nx : nullptr);
+                           (pb && (nx.y || A.dry)) ? &nx : nullptr);
             if (rc) return rc;
             snext = nx.out;
         }
+        carry = snext;                                           // (from the level's down-sampling block: the sums of the finer level's last norm2)
         if (!joined) {
             float* sum = A.alloc((size_t)N * h->ch[i] * Vl(i));
             RU_RUN(add_launch(dcur, dskip[i], sum, (size_t)N * h->ch[i] * Vl(i), s));
             dcur = sum;
+            carry = FusedSums();                                 // (the sums were those of the gradient before the skip gradient joined)
         }
     }
-    FusedSums sfirst;
+    FusedSums sfirst = carry;
     for (int j = (int)h->first_s.size() - 1; j >= 0; --j) {
         // the gradient a first-level block produces enters norm2 of the block before it, or (j = 0) norm_input (no activation: slope 1)
         GNNext nx{};
@@ -1260,8 +1305,8 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     return RU_OK;
 }
 
-extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx, ru_stream_t stream) {
-    RU_REQUIRE(h && params && dprobs && grads, "ru_unet_backward: null argument");
+extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx, ru_stream_t stream);
+static int backward_entry(ru_unet_t h, const float* params, const float* dprobs, const CritGradArgs* crit, float* grads, float* dx, ru_stream_t stream) {
     if (!h->have_fwd || !h->training) { set_error("ru_unet_backward: needs a preceding training-mode ru_unet_forward"); return RU_ESTATE; }
     Arena A;
     A.dry = false; A.base = h->ws; A.cap = h->ws_bytes; A.off = h->fwd_end; A.keep = h->fwd_keep;
@@ -1269,7 +1314,7 @@ extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* d
     h->red.main.e.clear();
     h->red.side.e.clear();
     ru::t_red = (h->fusion & RU_FUSE_BATCH_WREDUCE) && !trace_on() ? &h->red : nullptr;
-    int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream);
+    int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream, crit);
     ru::t_red = nullptr;
     ru::t_sink = nullptr;
     if (rc && h->side) {                                 // an error return must not leave the side stream running behind the caller's back
@@ -1279,6 +1324,17 @@ extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* d
     if (rc) return rc;
     if (A.failed) { set_error("ru_unet_backward: workspace too small"); return RU_ENOMEM; }
     return RU_OK;
+}
+extern "C" int ru_unet_backward_criterion(ru_unet_t h, const float* params, const float* target, const double* sums, double count,
+                                          float w_dice, float w_bce, float bg_weight, float priority, float* grads, float* dx, ru_stream_t stream) {
+    RU_REQUIRE(h && params && target && sums && grads && count > 0.0, "ru_unet_backward_criterion: null argument");
+    const CritGradArgs cg{target, sums, count, w_dice, w_bce, bg_weight, priority};
+    return backward_entry(h, params, nullptr, &cg, grads, dx, stream);
+}
+
+extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx, ru_stream_t stream) {
+    RU_REQUIRE(h && params && dprobs && grads, "ru_unet_backward: null argument");
+    return backward_entry(h, params, dprobs, nullptr, grads, dx, stream);
 }
 
 extern "C" int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream) {

@@ -25,29 +25,24 @@ __device__ __forceinline__ float2 stat_fetch(const float* p) {
 
 // sum of `cnt` consecutive pairs starting at p by the LPI lanes of a lane group (sl = lane % LPI); every lane of the group gets the sums.
 // The reads are ONE latency chain (the pairs were stored write-through: they come from the fabric, ~2 us a round trip under load), so a
-// lane has all of its loads in flight at once: 16-byte agent-scope (sc1) buffer loads, two pairs each, up to 16 per lane and pass.
-typedef unsigned int fin_u32x4 __attribute__((ext_vector_type(4)));
+// lane keeps up to 16 of its loads in flight.  8-byte agent-scope ATOMIC loads, the form Guideline 16 names for both sides (a variant
+// reading two pairs per 16-byte sc1 buffer load produced wrong statistics and was dropped: the pair stays the unit of publication AND
+// of reading).
 template <int LPI>
 __device__ __forceinline__ void fin_sum_pairs(const float* p, int cnt, int sl, double& o1, double& o2) {
     double s1 = 0.0, s2 = 0.0;
-    const int nq = cnt >> 1;                               // 16-byte quads (p is 16-byte aligned when cnt is even: see the callers)
-    if ((cnt & 1) == 0 && ((size_t)p & 15) == 0) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nq * 16, 0x00020000);
-        for (int q0 = 0; q0 < nq; q0 += 16 * LPI) {
-            fin_u32x4 v[16];
+    for (int i0 = 0; i0 < cnt; i0 += 16 * LPI) {
+        float2 v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {                 // out-of-range quads return zeros (buffer addressing)
-                const int q = q0 + j * LPI + sl;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, q < nq ? (unsigned)q * 16u : 0x80000000u, 0, 16 /* sc1 */);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                s1 += (double)__builtin_bit_cast(float, v[j][0]) + (double)__builtin_bit_cast(float, v[j][2]);
-                s2 += (double)__builtin_bit_cast(float, v[j][1]) + (double)__builtin_bit_cast(float, v[j][3]);
-            }
+        for (int j = 0; j < 16; ++j) {
+            const int i = i0 + j * LPI + sl;
+            v[j] = i < cnt ? stat_fetch(p + 2 * i) : make_float2(0.f, 0.f);
         }
-    } else {
-        for (int i = sl; i < cnt; i += LPI) { const float2 a = stat_fetch(p + 2 * i); s1 += (double)a.x; s2 += (double)a.y; }
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            s1 += (double)v[j].x + (double)v[j + 1].x;
+            s2 += (double)v[j].y + (double)v[j + 1].y;
+        }
     }
 #pragma unroll
     for (int o = LPI / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
@@ -143,14 +138,14 @@ __device__ __forceinline__ void fin_tail(const FinTail& f, const float* partials
     __syncthreads();
     if (*flag == 0u) return;                                     // (workgroup-uniform)
     if (f.kind == 1) {
-        const int cnt = (f.C / f.G) * f.nblk;                    // pairs per item: one pass of <= 16 quads per lane where the lanes allow
-        if (cnt > 512) fin_gn_stats<64>(f, partials);
-        else if (cnt > 128) fin_gn_stats<16>(f, partials);
+        const int cnt = (f.C / f.G) * f.nblk;                    // pairs per item: one pass of <= 16 pairs per lane where the lanes allow
+        if (cnt > 256) fin_gn_stats<64>(f, partials);
+        else if (cnt > 64) fin_gn_stats<16>(f, partials);
         else fin_gn_stats<4>(f, partials);
     } else {
         double* S = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + 16);
-        if (f.nblk > 512) fin_gn_bwd_phase1<64>(f, partials, S);
-        else if (f.nblk > 128) fin_gn_bwd_phase1<16>(f, partials, S);
+        if (f.nblk > 256) fin_gn_bwd_phase1<64>(f, partials, S);
+        else if (f.nblk > 64) fin_gn_bwd_phase1<16>(f, partials, S);
         else fin_gn_bwd_phase1<4>(f, partials, S);
         __syncthreads();
         fin_gn_bwd_phase2(f, S);

@@ -783,8 +783,11 @@ int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* w
 // Head of the backward pass on the 4-channel path, one pass instead of three (sigmoid backward, 4-channel copy, bias partials):
 // dz = dp*p*(1-p) (model.py:431) goes straight into the zero-padded voxel-major copy [N][V][4] that the head's weight- and
 // data-gradient kernels read, and the bias gradient's partial sums (model.py:348) are taken on the way.  V % 4 == 0.
+// CRIT: `dp` is the TARGET tensor and the incoming gradient is the criterion's (crit_grad_kernel's expression, same float operations in
+// the same order -> the same bits), formed from (p, target) and the per-class constants of `cg`
+template <bool CRIT>
 __global__ __launch_bounds__(256) void head_grad_c4_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ d4,
-                                                           float* __restrict__ part, int C, size_t V, int nblk) {
+                                                           float* __restrict__ part, int C, size_t V, int nblk, const CritGradArgs cg) {
     __shared__ float buf[4];
     const size_t n = blockIdx.y;
     const size_t v0 = (size_t)blockIdx.x * BG_CHUNK;
@@ -793,13 +796,34 @@ __global__ __launch_bounds__(256) void head_grad_c4_kernel(const float* __restri
     const float* dpp = dp + n * C * V;
     float4* op = reinterpret_cast<float4*>(d4) + n * V;
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    float kg[4] = {0.f, 0.f, 0.f, 0.f}, kp[4] = {0.f, 0.f, 0.f, 0.f}, cb = 0.f;
+    const float one_eps = (float)(1.0 + 1e-6);
+    if constexpr (CRIT) {
+        for (int c = 0; c < C && c < 4; ++c) {           // crit_grad_kernel's constants
+            const double I = cg.sums[c] + 1e-6, U = cg.sums[C + c] + 2e-6;
+            const double k = (double)cg.priority * (2.0 / (double)C) * (double)cg.w_dice;
+            kg[c] = (float)(-k / U);
+            kp[c] = (float)(2.0 * k * I / (U * U));
+        }
+        cb = (float)((double)cg.w_bce / cg.count);
+    }
     for (size_t v = v0 + (size_t)threadIdx.x * 4; v < v1; v += 1024) {
         float d[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const bool ok = c < C;
             const float4 q = *reinterpret_cast<const float4*>(pp + (ok ? c : 0) * V + v);
-            const float4 g = *reinterpret_cast<const float4*>(dpp + (ok ? c : 0) * V + v);
+            float4 g = *reinterpret_cast<const float4*>(dpp + (ok ? c : 0) * V + v);
+            if constexpr (CRIT) {
+                const float pv[4] = {q.x, q.y, q.z, q.w}, gv[4] = {g.x, g.y, g.z, g.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bce = -(gv[e] / (pv[e] + 1e-6f) - cg.bgw * (1.f - gv[e]) / (one_eps - pv[e]));
+                    o[e] = (kg[c] * gv[e] + kp[c] * pv[e]) + cb * bce;
+                }
+                g = make_float4(o[0], o[1], o[2], o[3]);
+            }
             d[c][0] = ok ? g.x * q.x * (1.f - q.x) : 0.f;
             d[c][1] = ok ? g.y * q.y * (1.f - q.y) : 0.f;
             d[c][2] = ok ? g.z * q.z * (1.f - q.z) : 0.f;
@@ -819,8 +843,18 @@ int head_grad_c4_launch(const float* p, const float* dp, float* d4, float* db, i
     RU_REQUIRE(C > 0 && C <= 4 && V % 4 == 0, "head_grad_c4: 1..4 channels, V % 4 == 0");
     if (!ws || ws_bytes < bias_grad_workspace_bytes(N, C, V)) { set_error("head_grad_c4: workspace too small"); return RU_ENOMEM; }
     const int nblk = (int)((V + BG_CHUNK - 1) / BG_CHUNK);
-    hipLaunchKernelGGL(head_grad_c4_kernel, dim3(nblk, N), dim3(256), 0, s, p, dp, d4, (float*)ws, C, V, nblk);
+    hipLaunchKernelGGL(head_grad_c4_kernel<false>, dim3(nblk, N), dim3(256), 0, s, p, dp, d4, (float*)ws, C, V, nblk, CritGradArgs{});
     RU_CHECK_LAUNCH("head_grad_c4_kernel");
+    hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, db, N, C, nblk);
+    RU_CHECK_LAUNCH("bias_final_kernel");
+    return RU_OK;
+}
+int head_grad_c4_crit_launch(const float* p, const CritGradArgs& cg, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s) {
+    RU_REQUIRE(C > 0 && C <= 4 && V % 4 == 0 && cg.target && cg.sums, "head_grad_c4_crit: 1..4 channels, V % 4 == 0, target and sums");
+    if (!ws || ws_bytes < bias_grad_workspace_bytes(N, C, V)) { set_error("head_grad_c4_crit: workspace too small"); return RU_ENOMEM; }
+    const int nblk = (int)((V + BG_CHUNK - 1) / BG_CHUNK);
+    hipLaunchKernelGGL(head_grad_c4_kernel<true>, dim3(nblk, N), dim3(256), 0, s, p, cg.target, d4, (float*)ws, C, V, nblk, cg);
+    RU_CHECK_LAUNCH("head_grad_c4_kernel<crit>");
     hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(256), 0, s, (const float*)ws, db, N, C, nblk);
     RU_CHECK_LAUNCH("bias_final_kernel");
     return RU_OK;

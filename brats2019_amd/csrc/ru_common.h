@@ -240,6 +240,15 @@ struct Wgrad1Args {
     const float* x1;         // c16 only, optional: input channels C0 .. Cin-1 live in this second tensor (a channel concat that was never made)
     int C0;                  // channels of x when x1 is set (multiple of 16)
     struct WgradRedList* defer;   // as Wgrad3Args::defer
+    // c16 only, Cout <= 32: the DATA gradient of the same 1x1x1 conv in the same pass over dy (the dy tile of a voxel chunk is in LDS for
+    // the weight gradient anyway): dx[v][c] = sum_o dg_w[o*dg_ldw + c] * dy[v][o], input channels < C0 (or all, without x1) written to
+    // dg_y0, the others to dg_y1 -- the latter through the LeakyReLU-backward mask of the x1 values staged for the weight gradient
+    // (dx * (x1 > 0 ? 1 : dg_mask_slope)): one read of dy and x1 instead of two.  Null dg_w: off.
+    const float* dg_w;
+    int dg_ldw;
+    float* dg_y0;
+    float* dg_y1;
+    float dg_mask_slope;
 };
 size_t wgrad1_workspace_bytes(int N, int Cin, int Cout, size_t V);
 int wgrad1_launch(const Wgrad1Args& a, hipStream_t s);
@@ -268,7 +277,16 @@ struct Conv1Args {
     // then applies to (and is laid out like) y1 only.  Two 1x1 convs of one input in one pass.
     float* y1;
     int Cout0;
+    // conv1_16_launch only (plain and scatter modes, no split output): fused GroupNorm-BACKWARD statistics, as Conv3Args::bst_* -- the
+    // stored output d (mask / residual included) is the gradient w.r.t. the activation after a GroupNorm of bst_y (laid out like the
+    // output tensor); the partial sums S1 = sum dh, S2' = sum dh*u (u = y*k1 + k2, dh = u > thr ? d : d*bst_slope) go to
+    // stat_partials [N][C][nblk][2], nblk = conv1_16_bst_nblk(a); gn_bwd_finalize_launch(..., s2_sign = 1) takes them.
+    const float* bst_y;
+    const float* bst_k;          // [N][3][C] (k1, k2, thr), C = channels of the output tensor
+    float bst_slope;
+    float* stat_partials;
 };
+int conv1_16_bst_nblk(const Conv1Args& a);      // partials per (sample, channel) the launch writes; 0: this shape has no fused-statistics form
 int conv1_launch(const Conv1Args& a, hipStream_t s);
 int transpose_launch(const float* src, float* dst, int rows, int cols, hipStream_t s);   // dst[c][r] = src[r][c]
 // NCDHW [N][C][V] <-> C16 [N][C/16][V][16] (C % 16 == 0); to_c16 = 1: src NCDHW -> dst C16, 0: the inverse
@@ -315,6 +333,9 @@ int bias_grad_launch(const float* dy, float* db, int N, int C, size_t V, void* w
 size_t bias_grad_workspace_bytes(int N, int C, size_t V);
 // dz = dp*p*(1-p) written as the zero-padded [N][V][4] copy + bias gradient, one pass (workspace as bias_grad)
 int head_grad_c4_launch(const float* p, const float* dp, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
+// the same with dp = the criterion's gradient (crit_grad_launch's arithmetic) formed in registers from (p, target, sums): dp is never written
+struct CritGradArgs { const float* target; const double* sums; double count; float w_dice, w_bce, bgw, priority; };
+int head_grad_c4_crit_launch(const float* p, const CritGradArgs& cg, float* d4, float* db, int N, int C, size_t V, void* ws, size_t ws_bytes, hipStream_t s);
 
 // ------------------------------------------------------------------ the same on the voxel-major layout C16 (pointwise_c16.hip)
 int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s,

@@ -468,6 +468,15 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
         for (int q = 0; q < CT; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int abase = (lane & 15) * W1_RS + (lane >> 4) + wave * 64;
     const long ntot = (long)a.N * nchunk;
+    // fused data gradient (Wgrad1Args::dg_*): A[m = input channel][k = output channel] fragments of this workgroup's CT channel tiles
+    const bool dgrad = a.dg_w != nullptr;
+    float dgw[CT][OT * 4];
+    if (dgrad) {
+#pragma unroll
+        for (int q = 0; q < CT; ++q)
+#pragma unroll
+            for (int ks = 0; ks < OT * 4; ++ks) dgw[q][ks] = a.dg_w[(size_t)(4 * ks + (lane >> 4)) * a.dg_ldw + c0 + q * 16 + (lane & 15)];
+    }
     for (long t = blockIdx.x; t < ntot; t += gridDim.x) {
         const int n = (int)(t / nchunk);
         const size_t v0 = (size_t)(t % nchunk) * W1_VC;
@@ -581,6 +590,32 @@ __global__ __launch_bounds__(256, 2) void wgrad1_f32_kernel(const Wgrad1Args a, 
 #pragma unroll
                 for (int q = 0; q < CT; ++q)
                     acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[p], bf[q], acc[p][q], 0, 0, 0);
+        }
+        if (dgrad) {
+            // dx[c][v] = sum_o w[o][c] dy[o][v] on the staged dy tile: wave w owns voxels 64 w .. 64 w + 63 (four 16-voxel tiles); the result
+            // tile D[m = channel][n = voxel] leaves each lane with 4 consecutive channels of one voxel = one float4 of the voxel-major output
+            const int xCB0 = a.x1 ? a.C0 >> 4 : a.Cin >> 4, xCB1 = a.x1 ? (a.Cin - a.C0) >> 4 : 1;
+#pragma unroll
+            for (int vt = 0; vt < 4; ++vt) {
+                const int vl = wave * 64 + vt * 16 + (lane & 15);
+                const size_t v = v0 + vl;
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < OT * 4; ++ks)
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(dgw[q][ks], dys[(4 * ks + (lane >> 4)) * W1_RS + vl], d, 0, 0, 0);
+                    const int kb = (c0 >> 4) + q;
+                    const bool second = kb >= xCB0;
+                    if (second) {                        // LeakyReLU backward from the staged x1 values (the activation's OUTPUT, model.py:422)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = xs[(q * 16 + 4 * (lane >> 4) + r) * W1_RS + vl] > 0.f ? d[r] : d[r] * a.dg_mask_slope;
+                    }
+                    float* dst = second ? a.dg_y1 : a.dg_y0;
+                    const size_t idx = (((size_t)n * (second ? xCB1 : xCB0) + (second ? kb - xCB0 : kb)) * V + v) * 16 + 4 * (lane >> 4);
+                    if (v < V && kb < (a.Cin >> 4)) *reinterpret_cast<float4*>(dst + idx) = make_float4(d[0], d[1], d[2], d[3]);
+                }
+            }
         }
     }
     // fold the four waves' accumulators through LDS (fixed order) and write ONE partial per workgroup
@@ -782,6 +817,8 @@ int wgrad1_launch(const Wgrad1Args& a, hipStream_t s) {
     RU_REQUIRE(!a.s2d || (a.c16 && a.Cin % 128 == 0 && (size_t)a.Dc * a.Hc * a.Wc == a.V), "wgrad1: bad stride-2 geometry");
     RU_REQUIRE(!a.x1 || (a.c16 && !a.s2d && a.C0 > 0 && a.C0 < a.Cin && a.C0 % 16 == 0), "wgrad1: a second input tensor needs voxel-major tensors and a split at a multiple of 16");
     const W1Choice c = wgrad1_choose(a.N, a.Cin, a.Cout, a.V);
+    RU_REQUIRE(!a.dg_w || (a.c16 && !a.s2d && a.Cout == c.ot * 16 && a.Cin % (c.ct * 16) == 0 && a.dg_y0 && (a.dg_y1 || !a.x1) && a.dg_ldw >= a.Cin),
+               "wgrad1: the fused data gradient needs voxel-major tensors, Cout <= 32 and whole channel tiles");
     if (!a.ws || a.ws_bytes < wgrad1_workspace_bytes(a.N, a.Cin, a.Cout, a.V)) {
         set_error("wgrad1: workspace too small");
         return RU_ENOMEM;

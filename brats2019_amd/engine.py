@@ -85,13 +85,13 @@ class UNetEngine:
         L.check(L.load().ru_unet_set_grad_precision(self.h, L.GRAD_PRECISIONS[grad_precision]), "ru_unet_set_grad_precision")
         self.grad_precision = grad_precision
 
-    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True, side_stream=True, batch_wreduce=True, tail_finalize=False):
+    def set_fusion(self, gn_bwd_stats=True, gn_bwd_apply=True, side_stream=True, batch_wreduce=True, tail_finalize=False, pw_dgrad=True):
         """Fusions of the voxel-major engine (ru_unet_set_fusion; tests switch them off to hold the fused kernels to the separate
         passes).  batch_wreduce: one launch sums the partials of every weight gradient of a backward pass; tail_finalize (opt-in: measured
         slower than the finalize launches it replaces): GroupNorm statistics / backward coefficients are finalized
-        by the last workgroup of the producing kernel."""
+        by the last workgroup of the producing kernel; pw_dgrad: the decoder's concat 1x1 weight-gradient kernel also forms its data gradient."""
         mask = ((L.FUSE_GN_BWD_STATS if gn_bwd_stats else 0) | (L.FUSE_GN_BWD_APPLY if gn_bwd_apply else 0) | (L.FUSE_SIDE_STREAM if side_stream else 0) |
-                (L.FUSE_BATCH_WREDUCE if batch_wreduce else 0) | (L.FUSE_TAIL_FINALIZE if tail_finalize else 0))
+                (L.FUSE_BATCH_WREDUCE if batch_wreduce else 0) | (L.FUSE_TAIL_FINALIZE if tail_finalize else 0) | (L.FUSE_PW_DGRAD if pw_dgrad else 0))
         L.check(L.load().ru_unet_set_fusion(self.h, mask), "ru_unet_set_fusion")
         self._ws_key = None                    # the backward's workspace layout depends on it
 
@@ -164,6 +164,18 @@ class UNetEngine:
         L.check(L.load().ru_unet_backward(self.h, L.f32(flat_params), L.f32(dprobs), L.f32(flat_grads), L.ptr(dx, True), L.stream()),
                 "ru_unet_backward")
         return (flat_grads, dx) if want_dx else flat_grads
+
+    def backward_criterion(self, flat_params, target, sums, count, w_dice, w_bce, bg_weight, priority, flat_grads=None):
+        """loss.backward() of the Dice/BCE criterion through the network in one call (ru_unet_backward_criterion): the criterion's gradient
+        (second phase of ops.criterion_grad) is formed inside the head's sigmoid-backward pass -- d(loss)/d(probs) is never written."""
+        if flat_grads is None:
+            flat_grads = torch.empty_like(flat_params)
+        if self._probs is None or tuple(target.shape) != tuple(self._probs.shape):
+            raise ValueError("backward_criterion: target must have the shape of the probabilities of the preceding training forward")
+        target = target.contiguous().float()
+        L.check(L.load().ru_unet_backward_criterion(self.h, L.f32(flat_params), L.f32(target), L.ptr(sums), float(count), float(w_dice), float(w_bce),
+                                                    float(bg_weight), float(priority), L.f32(flat_grads), None, L.stream()), "ru_unet_backward_criterion")
+        return flat_grads
 
     def gn_stats(self):
         """[(mean[N*8], rstd[N*8])] of every GroupNorm of the last forward, in execution order."""

@@ -74,6 +74,10 @@ class HipBackend:
     def backward(self, flat, dprobs, grads):
         return self.engine.backward(flat, dprobs, flat_grads=grads)
 
+    def backward_criterion(self, flat, target, sums, count, bg_weight, priority, grads):
+        """criterion gradient + backward in one call: d(loss)/d(probs) is formed inside the head's first backward pass, never written"""
+        return self.engine.backward_criterion(flat, target, sums, count, 0.5, 0.5, bg_weight, priority, flat_grads=grads)
+
     def adam(self, flat, grads, m, v, vmax, step, lr, betas, eps, weight_decay):
         from . import ops
         for a, b in self.live_segments:
@@ -177,6 +181,7 @@ class DataParallelStep:
         self.group = process_group
         self.global_step = 0
         self.comm = comm                       # RcclComm: the collectives go through ru_allreduce on the kernels' stream
+        self.fuse_criterion_grad = True        # the criterion's gradient is formed inside the backward's first pass (ru_unet_backward_criterion)
         self.comm_probe = None                 # bench.py: a list -> every collective of a step is bracketed by an event pair on the current stream
         if comm is not None:
             self.distributed, self.world, self.rank = True, comm.world, comm.rank
@@ -206,8 +211,11 @@ class DataParallelStep:
             self._all_reduce(sums)
         count = float(probs.numel()) * self.world
         loss, dice, bce = b.criterion_losses(sums, count, self.priority)
-        dprobs = b.criterion_grad(probs, target_shard, sums, count, self.bg_weight, self.priority)
-        b.backward(self.flat, dprobs, self.grads)
+        if self.fuse_criterion_grad and hasattr(b, "backward_criterion"):
+            b.backward_criterion(self.flat, target_shard, sums, count, self.bg_weight, self.priority, self.grads)
+        else:
+            dprobs = b.criterion_grad(probs, target_shard, sums, count, self.bg_weight, self.priority)
+            b.backward(self.flat, dprobs, self.grads)
         if self.distributed:
             # only the live runs of the flat bucket travel: the never-executed deepest decoder stage (a third of the 21.7 MB) has zero
             # gradients on every rank.  SUM, not mean: the criterion already carries the global 1/count.

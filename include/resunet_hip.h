@@ -187,6 +187,10 @@ int ru_unet_get_grad_precision(ru_unet_t h);
  *                         boundary cost.  */
 #define RU_FUSE_BATCH_WREDUCE 8
 #define RU_FUSE_TAIL_FINALIZE 16
+/*   RU_FUSE_PW_DGRAD      decoder 1x1x1 conv over the (never materialised) concat, Cout <= 32: its weight-gradient kernel also forms the data
+ *                         gradient of both halves from the dy tile it has staged (LeakyReLU backward of the up-sampled half included) --
+ *                         one pass over (dy, skip, up) instead of two.  */
+#define RU_FUSE_PW_DGRAD 32
 int ru_unet_set_fusion(ru_unet_t h, unsigned mask);
 /* In-situ timing of the dominant kernel (bench.py's roofline line): while enabled, every forward brackets its launches of
  * the 3x3x3 convolution 16 -> 16 at the input resolution (voxel-major split-bf16 engine; the forward of the shipped net has four) with a
@@ -223,6 +227,14 @@ int ru_unet_forward(ru_unet_t h, const float* params, const float* x, float* pro
  * Must follow a training-mode ru_unet_forward with the same params/ws.  dx (may be NULL) = d/d(input).  */
 int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx,
                      ru_stream_t stream);
+/* The same with the criterion's gradient formed on the way (train.py:203-210: `loss = (Dice + BCE) / 2; loss.backward()`): dprobs is not an
+ * operand but the second phase of the criterion -- ru_criterion_grad(probs, target, sums, count, w_dice, w_bce, bg_weight, priority) --
+ * evaluated inside the head's sigmoid-backward pass from the probabilities the forward wrote to the caller's buffer, `target` and the
+ * (all-reduced) `sums` of ru_criterion_sums: the gradient w.r.t. the probabilities is never written or read back (one pass instead of
+ * three over the class tensors; same float arithmetic in the same order, bit-identical gradients).  */
+int ru_unet_backward_criterion(ru_unet_t h, const float* params, const float* target, const double* sums, double count,
+                               float w_dice, float w_bce, float bg_weight, float priority, float* grads, float* dx,
+                               ru_stream_t stream);
 /* per-layer GroupNorm statistics of the last forward, for parity checks: copies mean/rstd [N*8] of the
  * idx-th executed GroupNorm (execution order) into DEVICE buffers.  Returns number of GN layers if idx<0. */
 int ru_unet_gn_stats(ru_unet_t h, int idx, float* mean, float* rstd, ru_stream_t stream);

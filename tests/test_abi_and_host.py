@@ -174,8 +174,8 @@ def test_argument_errors_are_reported_not_thrown(lib):
     from brats2019_amd import _lib as L
     from brats2019_amd.engine import ParamLayout
     lay = ParamLayout(**O.DEFAULT_CFG)
-    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0 and lib.ru_unet_set_fusion(lay.handle, 31) == 0
-    assert lib.ru_unet_set_fusion(lay.handle, 32) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
+    assert lib.ru_unet_set_fusion(lay.handle, 0) == 0 and lib.ru_unet_set_fusion(lay.handle, 3) == 0 and lib.ru_unet_set_fusion(lay.handle, 63) == 0
+    assert lib.ru_unet_set_fusion(lay.handle, 64) < 0 and b"ru_unet_set_fusion" in lib.ru_last_error()
     assert lib.ru_unet_set_precision(lay.handle, 7) < 0
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 12, 16, 16, 0) == 0            # extents must be divisible by 2^(depth-1)
     assert lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 1) > lib.ru_unet_workspace_bytes(lay.handle, 1, 16, 16, 16, 0) > 0

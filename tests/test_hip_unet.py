@@ -682,9 +682,9 @@ def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
     same partials in another fixed order (float64), so statistics agree to float rounding.  Two runs with the tails on are bit-identical
     (no float atomics; the ticket words are reset by the finisher), sizes at which persistent, 4-channel and one-stage kernels all occur."""
     res = {}
-    for key, (batch, tail) in {"plain": (False, False), "batch": (True, False), "tail": (True, True), "tail2": (True, True)}.items():
+    for key, (batch, tail) in {"plain": (False, False), "batch": (True, False), "tail": (True, True), "tail2": (True, True), "nopw": (True, False)}.items():
         net, _ = build_model(O.DEFAULT_CFG, 77, "bf16x3")
-        net._get_engine().set_fusion(True, True, True, batch, tail)
+        net._get_engine().set_fusion(True, True, True, batch, tail, pw_dgrad=(key != "nopw"))
         x = T(O.make_input(2, 64, 64, 64, seed=77)).cuda()
         g = T(O.make_target(2, 64, 64, 64, seed=77)).cuda()
         from brats2019_amd import loss as L
@@ -706,3 +706,34 @@ def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
                 for k in res["plain"][1])
     print("tail finalize vs finalize launches: max |dp| %.2e, worst relative L2 gradient difference %.2e" % (dp, worst))
     assert dp <= 1e-6 and worst <= 1e-4, (dp, worst)
+    # RU_FUSE_PW_DGRAD: the concat 1x1's data gradient formed inside its weight-gradient kernel (exact-f32 MFMA, K = Cout in one pass) against
+    # the conv1_16 launch it replaces (same products, the accumulation walks the output channels in the same order)
+    assert torch.equal(res["nopw"][0], res["batch"][0])
+    worst_pw = max(float(torch.linalg.vector_norm(res["nopw"][1][k].double() - res["batch"][1][k].double()) / torch.linalg.vector_norm(res["batch"][1][k].double()))
+                   for k in res["batch"][1])
+    print("fused 1x1 data gradient vs the conv1_16 launch: worst relative L2 gradient difference %.2e" % worst_pw)
+    assert worst_pw <= 1e-5, worst_pw
+
+
+def test_backward_criterion_equals_criterion_grad_then_backward():
+    """ru_unet_backward_criterion (the criterion's gradient formed inside the head's sigmoid-backward pass, d(loss)/d(probs) never written;
+    what DataParallelStep runs) against ru_criterion_grad followed by ru_unet_backward on the same forward: same float operations in the
+    same order, so the gradient bucket must agree to the last bits (asserted to 1e-6 relative L2; printed whether bit-identical)."""
+    from brats2019_amd import parallel as P
+    be = P.HipBackend(cfg=O.DEFAULT_CFG)
+    flat = be.new_flat()
+    for k, v in be.engine.layout.views(flat).items():
+        v.copy_(T(O.make_params(5, **O.DEFAULT_CFG)[k]))
+    x = T(O.make_input(2, 64, 64, 64, seed=5)).cuda()
+    g = T(O.make_target(2, 64, 64, 64, seed=5)).cuda()
+    res = {}
+    for fused in (False, True):
+        st = P.DataParallelStep(be, flat)
+        st.fuse_criterion_grad = fused
+        loss, _, _ = st.loss_and_grads(x, g)
+        res[fused] = (float(loss), st.grads.clone())
+    assert res[True][0] == res[False][0]
+    a, b = res[True][1].double(), res[False][1].double()
+    rel = float(torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(b))
+    print("backward_criterion vs criterion_grad + backward: relative L2 %.2e (%s)" % (rel, "bit-identical" if torch.equal(res[True][1], res[False][1]) else "not bit-identical"))
+    assert rel <= 1e-6, rel
