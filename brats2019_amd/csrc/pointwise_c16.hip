@@ -9,10 +9,15 @@
 // parameters once.
 #include "pw_helpers.hpp"
 #include "fin_tail.hpp"
+#include <type_traits>
 
 namespace ru {
 
 typedef float f32x4_c16 __attribute__((ext_vector_type(4)));
+template <int I, int N, class F> __device__ __forceinline__ void static_for_c1_impl(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_c1_impl<I + 1, N>(f); }
+}
+template <int N, class F> __device__ __forceinline__ void static_for_c1(F&& f) { static_for_c1_impl<0, N>(f); }
 
 static inline dim3 c16_grid(size_t V, int blocks_nc, unsigned cap = 2048) {
     size_t bx = (V * 4 + 255) / 256;
@@ -366,15 +371,18 @@ int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin,
 // K index of lane group g in step e is channel 4g + e on both sides.  D: lane holds output channels 4g..4g+3 of voxel r:
 // one aligned float4 of the C16 output.  A wave owns 64 voxels x COB*16 output channels.
 // S2D: 0 plain, 1 gather (stride-2 conv), 2 scatter (its transpose) -- compile-time, so the K loop has no branch around its loads
-// BST: fused GroupNorm-backward statistics of the stored output (Conv1Args::bst_*).  A wave then walks C1_VTL voxel tiles (fewer,
-// larger partials: one per workgroup and channel block), the four waves' sums meet in LDS.
-constexpr int C1_VTL = 4;
-template <int COB, int S2D, bool BST>
+// NSLOT > 0: fused GroupNorm-backward statistics of the stored output (Conv1Args::bst_*).  NSLOT = distinct 16-channel blocks of the OUTPUT
+// tensor a workgroup touches: COB in the plain mode; in scatter mode the COB blocks of a workgroup are (tap, fine block) pairs and block
+// cb carries fine block cb % NSLOT (NSLOT = fine channel blocks, 1 / 2 / 4) -- the sums and constants are kept per SLOT, not per block
+// (registers: the kernel is a latency-bound stream and lives on occupancy).  The four waves' sums meet in LDS: one partial per
+// (workgroup, channel).
+template <int COB, int S2D, int NSLOT>
 __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nvt) {
-    __shared__ float red[BST ? 4 * COB * 16 * 2 : 1];
+    constexpr bool BST = NSLOT > 0;
+    constexpr int NSL = BST ? NSLOT : 1;
+    __shared__ float red[BST ? 4 * NSL * 16 * 2 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.z, cog = blockIdx.y;
-    constexpr int VTL = BST ? C1_VTL : 1;
     const size_t V = a.V;
     const int r = lane & 15, g = lane >> 4;
     const int nkb0 = a.C0 >> 4, nkb1 = a.C1 >> 4, nkb = nkb0 + nkb1, CBo = a.Cout >> 4;
@@ -383,21 +391,21 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
     const size_t Vf = V * 8;
     const int CBf_out = CBo >> 3;                        // scatter: channel blocks of the fine output tensor
     const int Cstat = S2D == 2 ? (a.Cout >> 3) : a.Cout; // BST: channels of the output tensor
-    f32x4_c16 bs1[COB], bs2[COB], bk[COB][3];
+    f32x4_c16 bs1[NSL], bs2[NSL], bk[NSL][3];
     if constexpr (BST) {
 #pragma unroll
-        for (int cb = 0; cb < COB; ++cb) {
-            bs1[cb] = f32x4_c16{0.f, 0.f, 0.f, 0.f}; bs2[cb] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
-            const int cob = cog * COB + cb, chb = S2D == 2 ? cob % CBf_out : cob;
+        for (int sl = 0; sl < NSL; ++sl) {
+            bs1[sl] = f32x4_c16{0.f, 0.f, 0.f, 0.f}; bs2[sl] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+            const int cob = cog * COB + sl, chb = S2D == 2 ? cob % CBf_out : cob;
             const float* kp = a.bst_k + (size_t)n * 3 * Cstat + (cob < CBo ? chb : 0) * 16 + 4 * g;
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) { const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t3 * Cstat); bk[cb][t3] = f32x4_c16{q.x, q.y, q.z, q.w}; }
+            for (int t3 = 0; t3 < 3; ++t3) { const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t3 * Cstat); bk[sl][t3] = f32x4_c16{q.x, q.y, q.z, q.w}; }
         }
     }
-#pragma unroll 1
-    for (int it = 0; it < VTL; ++it) {
-    const int vt = (blockIdx.x * 4 + wave) * VTL + it;
-    if (vt >= nvt) { if constexpr (BST) break; else return; }
+    const int vt = blockIdx.x * 4 + wave;
+    const bool live = vt < nvt;
+    if (!live) { if constexpr (!BST) return; }
+    if (live) {
     const size_t v0 = (size_t)vt * 64;
     size_t vb[4], fv[4];                                 // float offset of this lane's voxel (coarse) / its fine corner voxel index
 #pragma unroll
@@ -491,50 +499,50 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
             *reinterpret_cast<float4*>(ydst + idx) = o;
             if constexpr (BST) {                         // sums of the STORED gradient (sb_out_tile_bst's arithmetic)
+                constexpr int sl = 0;
+                (void)sl;
                 const float4 yq = *reinterpret_cast<const float4*>(a.bst_y + idx);
-                const f32x4_c16 u = f32x4_c16{yq.x, yq.y, yq.z, yq.w} * bk[cb][0] + bk[cb][1];
                 const f32x4_c16 ov = f32x4_c16{o.x, o.y, o.z, o.w}, os = ov * a.bst_slope;
-                f32x4_c16 dh;
+                static_for_c1<NSL>([&](auto SL) {        // (compile-time slot: no register array is indexed by a run-time value)
+                    constexpr int s_ = decltype(SL)::value;
+                    if (cb % NSL == s_) {
+                        const f32x4_c16 u = f32x4_c16{yq.x, yq.y, yq.z, yq.w} * bk[s_][0] + bk[s_][1];
+                        f32x4_c16 dh;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dh[e] = u[e] > bk[cb][2][e] ? ov[e] : os[e];
-                bs1[cb] += dh;
-                bs2[cb] += dh * u;
+                        for (int e = 0; e < 4; ++e) dh[e] = u[e] > bk[s_][2][e] ? ov[e] : os[e];
+                        bs1[s_] += dh;
+                        bs2[s_] += dh * u;
+                    }
+                });
             }
         }
     }
-    }                                                    // voxel-tile loop
+    }                                                    // live
     if constexpr (BST) {
-        // lanes sharing g hold the same channel quad: fold the 16 voxel lanes, then the four waves; blocks of one workgroup that carry the
-        // same output channels (scatter mode: different taps) are added in block order -- one partial per (workgroup, channel)
+        // lanes sharing g hold the same channel quad: fold the 16 voxel lanes, then the four waves -- one partial per (workgroup, channel)
 #pragma unroll
-        for (int cb = 0; cb < COB; ++cb) {
+        for (int sl = 0; sl < NSL; ++sl) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { bs1[cb][e] += __shfl_xor(bs1[cb][e], o); bs2[cb][e] += __shfl_xor(bs2[cb][e], o); }
+                for (int o = 1; o < 16; o <<= 1) { bs1[sl][e] += __shfl_xor(bs1[sl][e], o); bs2[sl][e] += __shfl_xor(bs2[sl][e], o); }
             }
             if (r == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { red[((wave * COB + cb) * 16 + 4 * g + e) * 2] = bs1[cb][e]; red[((wave * COB + cb) * 16 + 4 * g + e) * 2 + 1] = bs2[cb][e]; }
+                for (int e = 0; e < 4; ++e) { red[((wave * NSL + sl) * 16 + 4 * g + e) * 2] = bs1[sl][e]; red[((wave * NSL + sl) * 16 + 4 * g + e) * 2 + 1] = bs2[sl][e]; }
             }
         }
         __syncthreads();
-        const int nslot = S2D == 2 ? (CBf_out < COB ? CBf_out : COB) : COB;         // distinct channel blocks this workgroup touches
-        const int per = COB / nslot;                                                   // blocks per slot (scatter: taps)
         const int nblk = S2D == 2 ? gridDim.x * gridDim.y : gridDim.x;
         const int blk = S2D == 2 ? blockIdx.y * gridDim.x + blockIdx.x : blockIdx.x;
-        for (int i = threadIdx.x; i < nslot * 16; i += 256) {
+        for (int i = threadIdx.x; i < NSL * 16; i += 256) {
             const int slot = i >> 4, c = i & 15;
-            const int cob0 = cog * COB + slot;                                        // first block of the slot; the others follow at stride nslot
+            const int cob0 = cog * COB + slot;
             if (cob0 >= CBo) continue;
             const int chb = S2D == 2 ? cob0 % CBf_out : cob0;
             float u1 = 0.f, u2 = 0.f;
-            for (int j = 0; j < per; ++j) {
-                const int cb = slot + j * nslot;
-                if (cog * COB + cb >= CBo) break;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { u1 += red[((w * COB + cb) * 16 + c) * 2]; u2 += red[((w * COB + cb) * 16 + c) * 2 + 1]; }
-            }
+            for (int w = 0; w < 4; ++w) { u1 += red[((w * NSL + slot) * 16 + c) * 2]; u2 += red[((w * NSL + slot) * 16 + c) * 2 + 1]; }
             float* p = a.stat_partials + (((size_t)n * Cstat + chb * 16 + c) * nblk + blk) * 2;
             p[0] = u1; p[1] = u2;
         }
@@ -544,10 +552,10 @@ int conv1_16_bst_nblk(const Conv1Args& a) {
     if (a.s2d == 1 || a.y1 || a.Cout % 16 || a.V == 0) return 0;
     const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
     const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
-    const int gx = cdiv(nvt, 4 * C1_VTL), gy = cdiv(CBo, cob);
+    const int gx = cdiv(nvt, 4), gy = cdiv(CBo, cob);
     if (a.s2d == 2) {
         const int cbf = CBo >> 3;                        // every workgroup must carry whole groups of taps of the same fine channel blocks
-        if (a.Cout % 128 || cbf > cob || cob % cbf) return 0;
+        if (a.Cout % 128 || cob != 4 || (cbf != 1 && cbf != 2 && cbf != 4)) return 0;
         return gx * gy;
     }
     return gx;
@@ -565,14 +573,17 @@ int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
     const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
     const bool bst = a.bst_y != nullptr;
     RU_REQUIRE(!bst || (a.bst_k && a.stat_partials && a.s2d != 1 && !a.y1 && conv1_16_bst_nblk(a) > 0), "conv1_16: fused GroupNorm-backward statistics need the plain or scatter mode with whole channel blocks per workgroup");
-    dim3 grid((unsigned)cdiv(nvt, 4 * (bst ? C1_VTL : 1)), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
+    dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
+    const int nslot = !bst ? 0 : (a.s2d == 2 ? (CBo >> 3) : cob);          // distinct output channel blocks per workgroup (conv1_16_bst_nblk checked the shape)
 #define RU_C1_LAUNCH(COB_)                                                                                          \
     do {                                                                                                           \
-        if (a.s2d == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 1, false>), grid, dim3(256), 0, s, a, nvt);       \
-        else if (a.s2d == 2 && bst) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, true>), grid, dim3(256), 0, s, a, nvt);  \
-        else if (a.s2d == 2) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, false>), grid, dim3(256), 0, s, a, nvt);  \
-        else if (bst) hipLaunchKernelGGL((conv1_16_kernel<COB_, 0, true>), grid, dim3(256), 0, s, a, nvt);          \
-        else hipLaunchKernelGGL((conv1_16_kernel<COB_, 0, false>), grid, dim3(256), 0, s, a, nvt);                  \
+        if (a.s2d == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 1, 0>), grid, dim3(256), 0, s, a, nvt);           \
+        else if (a.s2d == 2 && nslot == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, 1>), grid, dim3(256), 0, s, a, nvt);  \
+        else if (a.s2d == 2 && nslot == 2) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, (COB_ >= 2 ? 2 : 1)>), grid, dim3(256), 0, s, a, nvt);  \
+        else if (a.s2d == 2 && nslot == 4) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, (COB_ >= 4 ? 4 : 1)>), grid, dim3(256), 0, s, a, nvt);  \
+        else if (a.s2d == 2) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, 0>), grid, dim3(256), 0, s, a, nvt);      \
+        else if (bst) hipLaunchKernelGGL((conv1_16_kernel<COB_, 0, COB_>), grid, dim3(256), 0, s, a, nvt);          \
+        else hipLaunchKernelGGL((conv1_16_kernel<COB_, 0, 0>), grid, dim3(256), 0, s, a, nvt);                      \
     } while (0)
     if (cob == 4) RU_C1_LAUNCH(4);
     else if (cob == 2) RU_C1_LAUNCH(2);

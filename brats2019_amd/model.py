@@ -286,16 +286,36 @@ class UNet(nn.Module):
 
     def load_state_dict(self, *args, **kwargs):                   # writes through the aliased flat buffer in place
         self._unfreeze()
+        self.__dict__.pop("_flat_checked", None)
         return super().load_state_dict(*args, **kwargs)
 
     def _param_order(self):
         self._get_engine()
         return self.__dict__["_param_names"]
 
+    def _apply(self, fn, *args, **kwargs):                       # .cuda() / .to() / .float(): the parameters move, the alias check must run again
+        self.__dict__.pop("_flat_checked", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def _param_list(self):
+        """the nn.Parameter objects in state-dict order (they outlive .cuda() / load_state_dict: only their .data moves)"""
+        lst = self.__dict__.get("_params_cached")
+        if lst is None:
+            lst = [p for _, p in self.named_parameters()]
+            self.__dict__["_params_cached"] = lst
+        return lst
+
     def _flat_params(self):
         """One flat float32 device buffer aliased by every nn.Parameter (re-built if .to()/.cuda() broke the aliasing)."""
         eng = self._get_engine()
         flat = self.__dict__.get("_flat_buf")
+        if flat is not None and self.__dict__.get("_flat_checked"):
+            # steady state (a forward per step or per tile): the full walk over 93 pointers ran once after the last move; between moves only
+            # the first and last parameter are looked at (an optimizer updates in place; `p.data = ...` on a middle tensor is not a supported move)
+            lst = self._param_list()
+            first, last = self.__dict__["_flat_ends"]
+            if lst[0].data_ptr() == first and lst[-1].data_ptr() == last:
+                return flat
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
         ok = flat is not None and flat.device == dev
@@ -316,6 +336,9 @@ class UNet(nn.Module):
                     view.copy_(params[name].data)
                     params[name].data = view
             self.__dict__["_flat_buf"] = flat
+        lst = self._param_list()
+        self.__dict__["_flat_ends"] = (lst[0].data_ptr(), lst[-1].data_ptr())
+        self.__dict__["_flat_checked"] = True
         return flat
 
     def _replicate_for_data_parallel(self):
@@ -329,7 +352,7 @@ class UNet(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads"):     # never pickle the ctypes handle / the alias buffer
+        for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads", "_flat_checked", "_flat_ends", "_params_cached"):     # never pickle the ctypes handle / the alias buffer
             state.pop(k, None)
         return state
 
@@ -338,7 +361,7 @@ class UNet(nn.Module):
         inp = x[0]                                                # model.py:410
         if not inp.is_cuda:
             raise RuntimeError("brats2019_amd.model.UNet: input must be a ROCm device tensor (HIP-only path)")
-        params = [p for _, p in self.named_parameters()]
+        params = self._param_list()
         training = torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in params))
         probs = _UNetFn.apply(self, training, inp, *params)
         return [probs]                                            # model.py:433

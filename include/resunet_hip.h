@@ -231,7 +231,8 @@ int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, floa
  * operand but the second phase of the criterion -- ru_criterion_grad(probs, target, sums, count, w_dice, w_bce, bg_weight, priority) --
  * evaluated inside the head's sigmoid-backward pass from the probabilities the forward wrote to the caller's buffer, `target` and the
  * (all-reduced) `sums` of ru_criterion_sums: the gradient w.r.t. the probabilities is never written or read back (one pass instead of
- * three over the class tensors; same float arithmetic in the same order, bit-identical gradients).  */
+ * three over the class tensors; the same float expressions, so the gradients agree with the two-call sequence to float rounding --
+ * 1e-7 relative L2 measured, tests/test_hip_unet.py).  */
 int ru_unet_backward_criterion(ru_unet_t h, const float* params, const float* target, const double* sums, double count,
                                float w_dice, float w_bce, float bg_weight, float priority, float* grads, float* dx,
                                ru_stream_t stream);

@@ -66,9 +66,9 @@ def main():
                 old = json.load(open(dst)) if os.path.exists(dst) else {}
                 hist = old.get("history", {})
                 if "hbm_bytes_per_launch" in old:
-                    hist["round 1 consumer (one A fragment per M-tile and K-step)"] = {k: old[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch") if k in old}
+                    hist["previous file (%s)" % old.get("source", "?").split(";")[-1].strip()] = {k: old[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch", "avg_launch_us_in_trace", "mfma_busy_pct") if k in old}
                 json.dump({"kernel": "conv3_sb2_kernel<4,8,C16 in,C16 out,single chunk> (3x3x3 conv 16->16, split-bf16 x3, batch 4 x 128^3, voxel-major tensors)",
-                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; round 2",
+                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; %s" % os.environ.get("RU_ROUND_TAG", "round 4"),
                            "FETCH_SIZE_KB": mean("FETCH_SIZE"), "WRITE_SIZE_KB": mean("WRITE_SIZE"),
                            "correction": "FETCH_SIZE x2 for 16-byte-per-lane streaming reads on gfx950 (guide); WRITE_SIZE uncorrected",
                            "hbm_bytes_per_launch": int((2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024), "algorithmic_bytes_per_launch": int(alg_bytes),
