@@ -26,6 +26,25 @@ def _all_reduce_sums(sums, group):
     return 1
 
 
+def _hand_over(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority, gout):
+    """Backward of a criterion whose `pred` is DIRECTLY the output of model.UNet's autograd node: instead of writing d(loss)/d(pred) (a
+    100 MB pass that the network's backward reads straight back), describe it to that node -- it forms the gradient inside its first pass
+    (ru_unet_backward_criterion) -- and return a zero-stride placeholder of pred's shape.  Returns None when the hand-over does not apply
+    (another producer of pred, a second criterion on the same probabilities, d/d(input) wanted): the caller then writes the gradient."""
+    node = pred.grad_fn
+    if node is None or not getattr(node, "accepts_criterion", False) or type(node).__name__ != "_UNetFnBackward":
+        return None
+    if getattr(node, "pending_criterion", None) is not None:
+        # a second criterion on the same probabilities (the list evaluated module by module): both gradients are written out -- the
+        # first one's placeholder is zeros, so autograd's sum is this tensor
+        pc, node.pending_criterion = node.pending_criterion, None
+        first = ops.criterion_grad(pred, pc["target"], pc["sums"], pc["count"], pc["w_dice"], pc["w_bce"], pc["bg_weight"], pc["priority"]).mul_(pc["gout"].to(torch.float32))
+        return first.add_(ops.criterion_grad(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority).mul_(gout.to(torch.float32)))
+    dummy = torch.zeros((), dtype=pred.dtype, device=pred.device).expand(pred.shape)
+    node.pending_criterion = dict(target=gt, sums=sums, count=count, w_dice=w_dice, w_bce=w_bce, bg_weight=bg_weight, priority=priority, gout=gout, dummy=dummy)
+    return dummy
+
+
 class _CriterionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, w_dice, w_bce, bg_weight, priority, group):
@@ -41,8 +60,11 @@ class _CriterionFn(torch.autograd.Function):
     def backward(ctx, gout):
         pred, gt, sums = ctx.saved_tensors
         count, w_dice, w_bce, bg_weight, priority = ctx.cfg
-        dp = ops.criterion_grad(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority)
-        return dp.mul_(gout.to(dp.dtype)), None, None, None, None, None, None
+        dp = _hand_over(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority, gout)
+        if dp is None:
+            dp = ops.criterion_grad(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority)
+            dp.mul_(gout.to(dp.dtype))
+        return dp, None, None, None, None, None, None
 
 
 class _PairFn(torch.autograd.Function):
@@ -65,8 +87,11 @@ class _PairFn(torch.autograd.Function):
     def backward(ctx, gout, _gd, _gb):
         pred, gt, sums = ctx.saved_tensors
         count, bg_weight, priority = ctx.cfg
-        dp = ops.criterion_grad(pred, gt, sums, count, 0.5, 0.5, bg_weight, priority)
-        return dp.mul_(gout.to(dp.dtype)), None, None, None, None
+        dp = _hand_over(pred, gt, sums, count, 0.5, 0.5, bg_weight, priority, gout)
+        if dp is None:
+            dp = ops.criterion_grad(pred, gt, sums, count, 0.5, 0.5, bg_weight, priority)
+            dp.mul_(gout.to(dp.dtype))
+        return dp, None, None, None, None
 
 
 def fuse_criterion_list(criterion):

@@ -160,6 +160,10 @@ class _UNetFn(torch.autograd.Function):
         probs = eng.forward(flat, x, training=training)
         ctx.net, ctx.generation, ctx.training = net, eng.generation, training
         ctx.x_needs_grad = x.requires_grad
+        # loss._PairFn / _CriterionFn hand their gradient over as a DESCRIPTION (target, sums, weights) when the probabilities they were given
+        # are this node's output: the executor then forms d(loss)/d(probs) inside its first backward pass (ru_unet_backward_criterion)
+        ctx.accepts_criterion = bool(training) and not x.requires_grad
+        ctx.pending_criterion = None
         if training:
             ctx.save_for_backward(probs)          # the executor reads this buffer again in backward: autograd's version check then
         return probs                              # catches an in-place edit of the returned probabilities
@@ -174,8 +178,19 @@ class _UNetFn(torch.autograd.Function):
             raise RuntimeError("UNet.forward was called again before backward(): the executor keeps ONE forward state")
         _ = ctx.saved_tensors                     # raises if the probabilities were modified in place since the forward
         flat = net._flat_params()
-        res = eng.backward(flat, dprobs, want_dx=ctx.x_needs_grad)
-        grads, dx = res if ctx.x_needs_grad else (res, None)
+        pc, ctx.pending_criterion = ctx.pending_criterion, None
+        if pc is not None and dprobs.data_ptr() == pc["dummy"].data_ptr() and not any(dprobs.stride()):
+            # the incoming "gradient" is the criterion's zero-stride placeholder and nothing else was added to it: form the real one on the way
+            grads = eng.backward_criterion(flat, pc["target"], pc["sums"], pc["count"], pc["w_dice"], pc["w_bce"], pc["bg_weight"], pc["priority"])
+            grads.mul_(pc["gout"].to(grads.dtype))                 # d(final loss)/d(criterion value): 21 MB, once (1 for `loss.backward()`)
+            dx = None
+        else:
+            if pc is not None:                    # somebody else also used the probabilities: the placeholder was summed with a real gradient
+                from . import ops
+                dprobs = dprobs + ops.criterion_grad(ctx.saved_tensors[0], pc["target"], pc["sums"], pc["count"], pc["w_dice"], pc["w_bce"], pc["bg_weight"],
+                                                     pc["priority"]).mul_(pc["gout"].to(dprobs.dtype))
+            res = eng.backward(flat, dprobs, want_dx=ctx.x_needs_grad)
+            grads, dx = res if ctx.x_needs_grad else (res, None)
         net.__dict__["_last_flat_grads"] = grads      # parallel.all_reduce_gradients reduces this bucket in place when p.grad alias it
         views = eng.layout.views(grads)
         out = []

@@ -450,6 +450,31 @@ def test_fused_and_unfused_backward_agree_tightly():
     assert worst_v[0] < 2e-3, worst_v
 
 
+@pytest.mark.parametrize("n,dhw", [(3, (24, 40, 48)), (2, (40, 72, 88)), (1, (64, 64, 64))], ids=["b3-24x40x48", "b2-40x72x88", "b1-64"])
+def test_round4_backward_fusions_on_ragged_shapes(n, dhw):
+    """The round-4 backward fusions -- GroupNorm-backward sums in the store pass of the 1x1 / stride-2-transpose kernels (conv1_16 NSLOT
+    variants at every level), the decoder 1x1 data gradient inside its weight-gradient kernel, the batched weight-gradient reduce, the
+    criterion-direct head pass -- at extents that are not multiples of the tiles (partial voxel tiles in every kernel), odd batch sizes and
+    shapes where the deep levels take the one-stage kernels: all fusions on against all of them off on the same forward."""
+    net, _ = build_model(O.DEFAULT_CFG, 90 + n, "bf16x3")
+    x = T(O.make_input(n, *dhw, seed=90 + n)).cuda()
+    w = torch.randn((n, 3) + dhw, generator=torch.Generator().manual_seed(2)).cuda() * 1e-3
+    res = {}
+    for key, args in (("on", (True, True, True, True, False, True)), ("off", (False, False, False, False, False, False))):
+        net._get_engine().set_fusion(*args)
+        net.zero_grad()
+        p = net([x])[0]
+        (p * w).sum().backward()
+        res[key] = (p.detach().clone(), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
+    assert torch.equal(res["on"][0], res["off"][0])
+    rel = {k: float((res["on"][1][k] - res["off"][1][k]).norm() / (res["off"][1][k].norm() + 1e-30)) for k in res["on"][1]}
+    worst_w = max((v, k) for k, v in rel.items() if res["on"][1][k].dim() == 5)
+    worst_v = max((v, k) for k, v in rel.items() if res["on"][1][k].dim() != 5)
+    print("fusions on vs off at %s x %s: worst relative L2 %.2e (%s) on conv weights, %.2e (%s) on vectors" % ((n, dhw) + worst_w + worst_v))
+    assert worst_w[0] < 2e-4, worst_w
+    assert worst_v[0] < 2e-3, worst_v
+
+
 def test_side_stream_weight_gradients_are_bit_identical():
     """RU_FUSE_SIDE_STREAM only moves the deep-level 3x3x3 weight gradients to a second HIP stream (event-ordered, joined before
     ru_unet_backward returns): same kernels on the same operands -- every gradient must be bit-identical with it on and off, twice in a row

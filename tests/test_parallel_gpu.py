@@ -126,4 +126,11 @@ def test_bare_bench_launches_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 2 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
     assert out["fwd"]["replicas"] == 2 and out["fwd"]["value"] > 0
+    assert out["fwd_batch"]["replicas"] == 2 and out["fwd_batch"]["value"] > 0
     assert np.isfinite(out["final_loss"])
+    # what explains a scaling curve from the line alone (round 4): the collectives timed in place, per-rank step times, who talked to whom
+    ar = out["allreduce_ms"]
+    assert ar["gradients"] > 0 and ar["criterion_sums"] > 0 and len(ar["per_rank_gradients"]) == 2 and ar["gradient_bytes"] > 4 * 4_000_000
+    pr = out["step_ms_per_rank"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - out["ms_per_step"]) < 1e-2 * out["ms_per_step"] + 1e-3
+    assert out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo" and "gloo" in out["transport"]
