@@ -81,6 +81,7 @@ SIGNATURES = {
     "ru_tta_merge": (_i, [_vp, _i, C.c_uint, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ru_compose_labels": (_i, [_vp, _vp, C.c_ulonglong, _vp, _sz, _vp]),
     "ru_dice_counts": (_i, [_vp, _vp, _vp, _i, _i, _sz, _vp]),
+    "ru_dice_accumulate": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ru_tile_gather": (_i, [_vp, _vp] + [_i] * 6 + [C.POINTER(_i), _i, _i, _i, _vp]),
     "ru_tile_scatter": (_i, [_vp, _vp] + [_i] * 6 + [C.POINTER(_i), _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]),
     "ru_case_bbox": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

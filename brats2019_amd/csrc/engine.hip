@@ -1634,6 +1634,9 @@ extern "C" int ru_compose_labels(const unsigned char* mask, const unsigned long 
     return compose_labels_launch(mask, counts, et_min, labels, V, (hipStream_t)stream);
 }
 
+extern "C" int ru_dice_accumulate(const unsigned long long* counts, double* acc, int N, int C, int nacc, ru_stream_t stream) {
+    return dice_accumulate_launch(counts, acc, N, C, nacc, (hipStream_t)stream);
+}
 extern "C" int ru_dice_counts(const float* p, const float* g, unsigned long long* counts, int N, int C, size_t V, ru_stream_t stream) {
     RU_REQUIRE(p && g && counts && N > 0 && C > 0, "ru_dice_counts: bad argument");
     return dice_counts_launch(p, g, counts, N * C, V, (hipStream_t)stream);

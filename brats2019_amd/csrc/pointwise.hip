@@ -1141,6 +1141,27 @@ int dice_counts_launch(const float* p, const float* g, unsigned long long* count
     return RU_OK;
 }
 
+// metrics.py:124-130 on the device: r = 2*num/den in float32 (exact integer sums below 2^24 like the reference's float32 sums), NaN -> 1,
+// batch mean and accumulator in float64 -- one thread per class, samples in order
+__global__ void dice_accumulate_kernel(const unsigned long long* __restrict__ counts, double* __restrict__ acc, int N, int C, int nacc) {
+    const int c = threadIdx.x;
+    if (c >= nacc) return;
+    double sum = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float num = (float)counts[((size_t)n * C + c) * 2], den = (float)counts[((size_t)n * C + c) * 2 + 1];
+        float r = 2.f * num / den;
+        if (r != r) r = 1.f;
+        sum += (double)r;
+    }
+    acc[c] += sum / (double)N;
+}
+int dice_accumulate_launch(const unsigned long long* counts, double* acc, int N, int C, int nacc, hipStream_t s) {
+    RU_REQUIRE(counts && acc && N > 0 && nacc > 0 && nacc <= C && nacc <= 64, "dice_accumulate: bad argument");
+    hipLaunchKernelGGL(dice_accumulate_kernel, dim3(1), dim3(64), 0, s, counts, acc, N, C, nacc);
+    RU_CHECK_LAUNCH("dice_accumulate_kernel");
+    return RU_OK;
+}
+
 // ------------------------------------------------------------------ training input pipeline (dataloader.py:100-216)
 // z-score statistics: per channel count(x > 0), sum x, sum x^2 over ALL voxels (dataloader.py:124-130), float64, two stages
 constexpr int ZS_CHUNK = 16384;

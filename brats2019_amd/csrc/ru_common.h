@@ -362,6 +362,7 @@ int crit_value_launch(const double* sums, int C, double count, double priority, 
 int tta_merge_launch(const float* p, int K, unsigned flips, float* mean_out, unsigned char* mask, unsigned long long* counts, int C, int D, int H, int W, hipStream_t s);
 int compose_labels_launch(const unsigned char* mask, const unsigned long long* counts, unsigned long long et_min, unsigned char* labels, size_t V, hipStream_t s);
 int dice_counts_launch(const float* p, const float* g, unsigned long long* counts, int rows, size_t V, hipStream_t s);
+int dice_accumulate_launch(const unsigned long long* counts, double* acc, int N, int C, int nacc, hipStream_t s);
 // training input pipeline (dataloader.py:100-216)
 constexpr int RU_AUG_MAXC = 8;
 struct AugmentArgs {

@@ -39,10 +39,19 @@ class Dice(Metrics):
         pred = predict[self.input_index].detach()
         gr = ground[self.target_index].detach()
         assert gr.shape == pred.shape
-        counts = ops.dice_counts(pred.cuda(), gr.cuda()).to(torch.float32)      # [N,C,2], stays on the device: no host sync per update
-        r = ((2 * counts[..., 0]) / counts[..., 1]).to(torch.float64)           # float32 division like metrics.py:126 (0/0 -> NaN)
-        r = torch.where(torch.isnan(r), torch.ones_like(r), r)                  # metrics.py:127
-        self.accumulator = self.accumulator + r[:, : self.classes - 1].mean(dim=0)
+        counts = ops.dice_counts(pred.cuda(), gr.cuda())                        # [N,C,2] int64, stays on the device: no host sync per update
+        nacc = self.classes - 1
+        if nacc <= int(counts.shape[1]) and nacc <= 64:
+            # ratio (float32, 0/0 -> NaN -> 1), batch mean and accumulation (float64) in one tiny launch: metrics.py:124-130 without a
+            # dozen ATen passes over 12 numbers per training step
+            if not isinstance(self.accumulator, torch.Tensor):
+                self.accumulator = torch.full((nacc,), float(self.accumulator), dtype=torch.float64, device=counts.device)
+            ops.dice_accumulate(counts, self.accumulator, nacc)
+        else:
+            cf = counts.to(torch.float32)
+            r = ((2 * cf[..., 0]) / cf[..., 1]).to(torch.float64)               # float32 division like metrics.py:126 (0/0 -> NaN)
+            r = torch.where(torch.isnan(r), torch.ones_like(r), r)              # metrics.py:127
+            self.accumulator = self.accumulator + r[:, :nacc].mean(dim=0)
         self.samples += 1
 
     def get(self):

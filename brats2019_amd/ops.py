@@ -342,6 +342,14 @@ def dice_counts(pred, target):
     return counts
 
 
+def dice_accumulate(counts, acc, nacc):
+    """metrics.py:124-130 on the device: acc[c] += batch mean of 2*num/den (float32 ratio, NaN -> 1; float64 mean), c < nacc."""
+    n, c = int(counts.shape[0]), int(counts.shape[1])
+    assert counts.dtype == torch.int64 and counts.is_contiguous() and acc.dtype == torch.float64 and acc.numel() >= nacc
+    L.check(L.load().ru_dice_accumulate(L.ptr(counts), L.ptr(acc), n, c, int(nacc), L.stream()), "ru_dice_accumulate")
+    return acc
+
+
 # ---------------------------------------------------------------------- engine-internal voxel-major layout (tests / probes)
 def to_c16(x):
     """NCDHW [N,C,D,H,W] -> C16 storage [N,C/16,D,H,W,16] (device kernel ru_layout_convert)."""
