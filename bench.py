@@ -26,7 +26,13 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   fwd_f32      : the batch-1 forward in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
   trainer_step : the same training step driven through the reference surface (train.Trainer._train_one_epoch set up as main.py:126-142),
   roofline_families : ms per step of every kernel family (3x3x3 conv / weight gradient at the 16-channel level and deeper, GroupNorm passes,
-                 1x1 / stride-2 / up-sampling kernels) timed in place, next to the family's algorithmic FLOPs / bytes and its roofline bound.
+                 1x1 / stride-2 / up-sampling kernels) timed in place, next to the family's algorithmic FLOPs / bytes and its roofline bound
+                 (GroupNorm: the achievable-fusion bound -- the passes that cannot ride on a convolution for fp32 tensors),
+  roofline_top : the three largest families of the step, each with launches, average launch time and fraction of its own bound,
+  whole_step_frac : the step against the per-layer roofline priced on ALGORITHMIC FLOPs (`_executed`: on the three split-bf16 products),
+and at N > 1
+  allreduce_ms : the two collectives of a step timed in place (HIP event pairs on the kernels' stream, max over ranks), `step_ms_per_rank`,
+                 `rccl_ranks`, `dist_backend`, `transport`; `fwd` and `fwd_batch` are N independent replicas.
 """
 import argparse
 import json

@@ -10,6 +10,7 @@
 #include "pw_helpers.hpp"
 #include "fin_tail.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace ru {
 
@@ -548,14 +549,26 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
         }
     }
 }
+// output channel blocks per workgroup.  Scatter mode (the transposed stride-2 conv: a streaming kernel whose 16-byte stores land 128 bytes
+// apart): RU_C1_SCATTER_COB (env, tools only) overrides the default for A/B runs
+static int conv1_16_cob(const Conv1Args& a) {
+    const int CBo = a.Cout / 16;
+    int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
+    if (a.s2d == 2) {
+        static const int forced = [] { const char* e = getenv("RU_C1_SCATTER_COB"); return e ? atoi(e) : 0; }();
+        if ((forced == 2 || forced == 4 || forced == 1) && forced <= CBo) cob = forced;
+    }
+    return cob;
+}
 int conv1_16_bst_nblk(const Conv1Args& a) {
     if (a.s2d == 1 || a.y1 || a.Cout % 16 || a.V == 0) return 0;
     const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
-    const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
+    const int cob = conv1_16_cob(a);
     const int gx = cdiv(nvt, 4), gy = cdiv(CBo, cob);
     if (a.s2d == 2) {
         const int cbf = CBo >> 3;                        // every workgroup must carry whole groups of taps of the same fine channel blocks
-        if (a.Cout % 128 || cob != 4 || (cbf != 1 && cbf != 2 && cbf != 4)) return 0;
+        if (a.Cout % 128 || (cbf != 1 && cbf != 2 && cbf != 4) || !(cob % cbf == 0 || cbf % cob == 0)) return 0;
+        if (cbf > cob) return 0;                         // (a workgroup would carry a part of the fine blocks only: not a launch of the network)
         return gx * gy;
     }
     return gx;
@@ -570,7 +583,7 @@ int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
         RU_REQUIRE(a.s2d == 1 ? a.C0 % 128 == 0 : a.Cout % 128 == 0, "conv1_16: stride-2 modes need 8 x (multiple of 16) channels");
     }
     const int nvt = (int)((a.V + 63) / 64), CBo = a.Cout / 16;
-    const int cob = CBo >= 4 ? 4 : (CBo >= 2 ? 2 : 1);
+    const int cob = conv1_16_cob(a);
     const bool bst = a.bst_y != nullptr;
     RU_REQUIRE(!bst || (a.bst_k && a.stat_partials && a.s2d != 1 && !a.y1 && conv1_16_bst_nblk(a) > 0), "conv1_16: fused GroupNorm-backward statistics need the plain or scatter mode with whole channel blocks per workgroup");
     dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
