@@ -21,6 +21,7 @@
 
 namespace ru {
 
+constexpr int SB1_W_BYTES = SB_KSTEPS * 2 * 64 * 16;      // one (cog, chunk) weight block in LDS (one-stage kernel)
 template <int TZ, int TY, bool IN16, bool OUT16>
 __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk) {
     using P = SB<TZ, TY>;
@@ -64,40 +65,59 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
         else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv, c, 0, 0, 0);
     };
 
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        if (chunk) __syncthreads();
-        // ---- weight fragments of (cog, chunk) straight into registers (L2-resident, lane-linear 16-byte loads)
-        u32x4 wreg[SB_KSTEPS][2];
-        {
-            const u32x4* wp = wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane;
+    // ---- Software pipeline over the input-channel chunks (round 4).  The kernel runs where the grid is small -- one or two workgroups per CU,
+    // e.g. the 128-channel level of a batch-1 forward -- so nothing but the workgroup itself can hide the L2 latency of a chunk's operands,
+    // and with the weight fragments loaded into 112 registers at the top of every chunk that latency (~2 us) was exposed eight times per
+    // launch around 0.7 us of matrix work.  Now: the weight fragments of chunk c+1 (28 KB, the same for the four waves) and, for voxel-major
+    // input, its halo image are requested BEFORE the matrix loop of chunk c, travel through 7 + 8 registers per thread, and are stored
+    // to LDS behind the barrier that ends chunk c; the B fragments are read from LDS (lane-linear 16-byte reads).
+    constexpr int WPK = SB_KSTEPS * 2 * 64, WR = WPK / 256;          // 16-byte packets of one (cog, chunk) weight block; per thread
+    static_assert(WPK % 256 == 0, "weight block is a whole number of packets per thread");
+    u32x4* wl = lds + 4 * HVOLP;                                      // behind the image
+    u32x4 wv[WR];
+    auto issue_w = [&](int chunk) __attribute__((always_inline)) {
+        const u32x4* wp = wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + tid;
 #pragma unroll
-            for (int ks = 0; ks < SB_KSTEPS; ++ks) {
-                wreg[ks][0] = wp[(ks * 2 + 0) * 64];
-                wreg[ks][1] = wp[(ks * 2 + 1) * 64];
-            }
+        for (int j = 0; j < WR; ++j) wv[j] = wp[j * 256];
+    };
+    auto store_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < WR; ++j) wl[tid + j * 256] = wv[j];
+    };
+    // C16 input staging, split into issue (global loads -> registers) and store (transform / split -> LDS)
+    constexpr int NPOS16 = NROW * HX, NR16 = (NPOS16 + 127) / 128;
+    const int hsel = (tid >> 3) & 1;
+    const int pslot = (tid >> 4) * 8 + (tid & 7);
+    const bool s16 = IN16 && a.in_s16 != 0;          // split form in HBM: hi packet at float offset half*4, lo at 8 + half*4: plain copy
+    float4 v16[IN16 ? NR16 : 1][2];
+    unsigned vmask = 0;
+    size_t vofs[IN16 ? NR16 : 1];
+    if constexpr (IN16) {
+#pragma unroll
+        for (int r = 0; r < NR16; ++r) {
+            const int p = r * 128 + pslot;
+            const int row = p / HX, xc = p - row * HX;
+            const int hz = row / HY, hy = row - hz * HY;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
+            const bool ok = p < NPOS16 && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            vofs[r] = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+            vmask |= ok ? (1u << r) : 0u;
         }
+    }
+    auto in16_issue = [&](int chunk) __attribute__((always_inline)) {
         if constexpr (IN16) {
-            // ---- C16 input: (halo position, channel half) per thread and round; two aligned float4 per voxel half
-            constexpr int NPOS = NROW * HX, NR = (NPOS + 127) / 128;
-            const int hsel = (tid >> 3) & 1;
-            const int pslot = (tid >> 4) * 8 + (tid & 7);
-            const bool s16 = a.in_s16 != 0;              // split form in HBM: hi packet at float offset half*4, lo at 8 + half*4: plain copy
             const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16 + (s16 ? hsel * 4 : hsel * 8);
             const int second = s16 ? 8 : 4;
-            float4 v16[NR][2];
-            unsigned vmask = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int p = r * 128 + pslot;
-                const int row = p / HX, xc = p - row * HX;
-                const int hz = row / HY, hy = row - hz * HY;
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
-                const bool ok = p < NPOS && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
-                vmask |= ok ? (1u << r) : 0u;
-                v16[r][0] = *reinterpret_cast<const float4*>(xb + ofs);
-                v16[r][1] = *reinterpret_cast<const float4*>(xb + ofs + second);
+            for (int r = 0; r < NR16; ++r) {
+                v16[r][0] = *reinterpret_cast<const float4*>(xb + vofs[r]);
+                v16[r][1] = *reinterpret_cast<const float4*>(xb + vofs[r] + second);
             }
+        }
+    };
+    auto in16_store = [&](int chunk) __attribute__((always_inline)) {
+        if constexpr (IN16) {
+            constexpr int NPOS = NPOS16, NR = NR16;
             float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (xform) {
                 const int cofs = n * a.Cin + chunk * 16 + hsel * 8;
@@ -137,6 +157,16 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
             if (s16) body(std::integral_constant<int, 2>{});
             else if (xform) body(std::integral_constant<int, 1>{});
             else body(std::integral_constant<int, 0>{});
+        }
+    };
+    issue_w(0);
+    in16_issue(0);
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (chunk) __syncthreads();                  // every wave is done with the image and the weight block of the previous chunk
+        if constexpr (IN16) {
+            // ---- C16 input: converted and stored from the registers in16_issue filled one chunk earlier
+            in16_store(chunk);
         } else {
             // ---- NCDHW input (W % 4 == 0): halo row [x0-1, x0+17) = six aligned 16-byte segments [x0-4+4q, +4); slot = (row, q).
             //      Per slot and channel-half, 8 float4 loads (8 channels x 4 voxels) in flight, then transform + split + transpose
@@ -198,12 +228,14 @@ __global__ __launch_bounds__(256, 2) void conv3_sb_kernel(const Conv3Args a, con
                 }
             }
         }
+        store_w();
         __syncthreads();
+        if (chunk + 1 < nchunk) { issue_w(chunk + 1); in16_issue(chunk + 1); }      // in flight under this chunk's matrix loop
         // ---- 14 K-steps x MT M-tiles x 3 products
 #pragma unroll
         for (int ks = 0; ks < SB_KSTEPS; ++ks) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[ks][0]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[ks][1]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, wl[(ks * 2 + 0) * 64 + lane]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[(ks * 2 + 1) * 64 + lane]);
             bf16x8 ah[MT], al[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -615,7 +647,7 @@ static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static PerDevice attr_done;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES + SB1_W_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb)");
         attr_done.set();
     }
@@ -623,7 +655,7 @@ static int sb_cfg(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)((long)a.N * ntz * nty * ntx), (unsigned)cdiv(a.Cout, 16));
     RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.kind == 1 && a.fin.nblk == ntz * nty * ntx && a.fin.N == a.N && a.fin.C == a.Cout),
                "conv3_sb: tail descriptor does not match the launch");
-    hipLaunchKernelGGL((conv3_sb_kernel<TZ, TY, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16));
+    hipLaunchKernelGGL((conv3_sb_kernel<TZ, TY, IN16, OUT16>), grid, dim3(256), P::LDS_BYTES + SB1_W_BYTES, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16));
     RU_CHECK_LAUNCH("conv3_sb_kernel");
     return RU_OK;
 }
@@ -682,6 +714,10 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     if (c.ty == 8) {
         if (a.in_c16) return a.out_c16 ? sb_cfg<2, 8, true, true>(a, s) : sb_cfg<2, 8, true, false>(a, s);
         return a.out_c16 ? sb_cfg<2, 8, false, true>(a, s) : sb_cfg<2, 8, false, false>(a, s);
+    }
+    if (c.ty == 2) {
+        if (a.in_c16) return a.out_c16 ? sb_cfg<2, 2, true, true>(a, s) : sb_cfg<2, 2, true, false>(a, s);
+        return a.out_c16 ? sb_cfg<2, 2, false, true>(a, s) : sb_cfg<2, 2, false, false>(a, s);
     }
     if (a.in_c16) return a.out_c16 ? sb_cfg<2, 4, true, true>(a, s) : sb_cfg<2, 4, true, false>(a, s);
     return a.out_c16 ? sb_cfg<2, 4, false, true>(a, s) : sb_cfg<2, 4, false, false>(a, s);

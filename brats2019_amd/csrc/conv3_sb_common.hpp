@@ -201,20 +201,6 @@ __device__ __forceinline__ void static_for(F&& f) {           // f(integral_cons
 
 
 struct SBChoice { int tz, ty; };
-static inline SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
-    const int ncog = cdiv(Cout, 16);
-    auto blocks = [&](int tz, int ty) { return (long)N * cdiv(D, tz) * cdiv(H, ty) * cdiv(W, 16) * ncog; };
-    // the persistent kernel addresses a 16-channel block of a voxel-major input through a buffer descriptor with 32-bit byte offsets
-    // (its out-of-range lanes are the zero padding): volumes of 2^25 voxels and more (e.g. 336^3) take the one-stage kernel
-    const bool fits32 = (size_t)D * H * W * 64 < ((size_t)1 << 31);
-    if (fits32 && blocks(4, 8) >= 256) return {4, 8};   // one persistent producer/consumer workgroup per CU is enough (deep levels: 8 chunks per tile)
-    if (blocks(2, 8) >= 1024) return {2, 8};
-    return {2, 4};
-}
-
-// v2 (persistent producer/consumer) handles the large-tile case
-static inline bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
-
 static inline int sb_ncu() {                                  // CUs of the CURRENT device (cached per device id)
     static int ncu[64] = {};
     int dev = 0;
@@ -225,6 +211,24 @@ static inline int sb_ncu() {                                  // CUs of the CURR
     }
     return ncu[dev];
 }
+static inline SBChoice sb_choose(int N, int Cout, int D, int H, int W) {
+    const int ncog = cdiv(Cout, 16);
+    auto blocks = [&](int tz, int ty) { return (long)N * cdiv(D, tz) * cdiv(H, ty) * cdiv(W, 16) * ncog; };
+    // the persistent kernel addresses a 16-channel block of a voxel-major input through a buffer descriptor with 32-bit byte offsets
+    // (its out-of-range lanes are the zero padding): volumes of 2^25 voxels and more (e.g. 336^3) take the one-stage kernel
+    const bool fits32 = (size_t)D * H * W * 64 < ((size_t)1 << 31);
+    if (fits32 && blocks(4, 8) >= 256) return {4, 8};   // one persistent producer/consumer workgroup per CU is enough (deep levels: 8 chunks per tile)
+    if (blocks(2, 8) >= 1024) return {2, 8};
+    // fewer (2,4,16) tiles x cout groups than TWO per CU (the 128-channel level of a batch-1 forward: 256): the one-stage kernel walks its
+    // input-channel chunks with every chunk's weight-fragment latency exposed and only a second resident workgroup can hide it -- half-size tiles
+    static const bool no22 = [] { const char* e = getenv("RU_SB1_NO22"); return e && *e == '1'; }();      // (tools: A/B of the half-size tile)
+    if (!no22 && blocks(2, 4) < 2 * sb_ncu() && blocks(2, 2) >= sb_ncu()) return {2, 2};
+    return {2, 4};
+}
+
+// v2 (persistent producer/consumer) handles the large-tile case
+static inline bool sb_use_v2(const SBChoice& c) { return c.tz == 4 && c.ty == 8; }
+
 // workgroups along x of the persistent kernel: one resident workgroup per CU in total
 static inline long sb2_grid_x(int N, int Cout, int D, int H, int W) {
     const int ncu = sb_ncu(), ncog = cdiv(Cout, 16);
