@@ -1290,7 +1290,7 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     A.dry = false; A.base = (char*)ws; A.cap = ws_bytes;
     if (!h->tickets && (h->fusion & RU_FUSE_TAIL_FINALIZE)) {    // once per handle (a warm-up call, like the side stream and the events)
         hipError_t e = hipMalloc((void**)&h->tickets, 256 * sizeof(unsigned));
-        if (e == hipSuccess) e = hipMemset(h->tickets, 0, 256 * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemsetAsync(h->tickets, 0, 256 * sizeof(unsigned), (hipStream_t)stream);      // stream-ordered before the first kernel that takes a ticket
         if (e != hipSuccess) { h->tickets = nullptr; return hip_fail(e, "ru_unet_forward: ticket words"); }
     }
     h->ticket_next = 0;
@@ -1305,7 +1305,6 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     return RU_OK;
 }
 
-extern "C" int ru_unet_backward(ru_unet_t h, const float* params, const float* dprobs, float* grads, float* dx, ru_stream_t stream);
 static int backward_entry(ru_unet_t h, const float* params, const float* dprobs, const CritGradArgs* crit, float* grads, float* dx, ru_stream_t stream) {
     if (!h->have_fwd || !h->training) { set_error("ru_unet_backward: needs a preceding training-mode ru_unet_forward"); return RU_ESTATE; }
     Arena A;
