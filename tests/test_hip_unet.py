@@ -740,6 +740,28 @@ def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
     assert worst_pw <= 1e-5, worst_pw
 
 
+@pytest.mark.parametrize("cfgname,precision", [("small", "f32"), ("small", "bf16x3"), ("wide", "bf16x3")])
+def test_backward_criterion_fallback_paths(cfgname, precision):
+    """ru_unet_backward_criterion where the head has no pass to ride on: a configuration whose channels are not multiples of 16 (NCDHW
+    engine, both precisions) -- the criterion's gradient is then materialised into the workspace by the library itself (the workspace
+    query accounts for it) and the result equals the two-call sequence bit for bit."""
+    from brats2019_amd import parallel as P
+    be = P.HipBackend(cfg=SMALL, precision=precision)
+    flat = be.new_flat()
+    for k, v in be.engine.layout.views(flat).items():
+        v.copy_(T(O.make_params(8, **SMALL)[k]))
+    x = T(O.make_input(2, 16, 24, 16, seed=8)).cuda()
+    g = T(O.make_target(2, 16, 24, 16, seed=8)).cuda()
+    res = {}
+    for fused in (False, True):
+        st = P.DataParallelStep(be, flat)
+        st.fuse_criterion_grad = fused
+        loss, _, _ = st.loss_and_grads(x, g)
+        res[fused] = (float(loss), st.grads.clone())
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1])
+
+
 def test_backward_criterion_equals_criterion_grad_then_backward():
     """ru_unet_backward_criterion (the criterion's gradient formed inside the head's sigmoid-backward pass, d(loss)/d(probs) never written;
     what DataParallelStep runs) against ru_criterion_grad followed by ru_unet_backward on the same forward: same float operations in the
