@@ -283,7 +283,10 @@ int up2_fwd16_launch(const float* x, float* y, int N, int C, int D, int H, int W
 // transpose in gather form: coarse voxel k collects from fine 2k-1 .. 2k+2 on each axis.  A thread owns a coarse (ky, kx) column
 // (and channel quad) and marches through a chunk of UP2B_ZC coarse planes: the x/y-reduced value of fine plane z feeds the two
 // coarse planes it belongs to, so a coarse output costs 2 fine planes x 16 loads instead of 4 x 16.
-constexpr int UP2B_ZC = 8;
+#ifndef RU_UP2B_ZC
+#define RU_UP2B_ZC 8
+#endif
+constexpr int UP2B_ZC = RU_UP2B_ZC;
 __global__ __launch_bounds__(256) void up2_bwd16_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D, int H, int W) {
     const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
     const size_t nb = blockIdx.y;
