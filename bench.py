@@ -152,6 +152,30 @@ def family_bounds(batch, size, precision):
     return fam
 
 
+def committed_family_table():
+    """The per-family PMC table committed under profiles/ (tools/family_table.py on a GPU box: separate --pmc passes, never inside a timed run):
+    MFMA-busy % and counter HBM traffic of the 3x3x3 conv and weight-gradient kernels at the four level shapes.  Carried in the line as
+    context for `roofline_top` -- committed numbers, not measured in this run (the newest profiles/r*_family_table.txt)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_family_table.txt")))
+    if not files:
+        return None
+    rows = []
+    for ln in open(files[-1]):
+        if ln.startswith("#") or not ln.strip():
+            continue
+        f = ln.split()
+        try:    # kind(1-2 words) shape kernel avg_us alg_GB alg_GB/s hbm_frac counter_GB busy exec_TF exec_frac
+            tail = [float(v) for v in f[-8:]]
+            i = ln.index("ch")
+            ch = int(ln[:i].split()[-1])
+            rows.append({"kind": "wgrad" if ln.startswith("wgrad") else "conv_fwd", "channels": ch, "avg_us": tail[0], "algorithmic_gb": tail[1],
+                         "hbm_frac": tail[3], "counter_gb": tail[4], "mfma_busy_pct": tail[5], "executed_mfma_frac": tail[7]})
+        except (ValueError, IndexError):
+            continue
+    return {"source": "profiles/%s (rocprofv3 --pmc passes on tools/conv_probe.py, committed; not measured in this run)" % os.path.basename(files[-1]), "rows": rows}
+
+
 def synth(n, size, seed, device):
     rng = np.random.default_rng(seed)
     x = torch.from_numpy(rng.standard_normal((n, 4, size, size, size), dtype=np.float32)).to(device)
@@ -707,6 +731,9 @@ def main():
         rf = roofline_families(backend, one_step, args.batch, args.size, args.precision, 1e3 * dt / args.steps, steps=min(3, args.probe_steps))
         if rank == 0:
             out["roofline_top"] = rf.pop("top")       # the three largest kernel families of the step, each against its own roofline
+            ft = committed_family_table()
+            if ft is not None:
+                out["pmc_families"] = ft
             out["roofline_families"] = rf
     if rank == 0 and not args.no_extras:               # at every N: the dominant kernel as timed inside rank 0's steps
         out["roofline"] = roofline_probe(args.batch, args.size, args.precision, insitu=insitu,
