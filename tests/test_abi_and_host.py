@@ -273,3 +273,43 @@ def test_checkpoint_written_here_loads_into_the_reference_unet(tmp_path):
         assert list(got.keys()) == list(params.keys())
         for k, v in params.items():
             assert np.array_equal(got[k].numpy(), v), (tag, k)
+
+
+def test_tiling_copy_and_copy_back_on_host_tensors_match_reference(golden):
+    """`tiling.copy` / `copy_back` on HOST tensors (the reference's loader_helper.copy / copy_back take any tensor, train.py:165-171 hands them
+    CPU volumes): the slicing path that serves tensors the device kernels do not take (CPU, or a tile width that is not a multiple of 4)
+    against the tiles and the pasted volume the REFERENCE produced (tests/golden/tiling.npz)."""
+    from brats2019_amd import tiling
+    g = golden("tiling")
+    data = torch.from_numpy(g["small_data"])
+    c, b, tl = (8, 8, 8), (4, 4, 4), (16, 16, 16)
+    grid = tiling.grid_for(data.shape[2:], c)
+    res = torch.zeros_like(data)
+    n = 0
+    for i in range(grid[0]):
+        for j in range(grid[1]):
+            for k in range(grid[2]):
+                lo, hi = tiling.get_indices((i, j, k), c, b)
+                tile = tiling.copy(data, tl, lo, hi)
+                assert np.array_equal(tile.numpy(), g["small_tiles"][n]), (i, j, k)
+                tiling.copy_back(res, tile, c, lo, hi, b)
+                n += 1
+    assert np.array_equal(res.numpy(), g["small_result"])
+
+
+def test_bench_roofline_bookkeeping():
+    """bench.py's bounds are arithmetic on SURVEY 8(d)'s figures -- pinned so that a change of the layer table shows: algorithmic FLOPs of a
+    step = 4 x 890.87 GFLOP, fused-lower-bound bytes 37.9 GB, whole-step algorithmic bound 4.94 ms, GroupNorm achievable-fusion bytes 8.05 GB;
+    the committed PMC family table parses into eight rows."""
+    import bench
+    fb = bench.family_bounds(4, 128, "bf16x3")
+    gflop = sum(f["gflop"] for f in fb.values())
+    gbytes = sum(f["gbytes"] for k, f in fb.items() if k != "groupnorm")
+    assert abs(gflop - 4 * bench.FWDBWD_GFLOP_PER_VOL) < 1.0, gflop
+    assert abs(gbytes - 37.91) < 0.05, gbytes
+    assert abs(sum(f["bound_ms_algorithmic"] for f in fb.values()) - 4.936) < 0.01
+    assert abs(fb["groupnorm"]["achievable_gbytes"] - 8.053) < 0.01 and abs(fb["groupnorm"]["bound_ms_achievable_fusion"] - 1.0066) < 0.001
+    assert bench.step_roofline_ms(4, 128, "bf16x3") > sum(f["bound_ms_algorithmic"] for f in fb.values())          # executed products cost more than algorithmic ones
+    ft = bench.committed_family_table()
+    assert ft is not None and len(ft["rows"]) == 8 and {r["channels"] for r in ft["rows"]} == {16, 32, 64, 128}
+    assert all(0 < r["mfma_busy_pct"] < 100 and r["avg_us"] > 0 for r in ft["rows"])
