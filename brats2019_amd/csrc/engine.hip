@@ -386,6 +386,10 @@ extern "C" int ru_unet_set_precision(ru_unet_t h, int precision) {
 extern "C" int ru_unet_get_precision(ru_unet_t h) { return h ? h->precision : -1; }
 extern "C" int ru_unet_set_fusion(ru_unet_t h, unsigned mask) {
     RU_REQUIRE(h && (mask & ~(unsigned)(RU_FUSE_GN_BWD_STATS | RU_FUSE_GN_BWD_APPLY | RU_FUSE_SIDE_STREAM | RU_FUSE_BATCH_WREDUCE | RU_FUSE_TAIL_FINALIZE | RU_FUSE_PW_DGRAD)) == 0, "ru_unet_set_fusion: bad argument");
+    if ((mask & RU_FUSE_TAIL_FINALIZE) && !h->tickets) {      // here, not lazily in ru_unet_forward: that entry must stay free of allocations (stream capture)
+        hipError_t e = hipMalloc((void**)&h->tickets, 256 * sizeof(unsigned));
+        if (e != hipSuccess) { h->tickets = nullptr; (void)hipGetLastError(); }      // no device in this process (layout-only use): the first forward allocates
+    }
     h->fusion = mask;
     h->have_fwd = false;            // the workspace layout of the backward depends on it
     return RU_OK;
@@ -1145,7 +1149,9 @@ static int unet_backward_impl(ru_unet* h, const float* params, const float* dpro
             // dz is the gradient entering norm2 of the block that produced z (the last block of the next decoder stage, or of the deepest
             // encoder level): its GroupNorm-backward sums are taken in this launch's store pass
             carry = FusedSums();
-            const BlockSave* zb = (i + 1 <= depth - 2 && !h->dec_s[i + 1].empty()) ? &h->dec_s[i + 1].back()
+            // (a middle decoder stage with zero blocks: z is then a 1x1 output, not a block's -- no norm2 whose sums could ride here; the
+            // deepest encoder level's y2 is a tensor of ANOTHER level and must not be read as bst_y)
+            const BlockSave* zb = (i + 1 <= depth - 2) ? (!h->dec_s[i + 1].empty() ? &h->dec_s[i + 1].back() : nullptr)
                                   : (!h->enc_s[depth - 2].empty() ? &h->enc_s[depth - 2].back() : nullptr);
             if (zb && (zb->g2.k || A.dry) && (h->fusion & RU_FUSE_GN_BWD_STATS) && conv1_16_bst_nblk(a3) > 0) {
                 carry.nblk = conv1_16_bst_nblk(a3);
@@ -1288,10 +1294,15 @@ extern "C" int ru_unet_forward(ru_unet_t h, const float* params, const float* x,
     h->ws = (char*)ws; h->ws_bytes = ws_bytes;
     Arena A;
     A.dry = false; A.base = (char*)ws; A.cap = ws_bytes;
-    if (!h->tickets && (h->fusion & RU_FUSE_TAIL_FINALIZE)) {    // once per handle (a warm-up call, like the side stream and the events)
-        hipError_t e = hipMalloc((void**)&h->tickets, 256 * sizeof(unsigned));
-        if (e == hipSuccess) e = hipMemsetAsync(h->tickets, 0, 256 * sizeof(unsigned), (hipStream_t)stream);      // stream-ordered before the first kernel that takes a ticket
+    if (!h->tickets && (h->fusion & RU_FUSE_TAIL_FINALIZE)) {    // only the RU_FUSION_ON devtools route gets here (ru_unet_create / set_fusion may run without a device):
+        hipError_t e = hipMalloc((void**)&h->tickets, 256 * sizeof(unsigned));      // the bit is on from the first (warm-up) call; ru_unet_set_fusion allocates eagerly
         if (e != hipSuccess) { h->tickets = nullptr; return hip_fail(e, "ru_unet_forward: ticket words"); }
+    }
+    if (h->tickets && (h->fusion & RU_FUSE_TAIL_FINALIZE)) {
+        // every step starts from zeroed tickets (a memset node under capture): a launch that faulted or was aborted after taking a ticket cannot
+        // make a later launch that draws the same word skip its finalize
+        hipError_t e = hipMemsetAsync(h->tickets, 0, 256 * sizeof(unsigned), (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ru_unet_forward: ticket words");
     }
     h->ticket_next = 0;
     ru::t_sink = h->probe_families ? h->sink : nullptr;

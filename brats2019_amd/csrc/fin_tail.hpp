@@ -132,7 +132,9 @@ __device__ __forceinline__ void fin_tail(const FinTail& f, const float* partials
     unsigned* flag = reinterpret_cast<unsigned*>(lds);
     if (threadIdx.x == 0) {
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // acq_rel at agent scope: the arrival releases this workgroup's published partials (L2 write-back) and the last arriver's read of
+        // the others' is ordered behind its own ticket (L1 invalidate) -- no reliance on the publish / fetch forms alone
+        const unsigned t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         *flag = (t == total - 1) ? 1u : 0u;
     }
     __syncthreads();

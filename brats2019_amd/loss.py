@@ -26,11 +26,39 @@ def _all_reduce_sums(sums, group):
     return 1
 
 
+_HAND_OVER_DEPTH = 0          # process-wide on purpose: autograd runs the backward of device tensors on its own thread
+
+
+class hand_over_to_network:
+    """`with loss.hand_over_to_network(): loss.backward()` -- what the Trainer loop does (train.py:210).  Inside it the backward of a
+    criterion whose `pred` is DIRECTLY model.UNet's output does not write d(loss)/d(pred): it describes it to the network's autograd node,
+    which forms it inside its first backward pass (ru_unet_backward_criterion).  The price is stated here rather than paid silently: within
+    the context d(loss)/d(probs) does not exist as a tensor, so it must not be asked for (autograd.grad(loss, probs), retain_grad, hooks on
+    the probabilities -- the two latter are detected and switch the hand-over off).  Outside the context every backward writes the gradient."""
+
+    def __enter__(self):
+        global _HAND_OVER_DEPTH
+        _HAND_OVER_DEPTH += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _HAND_OVER_DEPTH
+        _HAND_OVER_DEPTH -= 1
+        return False
+
+
+def _observed(pred):
+    """somebody wants to SEE d(loss)/d(pred): retain_grad() or a tensor hook on the probabilities"""
+    return bool(getattr(pred, "retains_grad", False)) or bool(getattr(pred, "_backward_hooks", None))
+
+
 def _hand_over(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority, gout):
-    """Backward of a criterion whose `pred` is DIRECTLY the output of model.UNet's autograd node: instead of writing d(loss)/d(pred) (a
-    100 MB pass that the network's backward reads straight back), describe it to that node -- it forms the gradient inside its first pass
-    (ru_unet_backward_criterion) -- and return a zero-stride placeholder of pred's shape.  Returns None when the hand-over does not apply
-    (another producer of pred, a second criterion on the same probabilities, d/d(input) wanted): the caller then writes the gradient."""
+    """Backward of a criterion whose `pred` is DIRECTLY the output of model.UNet's autograd node, inside `hand_over_to_network()`: instead of
+    writing d(loss)/d(pred) (a 100 MB pass that the network's backward reads straight back), describe it to that node -- it forms the
+    gradient inside its first pass (ru_unet_backward_criterion) -- and return a zero-stride placeholder of pred's shape.  Returns None when
+    the hand-over does not apply (not enabled, another producer of pred, the probabilities are observed, d/d(input) wanted): the caller then
+    writes the gradient.  The description never outlives the graph task that created it (a callback at its end clears it), so a backward
+    that stops short of the network (autograd.grad(loss, probs)) cannot leak it into the next one."""
     node = pred.grad_fn
     if node is None or not getattr(node, "accepts_criterion", False) or type(node).__name__ != "_UNetFnBackward":
         return None
@@ -40,8 +68,14 @@ def _hand_over(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority, gout):
         pc, node.pending_criterion = node.pending_criterion, None
         first = ops.criterion_grad(pred, pc["target"], pc["sums"], pc["count"], pc["w_dice"], pc["w_bce"], pc["bg_weight"], pc["priority"]).mul_(pc["gout"].to(torch.float32))
         return first.add_(ops.criterion_grad(pred, gt, sums, count, w_dice, w_bce, bg_weight, priority).mul_(gout.to(torch.float32)))
+    if _HAND_OVER_DEPTH <= 0 or _observed(pred):
+        return None
     dummy = torch.zeros((), dtype=pred.dtype, device=pred.device).expand(pred.shape)
     node.pending_criterion = dict(target=gt, sums=sums, count=count, w_dice=w_dice, w_bce=w_bce, bg_weight=bg_weight, priority=priority, gout=gout, dummy=dummy)
+
+    def _clear():                                     # end of THIS graph task: whether or not the network's node ran, nothing stays behind
+        node.pending_criterion = None
+    torch.autograd.Variable._execution_engine.queue_callback(_clear)
     return dummy
 
 

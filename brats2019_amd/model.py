@@ -299,18 +299,39 @@ class UNet(nn.Module):
             self._unfreeze()
         return super().train(mode)
 
-    def load_state_dict(self, *args, **kwargs):                   # writes through the aliased flat buffer in place
+    def _drop_param_caches(self):
+        """anything that can REPLACE nn.Parameter objects (load_state_dict(assign=True), an overwrite-on-conversion _apply, re-registration):
+        the cached parameter list, its end pointers and the alias check are rebuilt from named_parameters() on the next forward"""
+        for k in ("_flat_checked", "_flat_ends", "_params_cached"):
+            self.__dict__.pop(k, None)
+
+    def load_state_dict(self, *args, **kwargs):                   # writes through the aliased flat buffer in place (assign=True: new Parameters)
         self._unfreeze()
-        self.__dict__.pop("_flat_checked", None)
-        return super().load_state_dict(*args, **kwargs)
+        self._drop_param_caches()
+        try:
+            return super().load_state_dict(*args, **kwargs)
+        finally:
+            self._drop_param_caches()
+
+    def register_parameter(self, name, param):
+        self._drop_param_caches()
+        return super().register_parameter(name, param)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, nn.Parameter):
+            self._drop_param_caches()
+        return super().__setattr__(name, value)
 
     def _param_order(self):
         self._get_engine()
         return self.__dict__["_param_names"]
 
-    def _apply(self, fn, *args, **kwargs):                       # .cuda() / .to() / .float(): the parameters move, the alias check must run again
-        self.__dict__.pop("_flat_checked", None)
-        return super()._apply(fn, *args, **kwargs)
+    def _apply(self, fn, *args, **kwargs):                       # .cuda() / .to() / .float(): the parameters move (or are replaced), the alias check must run again
+        self._drop_param_caches()
+        try:
+            return super()._apply(fn, *args, **kwargs)
+        finally:
+            self._drop_param_caches()
 
     def _param_list(self):
         """the nn.Parameter objects in state-dict order (they outlive .cuda() / load_state_dict: only their .data moves)"""
@@ -318,6 +339,7 @@ class UNet(nn.Module):
         if lst is None:
             lst = [p for _, p in self.named_parameters()]
             self.__dict__["_params_cached"] = lst
+            self.__dict__.pop("_flat_checked", None)             # a new list: the alias check walks all of it once
         return lst
 
     def _flat_params(self):

@@ -361,3 +361,49 @@ def init_process_group_from_env(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def init_process_groups_with_fallback(prefer="nccl", inject_failure=False, timeout_s=120, device_index=None):
+    """One-shot multi-GPU runs (bench.py under the driver's launcher): a run on a node nobody can look at must not end without a data
+    point because RCCL could not come up.  The DEFAULT process group is gloo (control plane: agreement, and the fallback transport); the
+    DATA group is RCCL (`backend="nccl"`), created on top and health-checked with one tiny all-reduce on every rank.  The ranks agree
+    over gloo whether ALL of them came through; if any did not, every rank uses the gloo group for the data collectives and the line says
+    so (`info["fallback_reason"]` = the first failing rank's error line).  Nothing is re-executed and no process is replaced.
+    -> (rank, local_rank, world, data_group_or_None_for_the_default_group, info)"""
+    import datetime
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 0, 1, None, {"backend": None, "fallback_reason": None}
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # see init_process_group_from_env
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    info = {"backend": "gloo", "fallback_reason": None}
+    if prefer != "nccl":
+        return rank, local, world, None, info
+    err, group = None, None
+    try:
+        if inject_failure:
+            raise RuntimeError("injected RCCL failure (RU_BENCH_INJECT_RCCL_FAIL=1): ncclCommInitRank would have failed here")
+        torch.cuda.set_device(local if device_index is None else device_index)      # the health check's tensor and the RCCL communicator live on this rank's GPU
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.synchronize()
+        if float(t.item()) != float(world):
+            raise RuntimeError("RCCL health check: all-reduce of ones over %d ranks returned %r" % (world, float(t.item())))
+    except Exception as e:                                          # noqa: BLE001 -- whatever RCCL / torch raise here is the reason we report
+        lines = [ln.strip() for ln in str(e).splitlines() if ln.strip()]
+        err = ("%s: %s" % (type(e).__name__, lines[0] if lines else ""))[:300]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                       # gloo, host tensor
+    if int(ok.item()) == 1:
+        info["backend"] = "nccl"
+        return rank, local, world, group, info
+    reasons = [None] * world
+    dist.all_gather_object(reasons, err)
+    info["fallback_reason"] = next(("rank %d: %s" % (i, r) for i, r in enumerate(reasons) if r), "unknown")
+    return rank, local, world, None, info

@@ -40,7 +40,8 @@ def copy(data, tile_shape, index_min, index_max):
     assert all(int(b) - int(a) == int(t) for a, b, t in zip(index_min, index_max, tile_shape))
     if _device_kernels_apply(data, tile_shape):
         return copy_tiles(data, tile_shape, [index_min])
-    out = data.new_zeros(tuple(data.shape[:2]) + tuple(int(t) for t in tile_shape))
+    # float32 whatever the volume's dtype, as loader_helper.py:43 allocates it (an integer label volume yields float tiles there too)
+    out = torch.zeros(tuple(data.shape[:2]) + tuple(int(t) for t in tile_shape), dtype=torch.float32, device=data.device)
     src, dst = [slice(None), slice(None)], [slice(None), slice(None)]
     for a, b, n in zip(index_min, index_max, data.shape[2:]):
         lo, hi = max(int(a), 0), min(int(b), int(n))
@@ -57,11 +58,11 @@ def copy_back(data, tile, center_shape, index_min, index_max, border):
         return
     src, dst = [slice(None), slice(None)], [slice(None), slice(None)]
     for a, c, b, n in zip(index_min, center_shape, border, data.shape[2:]):
-        lo = int(a) + int(b)                                 # first voxel of the centre block in the volume
-        hi = min(lo + int(c), int(n))
-        dst.append(slice(lo, hi))
-        src.append(slice(int(b), int(b) + hi - lo))
-    data[tuple(dst)] = tile.to(data.device)[tuple(src)]
+        first = int(a) + int(b)                              # first voxel of the centre block in the volume (negative: clamped, loader_helper.py:86)
+        lo, hi = max(first, 0), min(first + int(c), int(n))
+        dst.append(slice(lo, max(hi, lo)))
+        src.append(slice(int(b) + lo - first, int(b) + lo - first + max(hi - lo, 0)))
+    data[tuple(dst)] = tile.to(data.device)[tuple(src)].to(data.dtype)
 
 
 def grid_for(shape, center_shape):

@@ -220,7 +220,8 @@ class Trainer(object):
             else:
                 loss_val = [criterion(output, target)]
                 loss = loss_val[0]
-            loss.backward()                                                  # train.py:210
+            with hip_loss.hand_over_to_network():                            # this loop never looks at d(loss)/d(probs): the network's node forms it
+                loss.backward()                                              # train.py:210
             all_reduce_gradients(self.model)                                 # nn.DataParallel's reduce_add (main.py:61); no-op on one rank
             optimizer.step()
             optimizer.zero_grad()

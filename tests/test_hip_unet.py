@@ -742,16 +742,19 @@ def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
 
 @pytest.mark.parametrize("cfgname,precision", [("small", "f32"), ("small", "bf16x3"), ("wide", "bf16x3")])
 def test_backward_criterion_fallback_paths(cfgname, precision):
-    """ru_unet_backward_criterion where the head has no pass to ride on: a configuration whose channels are not multiples of 16 (NCDHW
-    engine, both precisions) -- the criterion's gradient is then materialised into the workspace by the library itself (the workspace
-    query accounts for it) and the result equals the two-call sequence bit for bit."""
+    """ru_unet_backward_criterion where the head has no pass to ride on: `small` -- a configuration whose channels are not multiples of 16
+    (NCDHW engine, both precisions); `wide` -- a voxel-major engine whose first level is wider than 16 channels (csrc/engine.hip: `head4 &&
+    C0 > 16` => the criterion's gradient is materialised into the workspace, then head_grad_c4 AND sigmoid_bwd run on it).  In both cases the
+    library materialises the gradient itself (the workspace query accounts for it) and the result equals the two-call sequence bit for bit."""
     from brats2019_amd import parallel as P
-    be = P.HipBackend(cfg=SMALL, precision=precision)
+    cfg, dhw = {"small": (SMALL, (16, 24, 16)), "wide": (WIDE, (32, 32, 32))}[cfgname]
+    be = P.HipBackend(cfg=cfg, precision=precision)
+    assert be.engine.precision == precision                  # wide: bf16x3 + channels % 16 == 0 => the voxel-major engine (csrc/engine.hip)
     flat = be.new_flat()
     for k, v in be.engine.layout.views(flat).items():
-        v.copy_(T(O.make_params(8, **SMALL)[k]))
-    x = T(O.make_input(2, 16, 24, 16, seed=8)).cuda()
-    g = T(O.make_target(2, 16, 24, 16, seed=8)).cuda()
+        v.copy_(T(O.make_params(8, **cfg)[k]))
+    x = T(O.make_input(2, *dhw, seed=8)).cuda()
+    g = T(O.make_target(2, *dhw, seed=8)).cuda()
     res = {}
     for fused in (False, True):
         st = P.DataParallelStep(be, flat)
@@ -760,6 +763,52 @@ def test_backward_criterion_fallback_paths(cfgname, precision):
         res[fused] = (float(loss), st.grads.clone())
     assert res[True][0] == res[False][0]
     assert torch.equal(res[True][1], res[False][1])
+    if cfgname == "wide":                                    # and the branch is not merely self-consistent: the oracle's gradients, elementwise
+        _, ref_loss, ref_grads = O.forward_backward(O.make_params(8, **cfg), O.make_input(2, *dhw, seed=8), O.make_target(2, *dhw, seed=8), **cfg)
+        assert abs(res[True][0] - ref_loss) < 5e-5
+        for k, v in be.engine.layout.views(res[True][1]).items():
+            if k in ref_grads:
+                r = T(ref_grads[k]).double()
+                rel = float((v.double().cpu() - r).norm() / (r.norm() + 1e-30))
+                assert rel < 1e-2, (k, rel)
+
+
+class _BucketAsModule:
+    """check_against_fixture reads `named_parameters()` / `.grad`: the flat gradient bucket of a DataParallelStep seen through the library's
+    layout (dead parameters: grad None, as the reference's never-executed modules keep it, model.py:420)."""
+
+    class _P:
+        def __init__(self, grad):
+            self.grad = grad
+
+    def __init__(self, layout, grads):
+        self._items = [(k, self._P(None if layout.entries[k][2] else v)) for k, v in layout.views(grads).items()]
+
+    def named_parameters(self):
+        return iter(self._items)
+
+
+def test_data_parallel_step_128_matches_reference_fixture(golden):
+    """The BENCHMARKED entry point -- parallel.DataParallelStep.loss_and_grads with its defaults (ru_unet_forward, ru_criterion_sums,
+    ru_unet_backward_criterion with the criterion's gradient formed inside the head pass, all backward fusions on) -- held DIRECTLY to the
+    reference's own 128^3 training step (train.py:201-210 around model.py / loss.py:76-79,114-122; unet128_train.npz: loss, Dice, BCE,
+    probabilities, mask, every gradient norm, projections of every parameter gradient, seven full conv-weight gradients) at the bars of
+    test_unet128_train_step_bf16x3_matches_reference_fixture.  No autograd, no second criterion entry in between."""
+    from brats2019_amd import parallel as P
+    g = golden("unet128_train")
+    be = P.HipBackend(cfg=O.DEFAULT_CFG)
+    assert be.engine.precision == "bf16x3"
+    flat = be.new_flat()
+    for k, v in be.engine.layout.views(flat).items():
+        v.copy_(T(O.make_params(2024, **O.DEFAULT_CFG)[k]))
+    x = T(O.make_input(2, 128, 128, 128, seed=2024)).cuda()
+    tgt = T(O.make_target(2, 128, 128, 128, seed=2024)).cuda()
+    st = P.DataParallelStep(be, flat)
+    assert st.fuse_criterion_grad
+    loss, dice, bce = st.loss_and_grads(x, tgt)
+    # the criteria as train.py:203-205 combines them: loss = (Dice + BCE) / 2, vals = the two criterion values
+    check_against_fixture(g, _BucketAsModule(be.engine.layout, st.grads), st.last_probs, float(loss), [float(dice), float(bce)],
+                          grad_rel=1e-3, prob_tol=2e-4, loss_tol=5e-5, flip_band=1e-3, conv_rel=2e-3, small_rel=5e-3, proj_rel=4e-3)
 
 
 def test_backward_criterion_equals_criterion_grad_then_backward():
@@ -784,3 +833,75 @@ def test_backward_criterion_equals_criterion_grad_then_backward():
     rel = float(torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(b))
     print("backward_criterion vs criterion_grad + backward: relative L2 %.2e (%s)" % (rel, "bit-identical" if torch.equal(res[True][1], res[False][1]) else "not bit-identical"))
     assert rel <= 1e-6, rel
+
+
+def test_criterion_hand_over_is_explicit_and_never_hides_or_leaks_a_gradient():
+    """loss.hand_over_to_network() (round-4 advisor finding): the criterion's gradient is handed to the network's autograd node as a
+    DESCRIPTION only inside the context the Trainer loop opens around loss.backward().  Outside it d(loss)/d(probs) is a real tensor
+    (autograd.grad(loss, probs) == ops.criterion_grad); inside it retain_grad() / hooks on the probabilities switch the hand-over off; a
+    graph task that stops short of the network leaves no description behind, so a later backward over the retained graph cannot add the
+    criterion's gradient twice; and the handed-over backward equals the written-out one."""
+    from brats2019_amd import loss as L, ops
+    net, _ = build_model(O.DEFAULT_CFG, 12, "bf16x3")
+    x = T(O.make_input(1, 32, 32, 32, seed=12)).cuda()
+    g = T(O.make_target(1, 32, 32, 32, seed=12)).cuda()
+    net.train()
+    crit = L.FusedCriterion()
+
+    def grads_of(fn):
+        for p in net.parameters():
+            p.grad = None
+        probs = net([x])[0]
+        fn(probs)
+        return probs.detach().clone(), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None}
+
+    # (0) the written-out reference: plain loss.backward() outside the context
+    _, ref = grads_of(lambda probs: crit([probs], [g]).backward())
+
+    # (1) autograd.grad of the probabilities, outside AND inside the context, is the real gradient; the later backward is not doubled
+    def observed(probs, inside):
+        loss = crit([probs], [g])
+        sums = ops.criterion_sums(probs.detach(), g, 1e-2)
+        want = ops.criterion_grad(probs.detach(), g, sums, float(probs.numel()), 0.5, 0.5, 1e-2, 1.0)
+        if inside:
+            with L.hand_over_to_network():
+                (dp,) = torch.autograd.grad(loss, probs, retain_graph=True)      # the task ends at the probabilities: the network's node never runs
+            assert probs.grad_fn.pending_criterion is None                       # ... and nothing stays behind
+        else:
+            (dp,) = torch.autograd.grad(loss, probs, retain_graph=True)
+            assert torch.equal(dp, want)
+        with L.hand_over_to_network():
+            loss.backward()
+        return dp
+    for inside in (False, True):
+        _, got = grads_of(lambda probs: observed(probs, inside))
+        for k in ref:
+            rel = float((got[k].double() - ref[k].double()).norm() / (ref[k].double().norm() + 1e-30))
+            assert rel <= 1e-6, ("doubled or missing criterion gradient", inside, k, rel)
+
+    # (2) retain_grad() and a hook on the probabilities see the real gradient inside the context
+    seen = {}
+
+    def with_observers(probs):
+        probs.retain_grad()
+        probs.register_hook(lambda gr: seen.__setitem__("hook", gr.detach().clone()))
+        with L.hand_over_to_network():
+            crit([probs], [g]).backward()
+        seen["retained"] = probs.grad.detach().clone()
+        sums = ops.criterion_sums(probs.detach(), g, 1e-2)
+        seen["want"] = ops.criterion_grad(probs.detach(), g, sums, float(probs.numel()), 0.5, 0.5, 1e-2, 1.0)
+    _, got = grads_of(with_observers)
+    assert torch.equal(seen["retained"], seen["want"]) and torch.equal(seen["hook"], seen["want"])
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+
+    # (3) the hand-over itself (what the Trainer loop runs): equal to the written-out backward to FMA-contraction noise
+    _, got = grads_of(lambda probs: _backward_in_context(L, crit([probs], [g])))
+    for k in ref:
+        rel = float((got[k].double() - ref[k].double()).norm() / (ref[k].double().norm() + 1e-30))
+        assert rel <= 1e-6, (k, rel)
+
+
+def _backward_in_context(L, loss):
+    with L.hand_over_to_network():
+        loss.backward()

@@ -133,4 +133,31 @@ def test_bare_bench_launches_its_own_ranks(tmp_path):
     assert ar["gradients"] > 0 and ar["criterion_sums"] > 0 and len(ar["per_rank_gradients"]) == 2 and ar["gradient_bytes"] > 4 * 4_000_000
     pr = out["step_ms_per_rank"]
     assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - out["ms_per_step"]) < 1e-2 * out["ms_per_step"] + 1e-3
-    assert out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo" and "gloo" in out["transport"]
+    assert out["ranks"] == 2 and out["rccl_ranks"] == 0 and out["dist_backend"] == "gloo" and "gloo" in out["transport"] and "degraded" not in out
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("mode", ["health-check-injected", "health-check-real", "ranks-die"])
+def test_bench_prints_a_flagged_gloo_line_when_rccl_does_not_come_up(mode):
+    """A degraded line instead of no line (round-4 verdict, item 7), on the HIP path: (1) the in-rank route the DRIVER's launcher form takes --
+    parallel.init_process_groups_with_fallback: RCCL health check fails (injected; and for real: two ranks on ONE device, which RCCL
+    refuses), the ranks agree over gloo and keep going; (2) the bare launcher's route -- the first set of ranks dies over RCCL before any GPU
+    call, ONE fresh gloo set is started.  Either way: exit code 0, one JSON line, `transport` = "gloo (fallback after RCCL failure: ...)",
+    `degraded`, `rccl_ranks` 0, and a real measurement behind `value`."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["RU_BENCH_INJECT_RCCL_FAIL"] = {"health-check-injected": "1", "health-check-real": "", "ranks-die": "2"}[mode]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--steps", "2", "--warmup", "1", "--size", "32", "--batch", "1",
+                        "--no-extras", "--probe-steps", "0"], env=env, capture_output=True, text=True, timeout=2000)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["rccl_ranks"] == 0 and out["dist_backend"] == "gloo" and out["degraded"] is True
+    assert out["transport"].startswith("gloo (fallback after RCCL failure: "), out["transport"]
+    if mode != "health-check-real":
+        assert "injected RCCL failure" in out["transport"]
+    else:
+        print("real RCCL failure with two ranks on one device:", out["transport"])
+    assert out["value"] > 0 and np.isfinite(out["final_loss"]) and out["allreduce_ms"]["gradients"] > 0
+    assert (r.stderr.count("starting ONE fresh set of ranks") == 1) == (mode == "ranks-die")

@@ -54,6 +54,11 @@ if bound is not None:
     lines.append("# fused lower bound (conv / weight-gradient / 1x1 passes read input + write output once, fp32; bench.family_bounds): %.2f GB per step = %.2f ms at 8 TB/s"
                  % (bound, bound / 8.0))
     lines.append("# measured / bound = %.2f" % (tot[3] / 1e9 / bound))
+    ab = bench.achievable_bounds(fb)
+    lines.append("# achievable bound (+ the GroupNorm passes no fusion removes for fp32 tensors: forward residual pass of every block, backward apply below the "
+                 "16-channel level): %.2f GB -> measured / bound = %.2f" % (ab["gbytes_achievable"], tot[3] / 1e9 / ab["gbytes_achievable"]))
+    lines.append("# achievable bound, all (+ the y re-read of every GroupNorm's backward sums, + the (y, d) reads of the 16-channel level's apply inside its "
+                 "weight gradient): %.2f GB -> measured / bound = %.2f" % (ab["gbytes_achievable_all"], tot[3] / 1e9 / ab["gbytes_achievable_all"]))
 text = "\n".join(lines) + "\n"
 if OUT:
     open(OUT, "w").write(text)
