@@ -812,12 +812,17 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
                 else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
             };
+            // devtools bits 20-22 (value k = 1..3): the consumers drop the last k fragment families of every halo row -- their MFMAs AND their
+            // LDS reads (k = 1: the ninth chain, 288 of 336 MFMAs left; 2: 216; 3: 144).  Results are wrong; the staging is unchanged.  It
+            // answers "what does this skeleton do with 1.5x / 2.3x fewer matrix operations per staged image" before a reduced-product
+            // kernel is written (profiles/r05_notes.txt).
+            constexpr int NF_KEEP = 5 - ((dbg >> 20) & 7);
             static_for<NSTEP>([&](auto S) {
                 constexpr int s = decltype(S)::value, r = s / 5, f = s % 5, cur = s % RING, nxt = (s + AH) % RING;
                 const bf16x8 ah = fh[cur], al = fl[cur];
-                bool fetched = (s + AH >= NSTEP);
+                bool fetched = (s + AH >= NSTEP) || ((s + AH) % 5 >= NF_KEEP);
                 auto fetch = [&]() __attribute__((always_inline)) {            // the slot of step s-1 is free once its MFMAs are issued
-                    if constexpr (s + AH < NSTEP) {
+                    if constexpr (s + AH < NSTEP && (s + AH) % 5 < NF_KEEP) {
                         const int o = frag_ofs(std::integral_constant<int, (s + AH < NSTEP ? s + AH : 0)>{});
                         fh[nxt] = __builtin_bit_cast(bf16x8, buf[o]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     }
                     fetched = true;
                 };
-                if (!(dbg & 4)) {
+                if (!(dbg & 4) && f < NF_KEEP) {
                     if constexpr (f < 4) {
                         // tiles r-2 (dy 2), r-1 (dy 1), r (dy 0); products lo*hi, hi*lo, hi*hi -- product-major, so MFMAs on one accumulator
                         // are three apart

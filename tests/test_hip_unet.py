@@ -767,7 +767,7 @@ def test_backward_criterion_fallback_paths(cfgname, precision):
         _, ref_loss, ref_grads = O.forward_backward(O.make_params(8, **cfg), O.make_input(2, *dhw, seed=8), O.make_target(2, *dhw, seed=8), **cfg)
         assert abs(res[True][0] - ref_loss) < 5e-5
         for k, v in be.engine.layout.views(res[True][1]).items():
-            if k in ref_grads:
+            if ref_grads.get(k) is not None:                  # (never-executed modules: None in the oracle, zeros in the bucket)
                 r = T(ref_grads[k]).double()
                 rel = float((v.double().cpu() - r).norm() / (r.norm() + 1e-30))
                 assert rel < 1e-2, (k, rel)
