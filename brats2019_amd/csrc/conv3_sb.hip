@@ -18,6 +18,7 @@
 //         registers: 14 K-steps x 2 x 4 VGPRs.
 //   C/D: lane holds 4 consecutive x voxels of output channel l&15 -> shared epilogue (conv3_epilogue.hpp).
 #include "conv3_sb_common.hpp"
+#include "conv3_wz.hpp"
 
 namespace ru {
 
@@ -590,20 +591,35 @@ __device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* 
     wfrag[(unit + 0) * 64 + lane] = hi;
     wfrag[(unit + 1) * 64 + lane] = lo;
 }
+// Every weight is packed in BOTH forms where the channel counts allow the Winograd-z kernel (conv3_wz.hpp): the direct fragments, and right behind
+// them (conv3_sb_frag_bytes_direct) the transformed ones -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
+// every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones.
+__device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int i) {
+    const int direct = ncog * nchunk * SB_KSTEPS * 64;
+    if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    if (!wz_channels_ok(cin_conv, cout_conv)) return;
+    wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct);
+}
+static inline int sb_pack_threads(int cin_conv, int cout_conv) {
+    const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0);
+}
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
-    sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, blockIdx.x * blockDim.x + threadIdx.x);
+    sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, blockIdx.x * blockDim.x + threadIdx.x);
 }
 // all 3x3x3 weights of a network in ONE launch (blockIdx.y = entry): the ~50 pack launches of a training step were 4.5 us each,
 // almost all of it launch latency (5 % of a batch-1 forward)
 __global__ void conv3_sb_pack_batch_kernel(const SbPackBatch b) {
     const SbPackEntry& e = b.e[blockIdx.y];
-    sb_pack_one(e.w, reinterpret_cast<u32x4*>(e.wfrag), e.Cin_f, e.Cout_f, e.mode, e.nchunk, e.ncog, blockIdx.x * blockDim.x + threadIdx.x);
+    sb_pack_both(e.w, reinterpret_cast<u32x4*>(e.wfrag), e.Cin_f, e.Cout_f, e.mode, e.nchunk, e.ncog, blockIdx.x * blockDim.x + threadIdx.x);
 }
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
     if (b.n == 0) return RU_OK;
     int maxtotal = 0;
     for (int i = 0; i < b.n; ++i) {
-        const int t = b.e[i].ncog * b.e[i].nchunk * SB_KSTEPS * 64;
+        const SbPackEntry& e = b.e[i];
+        const int t = sb_pack_threads(e.mode == 0 ? e.Cin_f : e.Cout_f, e.mode == 0 ? e.Cout_f : e.Cin_f);
         if (t > maxtotal) maxtotal = t;
     }
     hipLaunchKernelGGL(conv3_sb_pack_batch_kernel, dim3(cdiv(maxtotal, 256), b.n), dim3(256), 0, s, b);
@@ -619,22 +635,32 @@ int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, in
     return RU_OK;
 }
 
-size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {
+size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv) {
     return (size_t)cdiv(Cout_conv, 16) * cdiv(Cin_conv, 16) * SB_KSTEPS * 2 * 64 * 16;
+}
+size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments behind them)
+    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv);
 }
 
 int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    const int total = ncog * nchunk * SB_KSTEPS * 64;
+    const int total = sb_pack_threads(cin_conv, cout_conv);
     hipLaunchKernelGGL(conv3_sb_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, (u32x4*)wfrag, Cin_f, Cout_f, mode, nchunk, ncog);
     RU_CHECK_LAUNCH("conv3_sb_pack_kernel");
     return RU_OK;
 }
 
 // number of statistics partials per (sample, channel) the kernel chosen for this shape writes
-int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
-    (void)Cin;
+// The Winograd-z kernel (conv3_wz.hpp) takes the voxel-major three-product convolutions of 32 and more channels whose shape fills the chip;
+// RU_WZ=0 keeps every shape on the direct kernels (same-box A/B).  ONE rule for the launch and for the partial count the engine sizes.
+bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products) {
+    const char* e = getenv("RU_WZ");                    // read per call: tests and tools switch it inside one process
+    const bool off = e && *e == '0';
+    return !off && products != 1 && conv3_wz_shape_ok(N, Cin, Cout, D, H, W);
+}
+int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products) {
+    if (conv3_sb_uses_wz(N, Cin, Cout, D, H, W, products)) return (int)wz_grid_x(N, Cout, D, H, W);
     const SBChoice c = sb_choose(N, Cout, D, H, W);
     if (sb_use_v2(c)) return (int)sb2_grid_x(N, Cout, D, H, W);        // persistent kernel: one per workgroup
     return cdiv(D, c.tz) * cdiv(H, c.ty) * cdiv(W, 16);                 // one-stage kernel: one per tile
@@ -707,6 +733,8 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     if ((RU_SB2_DBG & 2048) && !a.stat_partials) c = SBChoice{2, 8};      // tools: time the one-stage kernel on a shape the persistent kernel would take
     if ((RU_SB2_DBG & 4096) && !a.stat_partials) c = SBChoice{2, 4};
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
+    if (a.in_c16 && a.out_c16 && !a.bias && !a.sigmoid && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.products))
+        return conv3_wz_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
     if (sb_use_v2(c)) {
         if (a.in_c16 && a.out_c16) return a.products == 1 ? conv3_sb2_launch_c16_p1(a, s) : conv3_sb2_launch_c16(a, s);
         return conv3_sb2_launch_mixed(a, s);             // (three products whatever a.products says: the NCDHW-side variants have no one-product form)

@@ -1,0 +1,73 @@
+// conv3_wz_pack.hpp -- fragment conventions of the Winograd-z convolution (conv3_wz.hpp) and the device function that packs one weight tensor
+// into them; shared with the batched pack kernel of conv3_sb.hip (one launch packs every 3x3x3 weight of the network in both forms).
+#pragma once
+#include "ru_common.h"
+
+namespace ru {
+
+typedef unsigned int wz_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WZ_KSTEPS = 5;
+constexpr int WZ_HY = 10, WZ_HX = 18;
+constexpr int WZ_PLANE = WZ_HY * WZ_HX;                  // 180 halo positions per transformed plane
+constexpr int WZ_HVOLP = 4 * WZ_PLANE;                   // packets per [hi/lo][channel half] section: 4 transformed planes
+constexpr int WZ_BUF = 4 * WZ_HVOLP;                     // packets per image buffer (46 080 bytes)
+constexpr int WZ_SCRATCH_FLOATS = 4 * 2 * 8 * 64 * 4;    // [wave][group][row][lane] float4: the four waves' M accumulators of one tile
+constexpr int WZ_LDS_BYTES = 2 * WZ_BUF * 16 + WZ_SCRATCH_FLOATS * 4 + SB_STAT_LDS_FLOATS * 4;
+constexpr int WZ_UNITS = 4 * 2 * WZ_KSTEPS * 2;          // 16-byte x 64-lane fragment units per (32-cout block, 16-cin chunk): [xi][group][K-step][hi/lo]
+
+// tap dy*3 + dx (or -1: phantom, zero weights) in K-slot `slot` of K-step ks of one transformed plane
+__host__ __device__ constexpr int wz_tap(int ks, int slot) {
+    if (ks < 3) return ks * 3 + slot;                    // (dy = ks, dx 0) | (dy = ks, dx 1)
+    if (ks == 3) return slot * 3 + 2;                    // (dy 0, dx 2) | (dy 1, dx 2)
+    return slot == 0 ? 2 * 3 + 2 : -1;                   // (dy 2, dx 2) | phantom
+}
+
+
+// channel counts for which the transformed fragments exist beside the direct ones (whether a SHAPE takes the kernel: conv3_wz_shape_ok)
+__host__ __device__ constexpr bool wz_channels_ok(int Cin_conv, int Cout_conv) { return Cin_conv >= 32 && Cin_conv % 16 == 0 && Cout_conv % 32 == 0; }
+
+// thread i of ncog32 * nchunk * 4 * 2 * WZ_KSTEPS * 64: unit u = ((((cog32*nchunk + chunk)*4 + xi)*2 + g)*WZ_KSTEPS + ks)*2 + hl, 64 lanes x 16 bytes;
+// lane l (col = l&15, k-group kg = l>>4) holds, for e = 0..7, G_xi[cout = cog32*32 + g*16 + col][cin = chunk*16 + (kg&1)*8 + e][tap = wz_tap(ks, kg>>1)]
+// with G_0 = g0, G_1 = (g0 + g1 + g2)/2, G_2 = (g0 - g1 + g2)/2, G_3 = g2 over the dz slices g_dz of the (mode 1: mirrored, channel-exchanged) weight.
+__device__ __forceinline__ void wz_pack_one(const float* __restrict__ w, wz_u32x4* __restrict__ wzfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog32, int i) {
+    const int total = ncog32 * nchunk * 4 * 2 * WZ_KSTEPS * 64;
+    if (i >= total) return;
+    const int lane = i & 63;
+    int u = i >> 6;
+    const int ks = u % WZ_KSTEPS; u /= WZ_KSTEPS;
+    const int g = u & 1; u >>= 1;
+    const int xi = u & 3; u >>= 2;
+    const int chunk = u % nchunk;
+    const int cog32 = u / nchunk;
+    const int col = lane & 15, kg = lane >> 4;
+    const int tap2 = wz_tap(ks, kg >> 1);
+    const int co = cog32 * 32 + g * 16 + col;
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = chunk * 16 + (kg & 1) * 8 + e;
+        float v = 0.f;
+        if (tap2 >= 0) {
+            float gz[3];
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int tap = dz * 9 + tap2;
+                gz[dz] = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+            }
+            v = xi == 0 ? gz[0] : (xi == 3 ? gz[2] : (xi == 1 ? 0.5f * ((gz[0] + gz[2]) + gz[1]) : 0.5f * ((gz[0] + gz[2]) - gz[1])));
+        }
+        t[e] = v;
+    }
+    wz_u32x4 hi, lo;
+    split_n<4>(t, hi, lo);
+    const size_t unit = ((((size_t)(cog32 * nchunk + chunk) * 4 + xi) * 2 + g) * WZ_KSTEPS + ks) * 2;
+    wzfrag[(unit + 0) * 64 + lane] = hi;
+    wzfrag[(unit + 1) * 64 + lane] = lo;
+}
+
+static inline size_t wz_frag_bytes(int Cin_conv, int Cout_conv) {
+    return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ_UNITS * 64 * 16 : 0;
+}
+
+}  // namespace ru

@@ -151,9 +151,11 @@ static inline int conv3_effective_mode(int mode, int W) { return (mode == RU_PRE
 int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int mode);
 int conv3_launch(const Conv3Args& a, hipStream_t s);
 // split-bf16 path (conv3_sb.hip)
-int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
+bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);                 // the launch takes the Winograd-z kernel (conv3_wz.hpp)
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s);
-size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);
+size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);          // direct fragments + the Winograd-z fragments behind them (where the channel counts allow)
+size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv);
 size_t conv3_sb4_frag_bytes(int Cout_conv);
 int conv3_sb4_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);
 bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W);                                   // shape fits the 4-channel kernel

@@ -52,6 +52,23 @@ def run(Cin, Cout, S, seed=0):
     mm = lambda a, b: torch.einsum('cxyzijk,ocijk->oxyzijk', a, b)
     for name, M in (("wino_sb3", mm(Vh, Uh) + mm(Vl, Uh) + mm(Vh, Ul)), ("wino_f32", mm(V, U)), ("wino_bf16", mm(Vh, Uh))):
         out[name] = xform(M, AT, torch.float32).permute(0, 1, 4, 2, 5, 3, 6).reshape(Cout, S, S, S)
+    # round 5: F(2,3) along z ONLY ((y, x) taps direct: 18 transformed-domain "taps" per output pair instead of 27 -- 1.5x fewer products), the
+    # form conv3_wz_kernel computes: U = B^T d along z (4 transformed planes per pair of output planes), G = G g along dz, out = A^T M
+    tz = xp.unfold(1, 4, 2)                                             # [Cin, T, S+2, S+2, 4]
+    Vz = torch.einsum('ai,cthwi->ctahw', BT.float(), tz)                # [Cin, T, 4, S+2, S+2]
+    Uz = torch.einsum('ai,ocijk->ocajk', G.float(), w32.float())        # [Cout, Cin, 4, 3, 3]
+    Vzh, Vzl = split(Vz)
+    Uzh, Uzl = split(Uz)
+
+    def mmz(a, b):                                                      # per transformed plane xi: a 2-D 3x3 convolution over (y, x)
+        T = a.shape[1]
+        o = []
+        for xi in range(4):
+            o.append(torch.nn.functional.conv2d(a[:, :, xi].permute(1, 0, 2, 3), b[:, :, xi]))    # [T, Cout, S, S]
+        return torch.stack(o, 2)                                        # [T, Cout, 4, S, S]
+    for name, M in (("wz_sb3", mmz(Vzh, Uzh) + mmz(Vzl, Uzh) + mmz(Vzh, Uzl)), ("wz_f32", mmz(Vz, Uz)), ("wz_bf16", mmz(Vzh, Uzh))):
+        o = torch.einsum('pa,tcahw->ctphw', AT.float(), M)              # [Cout, T, 2, S, S]
+        out[name] = o.reshape(Cout, S, S, S)
     rms = ref.pow(2).mean().sqrt()
     return {k: (((v.double() - ref).abs().max() / rms).item(), ((v.double() - ref).pow(2).mean().sqrt() / rms).item()) for k, v in out.items()}
 
