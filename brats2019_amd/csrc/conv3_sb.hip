@@ -654,6 +654,14 @@ int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, in
 // number of statistics partials per (sample, channel) the kernel chosen for this shape writes
 // The Winograd-z kernel (conv3_wz.hpp) takes the voxel-major three-product convolutions of 32 and more channels whose shape fills the chip;
 // RU_WZ=0 keeps every shape on the direct kernels (same-box A/B).  ONE rule for the launch and for the partial count the engine sizes.
+// Split-form inputs (the data-gradient convolutions: gn_bwd_apply16's hi / lo packets) stay on the direct kernel by default: there the staging is a
+// global -> LDS DMA copy with no VALU work at all, while the z transform has to re-join, transform and re-split every value (7 VALU per element
+// + four dword loads per plane) -- measured 120 / 143 / 104 us against 93 / 107 / 79 (BST / ADD / both, profiles/r05_notes.txt).  RU_WZ=2 sends
+// them through the Winograd-z kernel too (tests hold that path to the direct one).
+bool conv3_sb_wz_takes_split() {
+    const char* e = getenv("RU_WZ");
+    return e && *e == '2';
+}
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products) {
     const char* e = getenv("RU_WZ");                    // read per call: tests and tools switch it inside one process
     const bool off = e && *e == '0';
@@ -733,7 +741,7 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     if ((RU_SB2_DBG & 2048) && !a.stat_partials) c = SBChoice{2, 8};      // tools: time the one-stage kernel on a shape the persistent kernel would take
     if ((RU_SB2_DBG & 4096) && !a.stat_partials) c = SBChoice{2, 4};
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
-    if (a.in_c16 && a.out_c16 && !a.bias && !a.sigmoid && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.products))
+    if (a.in_c16 && a.out_c16 && !a.bias && !a.sigmoid && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.in_s16 && !conv3_sb_wz_takes_split() ? 1 : a.products))
         return conv3_wz_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
     if (sb_use_v2(c)) {
         if (a.in_c16 && a.out_c16) return a.products == 1 ? conv3_sb2_launch_c16_p1(a, s) : conv3_sb2_launch_c16(a, s);

@@ -145,10 +145,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
                     const bool okz = ok & ((unsigned)(zm1 + pz) < (unsigned)D);
                     const unsigned ofs = okz ? (unsigned)(base + dlt[rd] + pz * pstride) : 0x80000000u;
                     if (s16) {                                           // hi dwords at +0, lo dwords at +32 (gn_bwd_apply16's packet layout)
-                        const auto h2 = __builtin_amdgcn_raw_buffer_load_b64(rs, ofs, 0, 0);
-                        const auto l2 = __builtin_amdgcn_raw_buffer_load_b64(rs, ofs, 32, 0);
-                        v[rd][pz] = make_float4(__builtin_bit_cast(float, h2[0]), __builtin_bit_cast(float, h2[1]), __builtin_bit_cast(float, l2[0]),
-                                                __builtin_bit_cast(float, l2[1]));
+                        // four dword loads: __builtin_amdgcn_raw_buffer_load_b64 compiles to ONE buffer_load_dword on this toolchain (ROCm 7.2
+                        // hipcc: the second element is never loaded) -- found by tests/test_hip_c16.py::test_conv3_split_form_input
+                        v[rd][pz] = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 0, 0)),
+                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 4, 0)),
+                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 32, 0)),
+                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 36, 0)));
                     } else {
                         v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
                     }

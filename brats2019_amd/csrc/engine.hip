@@ -938,7 +938,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
     FusedSums sums1;
     if (fuse1) {
-        sums1.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, h->grad_products());
+        sums1.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, (c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());      // (split-form input: the direct kernel)
         sums1.part = A.alloc((size_t)N * C * sums1.nblk * 2);
         sums1.coef = A.alloc((size_t)N * C * 3);
         d2.bst_y = sv.y1; d2.bst_k = sv.g1.k; d2.bst_slope = kSlope; d2.stat_partials = sums1.part;  // constants written by the forward finalize
@@ -963,7 +963,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     if (nx) nx->out = FusedSums();
     if (nx && fuse1 && bp.down < 0) {                   // same shape and kernel choice as d2: dx = dout + dgrad(conv1) IS the gradient entering nx
-        nx->out.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, h->grad_products());
+        nx->out.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, (c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());
         nx->out.part = A.alloc((size_t)N * C * nx->out.nblk * 2);
         nx->out.coef = A.alloc((size_t)N * C * 3);
         d1.bst_y = nx->y; d1.bst_k = nx->k; d1.bst_slope = nx->slope; d1.stat_partials = nx->out.part;

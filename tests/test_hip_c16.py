@@ -178,3 +178,38 @@ def test_conv3_voxel_major_volume_beyond_32bit_block_offsets():
     patch = x[0, :, d - 2:, h - 2:, w - 2:].double()
     direct = float((patch * wt[5, :, :2, :2, :2].double()).sum())
     assert abs(float(y[0, 5, d - 1, h - 1, w - 1]) - direct) <= 1e-4 * max(1.0, abs(direct))
+
+
+def _split_form(xc16):
+    """[N][C/16][D][H][W][16] fp32 -> the split form gn_bwd_apply16 publishes: per voxel and 16-channel block 64 bytes =
+    [hi bf16 ch0-7 | hi ch8-15 | lo ch0-7 | lo ch8-15], hi = bf16_rne(v), lo = bf16_rne(v - hi); returned as float32 words"""
+    hi = xc16.to(torch.bfloat16)
+    lo = (xc16 - hi.float()).to(torch.bfloat16)
+    packed = torch.cat([hi, lo], dim=-1).contiguous()                 # [..., 32] bf16 = 64 bytes
+    return packed.view(torch.float32), hi.float() + lo.float()
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 32, 32, 32), (1, 64, 64, 32, 32, 32), (2, 64, 64, 22, 20, 24), (4, 16, 16, 32, 32, 64)],
+                         ids=["wz32", "wz64", "wz64-ragged", "direct16"])
+def test_conv3_split_form_input(shape):
+    """The data-gradient convolutions of the engine read their input in SPLIT form (gn_bwd_apply16's hi / lo packets; flags bit 3).  The
+    Winograd-z kernel re-joins hi + lo per value before its z transform, the direct kernels copy the packets: both must give the
+    convolution of hi + lo -- held to a float64 convolution of exactly those values, and to each other."""
+    import os
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = shape
+    x = _rand(n, cin, d, h, w, seed=21)
+    wt = _rand(cout, cin, 3, 3, 3, seed=22) * float((2.0 / (cin * 27)) ** 0.5)
+    xs, xjoined = _split_form(ops.to_c16(x))
+    ref = torch.nn.functional.conv3d(ops.from_c16(xjoined).double().cpu(), wt.double().cpu(), padding=1)
+    rms = float(ref.pow(2).mean().sqrt())
+    res = {}
+    for tag, env in (("wz", "2"), ("direct", "0")):          # RU_WZ=2: split-form inputs take the Winograd-z kernel too (default: the direct DMA-staged one)
+        os.environ["RU_WZ"] = env
+        try:
+            y = ops.from_c16(ops.conv3d_layout(xs, wt, in_c16=True, out_c16=True, in_split=True))
+        finally:
+            os.environ.pop("RU_WZ", None)
+        res[tag] = float((y.double().cpu() - ref).abs().max()) / rms
+    print("  %s split-form input: max error / rms  winograd-z %.2e  direct %.2e" % (shape, res["wz"], res["direct"]))
+    assert res["wz"] <= 6e-5 and res["direct"] <= 6e-5, res

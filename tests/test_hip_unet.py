@@ -426,9 +426,12 @@ def test_unet128_train_step_bf16x3_matches_reference_fixture(golden, fusion):
 
 def test_fused_and_unfused_backward_agree_tightly():
     """A/B of the fused GroupNorm-backward kernels against the separate passes on the SAME forward (batch 2 x 128^3, bf16x3): the
-    fusions only move where sums are taken, so every convolution-weight gradient agrees to 2e-4 in relative L2 and every GroupNorm
+    fusions only move where sums are taken, so every convolution-weight gradient agrees to 1e-3 in relative L2 and every GroupNorm
     gamma / beta / bias gradient (sums of 4e6 signed fp32 terms that cancel to ~1e-3 of their magnitude, so the summation order
-    shows) to 2e-3; a dropped term in a fused epilogue would show at the 1e-2 level."""
+    shows) to 2e-3; a dropped term in a fused epilogue would show at the 1e-2 level.  The difference is summation-order noise of the
+    first block's GroupNorm-backward sums under a RANDOM upstream gradient: over five seeds of that gradient it ranges 2e-5 .. 4.5e-4 on the
+    convolution weights with either set of forward kernels (tools/fused_unfused_diff.py; round 5 -- the 2e-4 bar of round 4 sat inside
+    that range and held for the one seed used here only with the direct forward kernels)."""
     net, _ = build_model(O.DEFAULT_CFG, 2024, "bf16x3")
     x = T(O.make_input(2, 128, 128, 128, seed=2024)).cuda()
     w = torch.randn(2, 3, 128, 128, 128, generator=torch.Generator().manual_seed(1)).cuda() * 1e-3
@@ -446,7 +449,7 @@ def test_fused_and_unfused_backward_agree_tightly():
     worst_w = max((v, k) for k, v in rel.items() if ga[k].dim() == 5)
     worst_v = max((v, k) for k, v in rel.items() if ga[k].dim() != 5)
     print("fused vs unfused backward: worst relative L2 %.2e (%s) on conv weights, %.2e (%s) on vectors" % (worst_w + worst_v))
-    assert worst_w[0] < 2e-4, worst_w
+    assert worst_w[0] < 1e-3, worst_w
     assert worst_v[0] < 2e-3, worst_v
 
 
@@ -471,7 +474,7 @@ def test_round4_backward_fusions_on_ragged_shapes(n, dhw):
     worst_w = max((v, k) for k, v in rel.items() if res["on"][1][k].dim() == 5)
     worst_v = max((v, k) for k, v in rel.items() if res["on"][1][k].dim() != 5)
     print("fusions on vs off at %s x %s: worst relative L2 %.2e (%s) on conv weights, %.2e (%s) on vectors" % ((n, dhw) + worst_w + worst_v))
-    assert worst_w[0] < 2e-4, worst_w
+    assert worst_w[0] < 1e-3, worst_w
     assert worst_v[0] < 2e-3, worst_v
 
 
@@ -905,3 +908,37 @@ def test_criterion_hand_over_is_explicit_and_never_hides_or_leaks_a_gradient():
 def _backward_in_context(L, loss):
     with L.hand_over_to_network():
         loss.backward()
+
+
+def test_winograd_z_convolutions_agree_with_the_direct_kernels_through_the_network():
+    """conv3_wz_kernel inside the engine, all four variants: RU_WZ=1 (default: the forward convolutions of the 32..128-channel levels, fused
+    GroupNorm + LeakyReLU input transform, statistics epilogue), RU_WZ=2 (also the data-gradient convolutions: split-form input, residual add,
+    fused GroupNorm-backward sums) against RU_WZ=0 (direct kernels everywhere) on one batch-2 x 128^3 training step: probabilities within
+    1e-4, loss within 1e-5, every parameter gradient within 4e-3 relative L2 (LeakyReLU kinks: a 1e-5 activation difference flips ~1e-5 of the
+    units; the direct kernels against the f32 engine measure 3e-3 .. 9e-3 on the same scale)."""
+    import os
+    from brats2019_amd import loss as L
+    res = {}
+    for mode in ("0", "1", "2"):
+        os.environ["RU_WZ"] = mode
+        try:
+            net, _ = build_model(O.DEFAULT_CFG, 31, "bf16x3")
+            x = T(O.make_input(2, 128, 128, 128, seed=31)).cuda()
+            g = T(O.make_target(2, 128, 128, 128, seed=31)).cuda()
+            net.train()
+            out = net([x])
+            loss = L.FusedCriterion()(out, [g])
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("RU_WZ", None)
+        res[mode] = (out[0].detach().clone(), float(loss), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
+        del net
+    assert not torch.equal(res["1"][0], res["0"][0]), "the default path did not take the Winograd-z kernel"
+    assert torch.equal(res["2"][0], res["1"][0])                       # same forward
+    for mode in ("1", "2"):
+        dp = float((res[mode][0] - res["0"][0]).abs().max())
+        worst = max((float((res[mode][2][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)), k) for k, v in res["0"][2].items())
+        print("RU_WZ=%s vs direct: max |dp| %.2e, loss %.7f vs %.7f, worst gradient relative L2 %.2e (%s)" % (mode, dp, res[mode][1], res["0"][1], worst[0], worst[1]))
+        assert dp <= 1e-4 and abs(res[mode][1] - res["0"][1]) <= 1e-5 and worst[0] <= 4e-3, (mode, dp, worst)
+    assert any(not torch.equal(res["2"][2][k], res["1"][2][k]) for k in res["1"][2]), "RU_WZ=2 did not change the backward"
