@@ -662,6 +662,13 @@ bool conv3_sb_wz_takes_split() {
     const char* e = getenv("RU_WZ");
     return e && *e == '2';
 }
+// RU_WZ=3: the engine publishes the gradients that enter a Winograd-z-shaped data-gradient convolution as plain float32 (gn_bwd_apply16 without
+// the split), so that convolution takes the kernel with the cheap staging (4 VALU per element) -- and the weight gradient of the same layer
+// converts its dy while staging instead of copying packets.
+bool conv3_sb_wz_plain_dgrad() {
+    const char* e = getenv("RU_WZ");
+    return e && *e == '3';
+}
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products) {
     const char* e = getenv("RU_WZ");                    // read per call: tests and tools switch it inside one process
     const bool off = e && *e == '0';

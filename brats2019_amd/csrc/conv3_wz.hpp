@@ -280,15 +280,22 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
         const int fbB = half * HVOLP + (xi * HY + slot) * HX + 2 + (lane & 15);          // K-steps 3 / 4: rows (r | r+1) at dx 2
         const int fbB2 = half * HVOLP + (xi * HY) * HX + 2 + (lane & 15);                // rows 8, 9: both slots row r (slot 1 meets zero weights)
         u32x4 wreg[2][WZ_KSTEPS][2];
-        auto wptr = [&](int chunk) { return wfrag + ((size_t)((cog32 * nchunk + chunk) * 4 + xi) * (2 * WZ_KSTEPS * 2)) * 64 + lane; };
+        // weight fragments through a buffer descriptor: lane offset in a VGPR (constant), the unit's offset scalar -- no 64-bit VALU address
+        // arithmetic in the matrix wave's stream (as plain pointer loads the 20 refill loads of an item cost ~27 cycles each there)
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wfrag), 0, (int)((size_t)gridDim.y * nchunk * WZ_UNITS * 1024), 0x00020000);
+        const unsigned wlane = (unsigned)lane * 16u;
+        auto wbase = [&](int chunk) { return (unsigned)(((cog32 * nchunk + chunk) * 4 + xi) * (2 * WZ_KSTEPS * 2)) * 1024u; };      // scalar byte offset of this wave's 20 units
+        auto wload = [&](unsigned base, int g, int ks, int hl) __attribute__((always_inline)) {
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, base + (unsigned)(((g * WZ_KSTEPS + ks) * 2 + hl) * 1024), 0));
+        };
         {
-            const u32x4* wp = wptr(0);
+            const unsigned wb0 = wbase(0);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int ks = 0; ks < WZ_KSTEPS; ++ks) {
-                    wreg[g][ks][0] = wp[((g * WZ_KSTEPS + ks) * 2 + 0) * 64];
-                    wreg[g][ks][1] = wp[((g * WZ_KSTEPS + ks) * 2 + 1) * 64];
+                    wreg[g][ks][0] = wload(wb0, g, ks, 0);
+                    wreg[g][ks][1] = wload(wb0, g, ks, 1);
                 }
         }
         f32x4 acc[2][MT];
@@ -422,10 +429,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
         for (int w = 0; w < nitems; ++w) {
             if constexpr (prof) t0 = __builtin_readcyclecounter();
             const bool last = chunk == nchunk - 1;
-            const u32x4* wnext = wptr(chunk + 1 < nchunk ? chunk + 1 : 0);
+            const unsigned wnext = wbase(chunk + 1 < nchunk ? chunk + 1 : 0);
             const u32x4* buf = lds + (w & 1) * BUF;
             commit_stats();
-            const bool fin = pending && !(dbg & 8);      // the previous tile is combined and stored under this item's matrix work
+            const bool fin = pending && !(dbg & (8 | 256));      // the previous tile is combined and stored under this item's matrix work
+            // (devtools bit 256: no combine and no scratch writes -- compile-time, so the FIN / LAST tests vanish from the stream -- but the accumulators
+            // are kept alive by one store after the loop: what the matrix loop costs without its row bookkeeping)
             if (fin) fin_prepare(pn, ptz, pty, ptx);
             pending = false;
             if (chunk == 0) {
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             // scratch row by row.  Run-time, wave-uniform tests: three compile-time copies of the body -- one branch per item instead of 26 --
             // were built and SPILLED (238-366 VGPRs to scratch memory: the allocator keeps the weights of all copies apart), 2.4x slower.)
             {
-                const bool FIN = fin, LAST = last;
+                const bool FIN = fin, LAST = last && !(dbg & 256);
                 auto frag_ofs = [&](auto S) __attribute__((always_inline)) {
                     constexpr int r = decltype(S)::value / 2, f = decltype(S)::value % 2;
                     return (f == 0 ? fbA : (r < 8 ? fbB : fbB2)) + r * HX;
@@ -493,8 +502,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
                     if constexpr (ksd >= 0 && !(dbg & 16)) {    // (devtools bit 16: the weights are never refilled)
     #pragma unroll
                         for (int g = 0; g < 2; ++g) {
-                            wreg[g][ksd][0] = wnext[((g * WZ_KSTEPS + ksd) * 2 + 0) * 64];
-                            wreg[g][ksd][1] = wnext[((g * WZ_KSTEPS + ksd) * 2 + 1) * 64];
+                            wreg[g][ksd][0] = wload(wnext, g, ksd, 0);
+                            wreg[g][ksd][1] = wload(wnext, g, ksd, 1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -537,6 +546,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             if constexpr (prof) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; pt[4] += 1; }
         }
         if constexpr (prof) t0 = __builtin_readcyclecounter();
+        if constexpr ((dbg & 256) != 0) {
+            f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) sink += acc[g][i];
+            *reinterpret_cast<f32x4*>(a.y + (size_t)(blockIdx.x * 4 + rw) * 256 + lane * 4) = sink;
+            pending = false;
+        }
         commit_stats();
         if (pending && !(dbg & 8)) {                     // the last tile of this workgroup: nothing left to hide it under
             fin_prepare(pn, ptz, pty, ptx);

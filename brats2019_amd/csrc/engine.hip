@@ -917,9 +917,14 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     // the block is converted, but at 32 channels it costs what it saves: 203 us against 131 us + a 70 us apply pass, same box,
     // profiles/r02_notes.txt -- every input-channel group recomputes the apply while staging, and the producers become the slower side.)
     const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && (h->fusion & RU_FUSE_GN_BWD_APPLY);
+    // form of the gradients dy2 / dy1 that enter the two data-gradient convs (and the two weight gradients): split hi / lo packets (default: the
+    // direct conv kernel copies them global -> LDS), or plain float32 where the shape takes the Winograd-z kernel and RU_WZ=3 asks for it
+    const bool wzd = c16 && !fa && h->precision == RU_PREC_BF16X3 && conv3_sb_wz_plain_dgrad() && conv3_sb_uses_wz(N, C, C, D, H, W, h->grad_products());
+    const bool ds16 = c16 && !wzd;
+    const int dgrad_products = wzd ? h->grad_products() : ((c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());      // (for the kernel choice / partial count only)
     float *coef2 = nullptr, *coef1 = nullptr;
     int rc = gn_bwd(h, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, sums2,
-                    fa ? &coef2 : nullptr);
+                    fa ? &coef2 : nullptr, ds16);
     if (rc) return rc;
     const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
     // weight gradients whose dy has no other producer role (no fused apply: dy2 / dy1 are complete when gn_bwd returns) leave the chain:
@@ -928,17 +933,17 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     const bool aside = !A.dry && (h->fusion & RU_FUSE_SIDE_STREAM) && c16 && h->precision == RU_PREC_BF16X3 && !fa && !trace_on();
     hipStream_t sw = s;
     if (aside) { rc = side_fork(h, s); if (rc) return rc; sw = h->side; }
-    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb2 : nullptr);
+    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.y1, &sv.g1, dy2, G(h, grads, bp.conv2), N, C, C, D, H, W, c16, c16, nullptr, ds16, fa ? &gb2 : nullptr);
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.products = h->grad_products(); d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = c16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.products = h->grad_products(); d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = ds16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
     // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
     const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
     FusedSums sums1;
     if (fuse1) {
-        sums1.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, (c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());      // (split-form input: the direct kernel)
+        sums1.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, dgrad_products);
         sums1.part = A.alloc((size_t)N * C * sums1.nblk * 2);
         sums1.coef = A.alloc((size_t)N * C * 3);
         d2.bst_y = sv.y1; d2.bst_k = sv.g1.k; d2.bst_slope = kSlope; d2.stat_partials = sums1.part;  // constants written by the forward finalize
@@ -950,20 +955,20 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(h, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, fuse1 ? &sums1 : nullptr,
-                fa ? &coef1 : nullptr);
+                fa ? &coef1 : nullptr, ds16);
     if (rc) return rc;
     const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
     if (aside) { rc = side_fork(h, s); if (rc) return rc; }
-    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, c16, fa ? &gb1 : nullptr);
+    rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, ds16, fa ? &gb1 : nullptr);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.products = h->grad_products(); d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
-    d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = c16;
+    d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = ds16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     if (nx) nx->out = FusedSums();
     if (nx && fuse1 && bp.down < 0) {                   // same shape and kernel choice as d2: dx = dout + dgrad(conv1) IS the gradient entering nx
-        nx->out.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, (c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());
+        nx->out.nblk = conv3_sb_tiles_per_sample(N, C, C, D, H, W, dgrad_products);
         nx->out.part = A.alloc((size_t)N * C * nx->out.nblk * 2);
         nx->out.coef = A.alloc((size_t)N * C * 3);
         d1.bst_y = nx->y; d1.bst_k = nx->k; d1.bst_slope = nx->slope; d1.stat_partials = nx->out.part;

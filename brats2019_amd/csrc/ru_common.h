@@ -153,6 +153,7 @@ int conv3_launch(const Conv3Args& a, hipStream_t s);
 // split-bf16 path (conv3_sb.hip)
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);
+bool conv3_sb_wz_plain_dgrad();                   // RU_WZ=3: gradients entering such a data-gradient convolution are published as plain float32
 bool conv3_sb_wz_takes_split();                   // RU_WZ=2: split-form (data-gradient) inputs take the Winograd-z kernel as well                 // the launch takes the Winograd-z kernel (conv3_wz.hpp)
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s);
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);          // direct fragments + the Winograd-z fragments behind them (where the channel counts allow)

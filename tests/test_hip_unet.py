@@ -913,13 +913,13 @@ def _backward_in_context(L, loss):
 def test_winograd_z_convolutions_agree_with_the_direct_kernels_through_the_network():
     """conv3_wz_kernel inside the engine, all four variants: RU_WZ=1 (default: the forward convolutions of the 32..128-channel levels, fused
     GroupNorm + LeakyReLU input transform, statistics epilogue), RU_WZ=2 (also the data-gradient convolutions: split-form input, residual add,
-    fused GroupNorm-backward sums) against RU_WZ=0 (direct kernels everywhere) on one batch-2 x 128^3 training step: probabilities within
+    fused GroupNorm-backward sums), RU_WZ=3 (the same with the incoming gradients published as plain float32 instead of hi / lo packets) against RU_WZ=0 (direct kernels everywhere) on one batch-2 x 128^3 training step: probabilities within
     1e-4, loss within 1e-5, every parameter gradient within 4e-3 relative L2 (LeakyReLU kinks: a 1e-5 activation difference flips ~1e-5 of the
     units; the direct kernels against the f32 engine measure 3e-3 .. 9e-3 on the same scale)."""
     import os
     from brats2019_amd import loss as L
     res = {}
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "2", "3"):
         os.environ["RU_WZ"] = mode
         try:
             net, _ = build_model(O.DEFAULT_CFG, 31, "bf16x3")
@@ -936,7 +936,8 @@ def test_winograd_z_convolutions_agree_with_the_direct_kernels_through_the_netwo
         del net
     assert not torch.equal(res["1"][0], res["0"][0]), "the default path did not take the Winograd-z kernel"
     assert torch.equal(res["2"][0], res["1"][0])                       # same forward
-    for mode in ("1", "2"):
+    assert torch.equal(res["3"][0], res["1"][0])
+    for mode in ("1", "2", "3"):
         dp = float((res[mode][0] - res["0"][0]).abs().max())
         worst = max((float((res[mode][2][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)), k) for k, v in res["0"][2].items())
         print("RU_WZ=%s vs direct: max |dp| %.2e, loss %.7f vs %.7f, worst gradient relative L2 %.2e (%s)" % (mode, dp, res[mode][1], res["0"][1], worst[0], worst[1]))
