@@ -25,6 +25,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   fwd_batch    : forward-only volumes/s at the per-GPU batch of the training configuration (batch 4),
   fwd_f32      : the batch-1 forward in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
   trainer_step : the same training step driven through the reference surface (train.Trainer._train_one_epoch set up as main.py:126-142),
+  sliding_window / sliding_window_c96 / predict_case : BASELINE configs[4] (48 tiles; and the 18-tile geometry beside it) and one test.py case (4 TTA flips
+                 at the padded crop 160 x 192 x 160, device end to end),
   roofline_families : ms per step of every kernel family (3x3x3 conv / weight gradient at the 16-channel level and deeper, GroupNorm passes,
                  1x1 / stride-2 / up-sampling kernels) timed in place, next to the family's algorithmic FLOPs / bytes and its roofline bound
                  (GroupNorm: the achievable-fusion bound -- the passes that cannot ride on a convolution for fp32 tensors),
@@ -197,7 +199,8 @@ def committed_family_table():
             tail = [float(v) for v in f[-8:]]
             i = ln.index("ch")
             ch = int(ln[:i].split()[-1])
-            rows.append({"kind": "wgrad" if ln.startswith("wgrad") else "conv_fwd", "channels": ch, "avg_us": tail[0], "algorithmic_gb": tail[1],
+            rows.append({"kind": "wgrad" if ln.startswith("wgrad") else ("conv_fwd_direct_kernel" if ln.startswith("conv dir") else "conv_fwd"), "channels": ch,
+                         "kernel": next((t for t in f if "kernel" in t), None), "avg_us": tail[0], "algorithmic_gb": tail[1],
                          "hbm_frac": tail[3], "counter_gb": tail[4], "mfma_busy_pct": tail[5], "executed_mfma_frac": tail[7]})
         except (ValueError, IndexError):
             continue
@@ -461,15 +464,15 @@ def power_probe(fn, seconds=1.2, device_index=0):
     return {"median_w": float(np.median([r[0] for r in rows])), "median_sclk_mhz": float(np.median([r[1] for r in rows])), "limit_w": limit[0], "samples": len(rows)}
 
 
-def sliding_window_probe(backend, flat, precision, batch_tiles=8):
+def sliding_window_probe(backend, flat, precision, batch_tiles=8, centre=(64, 64, 64), border=(32, 32, 32)):
     """BASELINE configs[4]: full-volume inference of one BraTS-native 240x240x155x4 volume with overlapping 128^3 tiles
     (centre 64, border 32 -> 4 x 4 x 3 = 48 tiles, train.py:158-174 geometry generalised as in SURVEY 3.4), tiles batched
-    per forward, volume resident in HBM."""
+    per forward, volume resident in HBM.  Second geometry reported BESIDE it (never instead): centre 96, border 16 -> 18 tiles."""
     from brats2019_amd import tiling
     dev = flat.device
     shape = (240, 240, 155)
     vol = torch.randn((1, 4) + shape, device=dev)
-    tile, centre, border = (128, 128, 128), (64, 64, 64), (32, 32, 32)
+    tile = tuple(c + 2 * b for c, b in zip(centre, border))
     grid = tiling.grid_for(shape, centre)
     positions = [(i, j, k) for i in range(grid[0]) for j in range(grid[1]) for k in range(grid[2])]
     out = torch.zeros((1, 3) + shape, device=dev)
@@ -482,8 +485,51 @@ def sliding_window_probe(backend, flat, precision, batch_tiles=8):
             tiling.copy_back_tiles(out, probs, centre, los, border)        # ru_tile_scatter
     run()
     dt = time_region(run, 3, False) / 3
-    return {"value": round(1.0 / dt, 3), "unit": "240x240x155 volumes/s", "tiles": len(positions), "tile": 128, "centre": 64, "border": 32,
+    return {"value": round(1.0 / dt, 3), "unit": "240x240x155 volumes/s", "tiles": len(positions), "tile": tile[0], "centre": centre[0], "border": border[0],
             "batch_tiles": batch_tiles, "ms_per_volume": round(dt * 1e3, 2), "tiles_per_s": round(len(positions) / dt, 1), "precision": precision}
+
+
+def predict_case_probe(backend, flat, precision, reps=3):
+    """BASELINE configs[0] / test.py:82-168 at the shape it really produces: one BraTS-native case [4, 240, 240, 155] whose non-zero box pads to
+    160 x 192 x 160 (test.py:92-99 pads the crop to multiples of 16), through inference.predict_case_device -- bbox, crop + pad + z-score + the four
+    test-time flips as one batch, ONE batch-4 forward, un-flip / mean / threshold, label composition, 26-connected component rejection, paste --
+    with the case resident in HBM.  `roofline_frac` = the per-layer forward roofline of the four flipped volumes / the time of the WHOLE case."""
+    from brats2019_amd import model as M, inference as INF
+    dev = flat.device
+    shape, box = (240, 240, 155), (150, 185, 148)
+    gen = torch.Generator(device="cpu").manual_seed(99)
+    img = torch.zeros((4,) + shape)
+    lo = [(s - b) // 2 for s, b in zip(shape, box)]
+    img[:, lo[0]:lo[0] + box[0], lo[1]:lo[1] + box[1], lo[2]:lo[2] + box[2]] = torch.rand((4,) + box, generator=gen) * 3.0 + 0.05     # positive intensities inside the head
+    img = img.to(dev)
+    net = M.UNet(**backend.cfg)
+    net.set_precision(precision)
+    net.cuda()
+    with torch.no_grad():
+        for (name, p), (_n, v) in zip(net.named_parameters(), backend.engine.layout.views(flat).items()):
+            assert name == _n
+            p.copy_(v)
+    net.eval()
+    run = lambda: INF.predict_case_device(net, img)
+    labels, counts = run()
+    padded = tuple(INF.closest_to_k(int(v), 16) for v in box)
+    dt = time_region(run, reps, False) / reps
+    batch = INF.prepare_case_device(img)[0]
+    with torch.no_grad():
+        fwd = lambda: net([batch])
+        fwd()
+        dtf = time_region(fwd, reps, False) / reps
+    vox = float(padded[0] * padded[1] * padded[2])
+    bound = step_roofline_ms(4, 128, precision, forward_only=True) * vox / 128.0 ** 3
+    del net
+    return {"value": round(1.0 / dt, 3), "unit": "cases/s", "ms_per_case": round(dt * 1e3, 2), "case": list(shape), "padded_crop": list(padded), "tta_flips": 4,
+            "precision": precision, "roofline_ms_forward": round(bound, 3), "roofline_frac": round(bound / (dt * 1e3), 4),
+            "forward_ms": round(dtf * 1e3, 2), "forward_roofline_frac": round(bound / (dtf * 1e3), 4),
+            "labels_nonzero": int((labels > 0).sum().item()),
+            "what": "inference.predict_case_device (test.py:82-168 on the device): case_bbox / case_stats / case_prepare, one batch-4 TTA forward at the padded crop, "
+                    "tta_merge_box, compose_labels, cc_reject, paste_labels; the case is resident in HBM, the 6 bbox integers visit the host.  `forward_ms` = the batch-4 forward "
+                    "alone; the rest is pre- / post-processing, dominated here by the component labelling of a NOISE prediction (random-init weights: millions of tiny "
+                    "components, `labels_nonzero`) -- a trained network's few large regions cost < 1 ms (tests/test_inference.py)"}
 
 
 def trainer_step_probe(backend, flat, x, g, steps, warmup=2):
@@ -822,6 +868,9 @@ def main():
             backend.engine.freeze_params(True)
         if args.size == 128:
             out["sliding_window"] = sliding_window_probe(backend, flat, args.precision)
+            # the wider-centre geometry SURVEY 8(d) names, beside the 48-tile figure (its parity: tests/golden/sliding240_c96.npz)
+            out["sliding_window_c96"] = sliding_window_probe(backend, flat, args.precision, batch_tiles=6, centre=(96, 96, 96), border=(16, 16, 16))
+            out["predict_case"] = predict_case_probe(backend, flat, args.precision)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
     if not args.no_extras and args.probe_steps > 0:    # every rank runs the probe steps (they contain the collectives); rank 0 reports

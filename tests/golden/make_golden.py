@@ -308,12 +308,14 @@ def gen_unet(tag, cfg, n, dhw, seed, full_output, with_backward, nsamp=16, full_
 
 
 # ------------------------------------------------------------------ (5b) BASELINE configs[4]: sliding window over a BraTS-native volume
-def gen_sliding240():
+def gen_sliding240(name="sliding240.npz", center=(64, 64, 64), border=(32, 32, 32)):
     """The loop body of Trainer.predict_tiled (train.py:158-174) around the reference's own get_indices / copy / copy_back
     (loader_helper.py:34-97) and the reference UNet, with the tile geometry of BASELINE configs[4] (tile 128, centre 64, border 32;
-    the reference hard-codes 192/48/72 at train.py:154-156) on one seeded 240x240x155x4 volume: 4 x 4 x 3 = 48 forwards."""
+    the reference hard-codes 192/48/72 at train.py:154-156) on one seeded 240x240x155x4 volume: 4 x 4 x 3 = 48 forwards.
+    Second geometry (round 5, SURVEY 8(d) names it): centre 96, border 16 -> 3 x 3 x 2 = 18 forwards (`sliding240_c96.npz`)."""
     shape, seed = (240, 240, 155), 4242
-    tile, center, border = (128, 128, 128), (64, 64, 64), (32, 32, 32)
+    tile = tuple(c + 2 * b for c, b in zip(center, border))
+    assert tile == (128, 128, 128)
     net, _ = load_ref_unet(O.DEFAULT_CFG, 1337)
     net.eval()
     inp = t(O.make_input(1, *shape, seed=seed))
@@ -331,7 +333,7 @@ def gen_sliding240():
     mask = pn > 0.5
     flat = pn.ravel()
     stride = max(1, flat.size // 4096)
-    save("sliding240.npz", seed=np.int64(seed), shape=np.asarray(shape), tile=np.asarray(tile), center=np.asarray(center),
+    save(name, seed=np.int64(seed), shape=np.asarray(shape), tile=np.asarray(tile), center=np.asarray(center),
          border=np.asarray(border), grid=np.asarray(grid), mask_packed=np.packbits(mask.ravel()), mask_count=np.int64(mask.sum()),
          near_half_1e_5=np.int64((np.abs(pn - 0.5) < 1e-5).sum()), near_half_1e_3=np.int64((np.abs(pn - 0.5) < 1e-3).sum()),
          sample_stride=np.int64(stride), samples=flat[::stride][:4096].copy(),
@@ -524,6 +526,8 @@ if __name__ == "__main__":
                              "encoder_convs.2.0.downsample.0.weight"), projections=True)
     if want("sliding240"):
         gen_sliding240()
+    if want("sliding240_c96"):
+        gen_sliding240("sliding240_c96.npz", center=(96, 96, 96), border=(16, 16, 16))
     if want("adam"):
         gen_adam()
     if want("tiling"):

@@ -355,5 +355,5 @@ def test_bench_roofline_bookkeeping():
     assert abs(ab["gbytes_fused_lower_bound"] - 37.91) < 0.05 and abs(ab["gbytes_achievable"] - 45.96) < 0.05 and abs(ab["gbytes_achievable_all"] - 54.01) < 0.05
     assert abs(ab["achievable_ms"] / 15.833 - 0.375) < 0.002                                                     # the round-4 driver line, recomputed by its judge as 0.376
     ft = bench.committed_family_table()
-    assert ft is not None and len(ft["rows"]) == 8 and {r["channels"] for r in ft["rows"]} == {16, 32, 64, 128}
+    assert ft is not None and len(ft["rows"]) >= 8 and {r["channels"] for r in ft["rows"]} == {16, 32, 64, 128}
     assert all(0 < r["mfma_busy_pct"] < 100 and r["avg_us"] > 0 for r in ft["rows"])

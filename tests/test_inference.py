@@ -169,15 +169,18 @@ def test_entry_point_loads_reference_checkpoint_and_segments(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,batch_tiles,tol,band", [("bf16x3", 8, 1e-3, 1e-3), ("f32", 3, 2e-5, 1e-5)])
-def test_sliding_window_240x240x155_matches_reference_fixture(golden, tmp_path, precision, batch_tiles, tol, band):
+@pytest.mark.parametrize("fixture,precision,batch_tiles,tol,band", [("sliding240", "bf16x3", 8, 1e-3, 1e-3), ("sliding240", "f32", 3, 2e-5, 1e-5),
+                                                                    ("sliding240_c96", "bf16x3", 6, 1e-3, 1e-3)],
+                         ids=["48tiles-bf16x3", "48tiles-f32", "18tiles-c96-bf16x3"])
+def test_sliding_window_240x240x155_matches_reference_fixture(golden, tmp_path, fixture, precision, batch_tiles, tol, band):
     """BASELINE configs[4] at its full size: one BraTS-native 240x240x155x4 volume, 128^3 tiles (centre 64, border 32 -> 48 tiles)
     through Trainer.predict_tiled with batched tiles and frozen (packed-once) weights, against the REFERENCE's own tiling loop and
     UNet (tests/golden/sliding240.npz: train.py:158-174 + loader_helper.py:34-97 run by make_golden.py).  bf16x3: probabilities
     within 1e-3 (the bar of BASELINE.json), labels may only flip where the probability is within 1e-3 of the threshold; f32: 2e-5 /
-    1e-5 like the other exact-f32 tests (3 tiles per forward: a ragged last batch)."""
+    1e-5 like the other exact-f32 tests (3 tiles per forward: a ragged last batch).  Second geometry (round 5; SURVEY 8(d) names it): centre
+    96, border 16 -> 3 x 3 x 2 = 18 tiles, its own fixture `sliding240_c96.npz` generated by the same reference loop."""
     from brats2019_amd import model as M, train as TR
-    g = golden("sliding240")
+    g = golden(fixture)
     shape = tuple(int(v) for v in g["shape"])
     params = O.make_params(1337, **O.DEFAULT_CFG)
     net = M.UNet(**O.DEFAULT_CFG)

@@ -20,10 +20,10 @@ N = 4
 BF16_PEAK, HBM_PEAK = 2.5e15, 8.0e12
 
 
-def run(tag, extra, args):
+def run(tag, extra, args, more_env=None):
     out = "/tmp/ft_%s" % tag
     subprocess.run(["rm", "-rf", out])
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", **(more_env or {}))
     subprocess.run(["rocprofv3"] + extra + ["--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, PROBE] + args,
                    cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     return out
@@ -39,11 +39,16 @@ def kernel_rows(out, pattern, want):
 def main():
     lines = ["# kernel family table (tools/family_table.py): batch %d, voxel-major tensors, split-bf16 x3; peaks: %.1f PF dense bf16, %.1f TB/s HBM" % (N, BF16_PEAK / 1e15, HBM_PEAK / 1e12),
              "# kind   shape        kernel                          avg_us  alg_GB  alg_GB/s  hbm_frac  counter_GB (fetch x2 + write)  MFMA_busy%%  exec_MFMA_TF  exec_frac"]
-    for kind, kpat, flags in (("conv fwd", "conv3_sb2_kernel", "3"), ("wgrad", "wgrad3_tz_kernel", "3")):
+    # "conv fwd": the kernel the engine runs at that shape (round 5: conv3_wz_kernel -- Winograd F(2,3) along z -- at 32..128 channels);
+    # "conv dir": the direct persistent kernel at the same shapes (RU_WZ=0), kept beside it for comparison
+    for kind, kpats, flags, more_env in (("conv fwd", ("conv3_sb2_kernel", "conv3_wz_kernel"), "3", {}), ("conv dir", ("conv3_sb2_kernel",), "3", {"RU_WZ": "0"}),
+                                         ("wgrad", ("wgrad3_tz_kernel",), "3", {})):
         for c, size in SHAPES:
-            args = ["fwd" if kind == "conv fwd" else "wgrad", "bf16x3", str(N), str(c), str(size), "6", flags]
-            want = lambda r, kpat=kpat: kpat in r.get("Kernel_Name", r.get("Name", ""))
-            tr = kernel_rows(run("t", ["--kernel-trace"], args), "kernel_trace", want)
+            if kind == "conv dir" and c < 32:
+                continue
+            args = ["fwd" if kind.startswith("conv") else "wgrad", "bf16x3", str(N), str(c), str(size), "6", flags]
+            want = lambda r, kpats=kpats: any(k in r.get("Kernel_Name", r.get("Name", "")) for k in kpats)
+            tr = kernel_rows(run("t", ["--kernel-trace"], args, more_env), "kernel_trace", want)
             if not tr:
                 continue
             durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr)
@@ -51,13 +56,15 @@ def main():
             name = tr[0]["Kernel_Name"].replace("void ", "").split("(")[0]
             cnt = {}
             for cs in (["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]):
-                for r in kernel_rows(run("c", ["--pmc"] + cs, args), "counter_collection", want):
+                for r in kernel_rows(run("c", ["--pmc"] + cs, args, more_env), "counter_collection", want):
                     cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             mean = lambda k: sum(cnt[k]) / len(cnt[k]) if cnt.get(k) else float("nan")
             vox = N * size ** 3
-            alg_bytes = 2.0 * c * vox * 4 if kind == "conv fwd" else 2.0 * c * vox * 4      # conv: x + y; weight gradient: x + dy (fp32)
+            alg_bytes = 2.0 * c * vox * 4                                                    # conv: x + y; weight gradient: x + dy (fp32)
             flops = 2.0 * 27 * c * c * vox
-            exec_tf = flops * 3 * 28 / 27 / (us * 1e-6) / 1e12
+            # executed MFMA products per algorithmic one: direct kernels 3 x 28/27 (one phantom tap); Winograd-z 3 x 40/54 (four transformed planes x
+            # 10 tap slots, one of them phantom, per two output planes)
+            exec_tf = flops * (3 * 40 / 54 if "conv3_wz" in name else 3 * 28 / 27) / (us * 1e-6) / 1e12
             counter_gb = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024 / 1e9
             busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
             if kind == "conv fwd" and c == 16 and "--json" in sys.argv:
@@ -68,7 +75,7 @@ def main():
                 if "hbm_bytes_per_launch" in old:
                     hist["previous file (%s)" % old.get("source", "?").split(";")[-1].strip()] = {k: old[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch", "avg_launch_us_in_trace", "mfma_busy_pct") if k in old}
                 json.dump({"kernel": "conv3_sb2_kernel<4,8,C16 in,C16 out,single chunk> (3x3x3 conv 16->16, split-bf16 x3, batch 4 x 128^3, voxel-major tensors)",
-                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; %s" % os.environ.get("RU_ROUND_TAG", "round 4"),
+                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; %s" % os.environ.get("RU_ROUND_TAG", "round 5"),
                            "FETCH_SIZE_KB": mean("FETCH_SIZE"), "WRITE_SIZE_KB": mean("WRITE_SIZE"),
                            "correction": "FETCH_SIZE x2 for 16-byte-per-lane streaming reads on gfx950 (guide); WRITE_SIZE uncorrected",
                            "hbm_bytes_per_launch": int((2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024), "algorithmic_bytes_per_launch": int(alg_bytes),
