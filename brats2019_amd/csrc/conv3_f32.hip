@@ -269,6 +269,7 @@ int conv3_launch(const Conv3Args& a_in, hipStream_t s) {
     a.CoutP = conv3_cout_pad(a.Cout);
     RU_REQUIRE(a.N > 0 && a.Cin > 0 && a.Cout > 0 && a.D > 0 && a.H > 0 && a.W > 0, "conv3: bad shape");
     RU_REQUIRE((size_t)a.D * a.H * a.W < (1u << 31), "conv3: volume too large for 32-bit voxel offsets");
+    if ((a.in_c16 || a.out_c16) && !a.in_c4 && a.mode == RU_PREC_F32) return conv3_f32c_launch(a, a.wfrag, s);      // exact-f32 voxel-major flow (inference)
     if (a.in_c16 || a.out_c16 || a.in_c4) RU_REQUIRE(a.mode == RU_PREC_BF16X3, "conv3: voxel-major tensors need the split-bf16 kernel");
     if (a.in_c16 || a.out_c16 || a.in_c4 || conv3_effective_mode(a.mode, a.W) == RU_PREC_BF16X3) {
         RU_REQUIRE(a.wfrag != nullptr, "conv3: bf16x3 mode needs packed weight fragments");

@@ -467,6 +467,8 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments, all in one launch)
     auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
         if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
+        // exact-f32 voxel-major inference: per-lane f32 fragments in the same slot (never larger than the split-bf16 ones)
+        if (h->precision == RU_PREC_F32 && h->c16) RU_RUN(conv3_f32c_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
         // outside the voxel-major flow the f32 layout is always kept: ragged W falls back to the f32 kernel
         if (!h->c16) RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
         return RU_OK;
@@ -503,7 +505,8 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
 static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const float* wp, const char* wf, float* y, const GNSave* in_gn,
                     const float* gamma, const float* beta, GNSave& out_gn, int N, int Cin, int Cout, int D, int H, int W, bool x_c16 = true,
                     bool x_c4 = false) {
-    const int nblk = h->c16 ? conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision);
+    const int nblk = !h->c16 ? conv3_tiles_per_sample(N, Cin, Cout, D, H, W, h->precision)
+                     : (h->precision == RU_PREC_F32 ? conv3_f32c_tiles_per_sample(N, Cin, Cout, D, H, W) : conv3_sb_tiles_per_sample(N, Cin, Cout, D, H, W));
     t_hint_c = Cout;
     float* partials = A.alloc((size_t)N * Cout * nblk * 2);
     out_gn.mean = A.alloc_keep((size_t)N * kGroups);
@@ -533,7 +536,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     const int ksplit = (!h->c16 && conv3_effective_mode(h->precision, W) == RU_PREC_F32) ? conv3_f32_ksplit(N, Cin, Cout, D, H, W) : 1;
     out_gn.k = (h->training && h->c16) ? A.alloc_keep((size_t)N * 3 * Cout) : nullptr;
     // RU_FUSE_TAIL_FINALIZE: the conv's last workgroup turns the partials into mean / rstd / scale / shift (every split-bf16 kernel has the tail)
-    const bool tail = !A.dry && h->tails() && ksplit == 1;
+    const bool tail = !A.dry && h->tails() && ksplit == 1 && h->precision == RU_PREC_BF16X3;
     if (tail) {
         FinTail& f = a.fin;
         f.ticket = h->next_ticket(); f.kind = 1; f.nblk = nblk; f.N = N; f.C = Cout; f.G = kGroups; f.V = (size_t)D * H * W; f.eps = kEps;
@@ -620,7 +623,11 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     for (int i = 0; i < depth; ++i) { Dl[i] = h->D >> i; Hl[i] = h->H >> i; Wl[i] = h->W >> i; }
     auto Vl = [&](int i) { return (size_t)Dl[i] * Hl[i] * Wl[i]; };
     h->gn_order.clear();
-    h->c16 = h->precision == RU_PREC_BF16X3 && (h->W & 3) == 0;
+    // voxel-major flow: the split-bf16 engine, and (round 5) the exact-f32 INFERENCE forward -- conv3_f32c_kernel on voxel-major tensors with the same
+    // fused statistics / staging-side GroupNorm + LeakyReLU / coarse-grid 1x1 / no concat as the split-bf16 flow (BASELINE configs[1]; the exact-f32
+    // training path keeps the NCDHW kernels: its weight gradients exist there only).  RU_F32C=0: the NCDHW flow for the f32 forward too (A/B).
+    static const bool f32c_off = [] { const char* e = getenv("RU_F32C"); return e && *e == '0'; }();
+    h->c16 = (h->precision == RU_PREC_BF16X3 || (h->precision == RU_PREC_F32 && !h->training && !f32c_off)) && (h->W & 3) == 0;
     for (int c : h->ch) h->c16 = h->c16 && (c % 16 == 0);
     h->pack = A.alloc(h->pk_total);
     h->fpack = reinterpret_cast<char*>(A.alloc(h->fk_total / sizeof(float) + 64));
@@ -640,7 +647,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     h->x_in4_planned = false;
     h->y0 = A.alloc((size_t)N * C0 * Vl(0));
     const size_t stem_mark = A.off;
-    if (h->c16 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
+    if (h->c16 && h->precision == RU_PREC_BF16X3 && conv3_sb4_usable(N, kInCh, C0, Dl[0], Hl[0], Wl[0])) {
         // few input channels: 4-channel copy + the tap-pair kernel (K = 2 taps x 4 channels per packet) instead of padding 4 -> 16 channels
         float* x4 = A.alloc((size_t)N * 4 * Vl(0));
         float* wf4 = wf4_in;

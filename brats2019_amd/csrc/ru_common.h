@@ -150,6 +150,12 @@ static inline int conv3_effective_mode(int mode, int W) { return (mode == RU_PRE
 // number of spatial tiles per sample the kernel will use (== nblk of stat_partials)
 int conv3_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int mode);
 int conv3_launch(const Conv3Args& a, hipStream_t s);
+// exact-f32 convolution on voxel-major tensors (conv3_f32c.hip): forward only; `wfr` = fragments from conv3_f32c_pack_weights (Conv3Args::wfrag when
+// mode == RU_PREC_F32 and a voxel-major side is set -- conv3_launch routes there)
+size_t conv3_f32c_frag_bytes(int Cin_conv, int Cout_conv);
+int conv3_f32c_pack_weights(const float* w, void* wfr, int Cin_f, int Cout_f, int mode, hipStream_t s);
+int conv3_f32c_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s);
 // split-bf16 path (conv3_sb.hip)
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);
