@@ -103,8 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
     const int swz = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const int nsteps = swz < ntile ? (ntile - swz + G - 1) / G : 0;
     const int nitems = nsteps * nchunk;
-    // k-groups of 4 input channels that hold real channels in a chunk (the stem: Cin = 4 -> one group; otherwise 4)
-    const int kgroups = (a.Cin >= 16 || nchunk > 1) ? 4 : (a.Cin + 3) / 4;
+    constexpr int kgroups = IN16 ? 4 : 1;                // k-groups of 4 input channels per chunk (NCDHW input: the stem, Cin <= 4)
     auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
         int b = tile;
         n = b / tiles_per_sample;
@@ -275,29 +274,35 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            // (dz, dx) groups x 4-channel k-groups: MT + 2 operand rows read once, used by the three dy taps
+            // (dz, dx) groups x 4-channel k-groups = KQ * 9 blocks: the MT + 2 operand rows of a block are read once and serve its three dy taps.
+            // The rows of block b+1 are requested BEFORE block b's MFMAs (two register sets): issued right in front of their first use, the LDS
+            // latency of every block was exposed -- 17 % of the matrix loop at 8 rows per wave, 40 % at 2 (the 128-channel level of a batch-1 forward).
+            constexpr int KQ = IN16 ? 4 : 1;                 // k-groups of 4 input channels per chunk (NCDHW input: the stem's 4 channels)
+            constexpr int NB = 9 * KQ;
+            float fr[2][MT + 2];
+            auto load_block = [&](auto B, float (&dst)[MT + 2]) __attribute__((always_inline)) {
+                constexpr int b = decltype(B)::value, g9 = b / KQ, q = b % KQ, dz = g9 / 3, dx = g9 % 3;
 #pragma unroll
-            for (int g9 = 0; g9 < 9; ++g9) {
-                const int dz = g9 / 3, dx = g9 % 3;
+                for (int r = 0; r < MT + 2; ++r) dst[r] = buf[abase + q * 4 * CS + (dz * HY + r) * HX + dx];
+            };
+            load_block(std::integral_constant<int, 0>{}, fr[0]);
+            static_for<NB>([&](auto B) {
+                constexpr int b = decltype(B)::value, g9 = b / KQ, q = b % KQ, dz = g9 / 3, dx = g9 % 3;
+                if constexpr (b + 1 < NB) load_block(std::integral_constant<int, (b + 1 < NB ? b + 1 : 0)>{}, fr[(b + 1) & 1]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q >= kgroups) break;                  // (wave-uniform: the stem's single k-group)
-                    float fr[MT + 2];
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float4 w4 = wreg[dz * 9 + dy * 3 + dx];
+                    const float wv = q == 0 ? w4.x : (q == 1 ? w4.y : (q == 2 ? w4.z : w4.w));
 #pragma unroll
-                    for (int r = 0; r < MT + 2; ++r) fr[r] = buf[abase + q * 4 * CS + (dz * HY + r) * HX + dx];
+                    for (int i = 0; i < MT; ++i) acc[i] = mm(fr[b & 1][i + dy], wv, acc[i]);
+                }
+                if constexpr (q == KQ - 1) {
+                    if (nchunk > 1) {                    // the three taps of this group are dead for this item: the next chunk's go into their registers
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const float4 w4 = wreg[dz * 9 + dy * 3 + dx];
-                        const float wv = q == 0 ? w4.x : (q == 1 ? w4.y : (q == 2 ? w4.z : w4.w));
-#pragma unroll
-                        for (int i = 0; i < MT; ++i) acc[i] = mm(fr[i + dy], wv, acc[i]);
+                        for (int dy = 0; dy < 3; ++dy) wreg[dz * 9 + dy * 3 + dx] = wnext[(dz * 9 + dy * 3 + dx) * 64];
                     }
                 }
-                if (nchunk > 1) {                        // the three taps of this group are dead for this item: the next chunk's go into their registers
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) wreg[dz * 9 + dy * 3 + dx] = wnext[(dz * 9 + dy * 3 + dx) * 64];
-                }
-            }
+            });
             if (last) {
                 const int n = cn;
                 if (n != n_acc) {
@@ -358,7 +363,7 @@ int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s) {
     RU_REQUIRE(wfr != nullptr, "conv3_f32c: packed weight fragments missing");
     RU_REQUIRE(!a.add && !a.bst_y && !a.in_s16 && !a.in_c4 && !a.fin.ticket, "conv3_f32c: forward convolution only (no residual / fused backward sums / split-form input / tail)");
     RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_f32c: voxel-major input needs Cin %% 16 == 0");
-    RU_REQUIRE(a.in_c16 || a.Cin <= 16, "conv3_f32c: an NCDHW input has at most one 16-channel chunk (the stem)");
+    RU_REQUIRE(a.in_c16 || a.Cin <= 4, "conv3_f32c: an NCDHW input has at most four channels (the stem: one 4-channel k-group)");
     RU_REQUIRE(!a.out_c16 || (a.Cout % 16 == 0 && !a.bias && !a.sigmoid), "conv3_f32c: voxel-major output needs Cout %% 16 == 0 and has no bias / activation");
     RU_REQUIRE(a.out_c16 || (a.W & 3) == 0, "conv3_f32c: NCDHW output needs W %% 4 == 0");
     RU_REQUIRE(!a.in_c16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_f32c: a 16-channel block of the voxel-major input must be smaller than 2 GiB");

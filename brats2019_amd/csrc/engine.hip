@@ -1686,9 +1686,11 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     Conv3Args a{};
     void* wf = C.take(conv3_sb_frag_bytes(Cin, Cout) / 4 + 64);
     RU_WS_OK(C);
-    int rc = conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s);
+    const bool f32 = (flags & 16) != 0;                          // exact-f32 arithmetic on voxel-major tensors (conv3_f32c_kernel)
+    RU_REQUIRE(!f32 || ((flags & 3) != 0 && !(flags & (4 | 8))), "ru_conv3d_fwd_l: the exact-f32 form needs a voxel-major side and takes neither the 4-channel copy nor a split-form input");
+    int rc = f32 ? conv3_f32c_pack_weights(w, wf, Cin, Cout, 0, s) : conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s);
     if (rc) return rc;
-    a.mode = RU_PREC_BF16X3; a.wfrag = wf;
+    a.mode = f32 ? RU_PREC_F32 : RU_PREC_BF16X3; a.wfrag = wf;
     a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
     a.in_s16 = (flags >> 3) & 1;                                 // x is voxel-major in SPLIT form (hi / lo bf16 packets, as gn_bwd_apply16 publishes it)
     RU_REQUIRE(!a.in_s16 || a.in_c16, "ru_conv3d_fwd_l: the split form is a voxel-major layout");
@@ -1705,7 +1707,7 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
         if (rc) return rc;
         a.x = x4; a.wfrag = wf4; a.in_c4 = 1;
     }
-    return conv3_sb_launch(a, s);
+    return f32 ? conv3_launch(a, s) : conv3_sb_launch(a, s);
 }
 
 extern "C" int ru_conv3d_bwd_weight_l(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,

@@ -395,7 +395,7 @@ def to_split_c16(x_c16):
     return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32)
 
 
-def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False, in_split=False):
+def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False, in_split=False, exact_f32=False):
     """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16); few_channels: NCDHW input
     with Cin <= 4 through the 4-channel tap-pair kernel."""
     x, w, bias = _prep(x), _prep(w), _prep(bias)
@@ -409,7 +409,7 @@ def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=Fal
     lib = L.load()
     ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3) + (n * d * h * wd * 16 + 65536 if few_channels else 0), x.device)
     L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd,
-                                int(in_c16) | (int(out_c16) << 1) | (int(few_channels) << 2) | (int(in_split) << 3),
+                                int(in_c16) | (int(out_c16) << 1) | (int(few_channels) << 2) | (int(in_split) << 3) | (int(exact_f32) << 4),
                                 L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd_l")
     return y
 

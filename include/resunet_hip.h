@@ -315,7 +315,8 @@ int ru_paste_labels(const unsigned char* lab, unsigned char* full, int D, int H,
  * runs instead of 16 channel planes x short rows.  Nothing in that layout crosses the boundary of ru_unet_*; the
  * entry points below exist so the tests and probes can drive the layout-aware kernels one at a time.
  * flags: bit 0 = x (input) is C16, bit 1 = y (output) is C16, bit 2 = x is NCDHW with Cin <= 4 and goes through the 4-channel
- * tap-pair kernel (needs extra workspace: 16 bytes per input voxel).  k = 3, RU_PREC_BF16X3 only. */
+ * tap-pair kernel (needs extra workspace: 16 bytes per input voxel); bit 3 = x is voxel-major in SPLIT form (hi / lo bf16 packets); bit 4 = exact-f32
+ * arithmetic (v_mfma_f32_16x16x4_f32 on voxel-major tensors: the exact-f32 inference forward of the engine; not with bits 2 / 3).  k = 3. */
 int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int to_c16, ru_stream_t stream);
 int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y,
                     int N, int Cin, int Cout, int D, int H, int W, int flags,

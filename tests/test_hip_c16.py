@@ -213,3 +213,30 @@ def test_conv3_split_form_input(shape):
         res[tag] = float((y.double().cpu() - ref).abs().max()) / rms
     print("  %s split-form input: max error / rms  winograd-z %.2e  direct %.2e" % (shape, res["wz"], res["direct"]))
     assert res["wz"] <= 6e-5 and res["direct"] <= 6e-5, res
+
+
+F32C_SHAPES = [(1, 16, 16, 32, 32, 64, True, True), (1, 32, 32, 16, 32, 32, True, True), (2, 64, 32, 10, 20, 24, True, True), (1, 128, 128, 16, 16, 16, True, True),
+               (2, 16, 3, 12, 20, 24, True, False), (2, 4, 16, 12, 20, 24, False, True), (1, 4, 16, 64, 64, 64, False, True)]
+
+
+@pytest.mark.parametrize("shape", F32C_SHAPES, ids=["%dx%d-%d_%dx%dx%d_%d%d" % s for s in F32C_SHAPES])
+def test_conv3_exact_f32_voxel_major_equals_ncdhw_kernel_class(shape):
+    """conv3_f32c_kernel (exact-f32 MFMA on voxel-major tensors: the exact-f32 INFERENCE forward, BASELINE configs[1]) against a float64 convolution
+    and against the NCDHW exact-f32 kernel on the same inputs: both are k-ordered fmaf chains over the same products in different orders, so they agree
+    to f32 round-off and sit equally close to float64 (measured 0.8e-6 .. 2.3e-6 of the output maximum, growing with K = 27 Cin, the NCDHW kernel
+    0.7e-6 .. 2.6e-6; bars 4e-6 and 1.3x the NCDHW kernel's error).  Shapes: the three tile sizes ((4,8), (2,8), (2,4)), several input
+    chunks, ragged extents with several samples, the head form (voxel-major in, NCDHW out, 3 channels + bias) and the stem form (4 NCDHW channels in)."""
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w, in16, out16 = shape
+    x = _rand(n, cin, d, h, w, seed=41)
+    wt = _rand(cout, cin, 3, 3, 3, seed=42) * float((2.0 / (cin * 27)) ** 0.5)
+    bias = None if out16 else _rand(cout, seed=43)
+    ref64 = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), None if bias is None else bias.double().cpu(), padding=1)
+    ncdhw = ops.conv3d(x, wt, bias, precision="f32")
+    y = ops.conv3d_layout(ops.to_c16(x) if in16 else x, wt, bias, in_c16=in16, out_c16=out16, exact_f32=True)
+    if out16:
+        y = ops.from_c16(y)
+    scale = float(ref64.abs().max())
+    e_new, e_old = float((y.double().cpu() - ref64).abs().max()) / scale, float((ncdhw.double().cpu() - ref64).abs().max()) / scale
+    print("  %s: max error / max |y|  voxel-major f32 %.2e  NCDHW f32 %.2e" % (shape, e_new, e_old))
+    assert e_new <= 4e-6 and e_new <= 1.3 * e_old + 5e-7 and float((y - ncdhw).abs().max()) <= 5e-6 * scale
