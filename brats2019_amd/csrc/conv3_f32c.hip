@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
             dlt[r] = IN16 ? ((hz * H + hy) * W + xc) * 64 : ((hz * H + hy) * W + xc) * 4;      // byte offset relative to the halo origin
         }
         float4 v[NR][4];                                   // [round][channel quad]
+        float4 scq[4], shq[4];                             // fused input transform of the item in flight: requested with its loads, one item ahead
         unsigned vmask = 0;
         int n_cur = 0, chunk_cur = 0;
         auto issue = [&](int item) {
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
             n_cur = n; chunk_cur = chunk;
             const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
             vmask = 0;
+            if (xform && IN16) {                               // (read at store time these 8 loads were an exposed L2 round trip per item)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    scq[q] = *reinterpret_cast<const float4*>(a.in_scale + n * a.Cin + chunk * 16 + q * 4);
+                    shq[q] = *reinterpret_cast<const float4*>(a.in_shift + n * a.Cin + chunk * 16 + q * 4);
+                }
+            }
             if constexpr (IN16) {
                 const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
@@ -178,12 +186,20 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
         };
         auto store = [&](float* buf) {
             float sc[16], sh[16];
+            if (xform && IN16) {                               // voxel-major input: whole 16-channel chunks (Cin % 16 == 0)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int cg = chunk_cur * 16 + c;
-                const bool cok = cg < a.Cin;
-                sc[c] = cok ? 1.f : 0.f; sh[c] = 0.f;                               // channels beyond Cin: exact zeros
-                if (xform && cok) { sc[c] = a.in_scale[n_cur * a.Cin + cg]; sh[c] = a.in_shift[n_cur * a.Cin + cg]; }
+                for (int q = 0; q < 4; ++q) {
+                    sc[q * 4] = scq[q].x; sc[q * 4 + 1] = scq[q].y; sc[q * 4 + 2] = scq[q].z; sc[q * 4 + 3] = scq[q].w;
+                    sh[q * 4] = shq[q].x; sh[q * 4 + 1] = shq[q].y; sh[q * 4 + 2] = shq[q].z; sh[q * 4 + 3] = shq[q].w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int cg = chunk_cur * 16 + c;
+                    const bool cok = cg < a.Cin;
+                    sc[c] = cok ? 1.f : 0.f; sh[c] = 0.f;                           // channels beyond Cin: exact zeros
+                    if (xform && cok) { sc[c] = a.in_scale[n_cur * a.Cin + cg]; sh[c] = a.in_shift[n_cur * a.Cin + cg]; }
+                }
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
