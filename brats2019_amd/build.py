@@ -41,7 +41,7 @@ def _stale(target, deps):
 
 
 def _compile(src, force, devtools=None):
-    if not (src.startswith("conv3_sb") or src.startswith("conv3_wz")):
+    if not (src.startswith("conv3_sb") or src.startswith("conv3_wz") or src.startswith("wgrad_tr")):
         devtools = None                        # only this unit has RU_SB2_DBG switches: the others are shared with the product build
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + (".dbg%d.o" % devtools if devtools is not None else ".o"))
     path = os.path.join(CSRC, src)

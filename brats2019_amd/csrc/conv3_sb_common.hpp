@@ -491,7 +491,8 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 const int gz = zm1 + (pk[r] & 0xff), gy = ym1 + ((pk[r] >> 8) & 0xff), gx = xm1 + ((pk[r] >> 16) & 0xff);
                 bool ok = ((unsigned)gz < (unsigned)D) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);     // (no short-circuit branches)
                 if constexpr ((r + 1) * 128 > NPOS) ok = ok & plast;
-                const unsigned ofs = ok ? (unsigned)(base + dlt[r]) : 0x80000000u;
+                // (devtools bit 25: every staging load of the voxel-major path hits one cache line -- results wrong -- is memory latency / bandwidth on the critical path?)
+                const unsigned ofs = ok ? ((dbg & (1 << 25)) ? 0u : (unsigned)(base + dlt[r])) : 0x80000000u;
                 vmask |= ok ? (1u << r) : 0u;
                 v16[r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
                 if (NP == 3 || !s16) v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, second, 0));   // (split form, one product: the lo packet is not read)

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const int gz = hp0 + pl - 1, gy = y0 + hy - 1, gx = x0 + xc - 1;
                 const bool live = pl < npl;
                 const bool ok = live && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#if defined(RU_SB2_DBG) && (RU_SB2_DBG & (1 << 24))
+                const size_t ofs = 0;                    // devtools bit 24: every staging load hits one cache line (results wrong): is the staging LATENCY on the critical path?
+#else
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+#endif
                 if constexpr (XS == 1) {                 // 4-channel copy: channels 0-3 real (half 0), the rest of the block is zero
                     mx |= (ok && hsel == 0) ? (1u << r) : 0u;
                     vx[r][0] = *reinterpret_cast<const float4*>(a.x + (size_t)n * DHW * 4 + (ofs >> 2));
@@ -250,7 +254,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 const int gz = 2 * k + z, gy = y0 + y, gx = x0 + xc;
                 const bool ok = p < DPOS && gz < D && gy < H && gx < W;
                 const float* db = a.dy + ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + hsel * 8;
+#if defined(RU_SB2_DBG) && (RU_SB2_DBG & (1 << 24))
+                const size_t ofs = 0;
+#else
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
+#endif
                 if constexpr (DS == 3) {                 // GroupNorm-backward apply on the fly: forward tensor y and gradient d
                     md |= ok ? (1u << r) : 0u;
                     const size_t cb = ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 8;

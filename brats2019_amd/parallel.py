@@ -363,7 +363,7 @@ def init_process_group_from_env(backend=None):
     return rank, local, world
 
 
-def init_process_groups_with_fallback(prefer="nccl", inject_failure=False, timeout_s=120, device_index=None):
+def init_process_groups_with_fallback(prefer="nccl", inject_failure=False, timeout_s=120, device_index=None, allow_single=False):
     """One-shot multi-GPU runs (bench.py under the driver's launcher): a run on a node nobody can look at must not end without a data
     point because RCCL could not come up.  The DEFAULT process group is gloo (control plane: agreement, and the fallback transport); the
     DATA group is RCCL (`backend="nccl"`), created on top and health-checked with one tiny all-reduce on every rank.  The ranks agree
@@ -373,7 +373,7 @@ def init_process_groups_with_fallback(prefer="nccl", inject_failure=False, timeo
     import datetime
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not (allow_single and "RANK" in os.environ):       # (allow_single: tests run the group set-up with ONE rank on the one-GPU boxes)
         return 0, 0, 1, None, {"backend": None, "fallback_reason": None}
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))

@@ -33,7 +33,15 @@ def main():
     backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(0)
-    if world > 1 or backend == "nccl":
+    group = None
+    if backend == "gloo+nccl":
+        # what bench.py's ranks do (parallel.init_process_groups_with_fallback): gloo default group, RCCL data group on top, health check
+        from brats2019_amd import parallel as P0
+        os.environ.setdefault("LOCAL_RANK", "0")
+        _r, _l, _w, group, info = P0.init_process_groups_with_fallback("nccl", allow_single=True, device_index=0)
+        assert info == {"backend": "nccl", "fallback_reason": None}, info
+        assert group is not None and dist.get_backend(group) == "nccl" and dist.get_backend() == "gloo"
+    elif world > 1 or backend == "nccl":
         dist.init_process_group("gloo" if backend == "rccl-direct" else backend, rank=rank, world_size=world)
     from brats2019_amd import parallel as P
     x = torch.from_numpy(O.make_input(GLOBAL_BATCH, *DHW, seed=SEED))
@@ -47,12 +55,12 @@ def main():
         for k, v in be.engine.layout.views(flat).items():
             v.copy_(torch.from_numpy(params[k]))
         comm = P.RcclComm(rank, world) if backend == "rccl-direct" else None      # ru_comm_* / ru_allreduce instead of torch.distributed
-        st = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm)
+        st = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm, process_group=group)
         sl = P.DataParallelStep.shard(GLOBAL_BATCH, rank, world)
         xs, gs = x[sl].cuda(), g[sl].cuda()
         l1, d1, b1 = st.loss_and_grads(xs, gs)
         res.update(loss=float(l1), dice=float(d1), bce=float(b1), grads=st.grads.cpu().numpy())
-        st2 = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm)
+        st2 = P.DataParallelStep(be, flat, lr=1e-3, step_size=1, gamma=0.5, comm=comm, process_group=group)
         la = float(st2.step(xs, gs)[0])
         lb = float(st2.step(xs, gs)[0])
         res.update(l_step1=la, l_step2=lb, weights=flat.cpu().numpy())

@@ -97,6 +97,17 @@ def test_rccl_transport_executes_with_one_rank(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_rccl_data_group_on_a_gloo_default_group_executes_with_one_rank(tmp_path):
+    """The process-group set-up bench.py's ranks use under the driver's launcher (parallel.init_process_groups_with_fallback: gloo default group,
+    RCCL data group created on top, health-check all-reduce, agreement over gloo) executed on the HEALTHY path with one rank: the data group is
+    RCCL, no fallback reason, and the step through `process_group=<that group>` equals the run without any process group bit for bit."""
+    (ref,) = _launch("step", tmp_path, 1)
+    ref = {k: v.copy() for k, v in ref.items()}
+    (got,) = _launch("step", tmp_path, 1, backend="gloo+nccl")
+    assert float(got["loss"]) == float(ref["loss"]) and np.array_equal(got["grads"], ref["grads"]) and np.array_equal(got["weights"], ref["weights"])
+
+
+@pytest.mark.timeout(900)
 def test_library_rccl_entry_points_execute_with_one_rank(tmp_path):
     """ru_comm_unique_id / ru_comm_init / ru_allreduce (include/resunet_hip.h): the step's collectives through the library's own RCCL
     binding on the kernels' stream, no torch.distributed call in the data path.  One rank (RCCL refuses two ranks on one device):
