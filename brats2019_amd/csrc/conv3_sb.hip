@@ -18,7 +18,7 @@
 //         registers: 14 K-steps x 2 x 4 VGPRs.
 //   C/D: lane holds 4 consecutive x voxels of output channel l&15 -> shared epilogue (conv3_epilogue.hpp).
 #include "conv3_sb_common.hpp"
-#include "conv3_wz.hpp"
+#include "conv3_wz_pack.hpp"
 
 namespace ru {
 

@@ -31,22 +31,6 @@
 
 namespace ru {
 
-// shapes the kernel takes: voxel-major in and out, several input chunks, whole 32-channel output blocks, an even number of planes, and at least
-// one (2,8,16) tile x 32-cout block per CU (below that the one-stage kernel's smaller tiles fill the chip better)
-static inline bool conv3_wz_shape_ok(int N, int Cin, int Cout, int D, int H, int W) {
-    if (Cin < 32 || Cin % 16 != 0 || Cout % 32 != 0 || (D & 1)) return false;
-    if ((size_t)D * H * W * 64 >= ((size_t)1 << 31)) return false;
-    const long items = (long)N * (D / 2) * cdiv(H, 8) * cdiv(W, 16) * (Cout / 32);
-    return items >= sb_ncu();
-}
-static inline long wz_grid_x(int N, int Cout, int D, int H, int W) {
-    const int ncu = sb_ncu(), ncog = Cout / 32;
-    const long ntile = (long)N * (D / 2) * cdiv(H, 8) * cdiv(W, 16);
-    long gx = ncu / (ncog < ncu ? ncog : ncu);
-    if (gx < 1) gx = 1;
-    return gx > ntile ? ntile : gx;
-}
-
 // devtools bit 128: consumer wave 0 of every workgroup adds s_memtime section sums here (cycles): [0] item setup, [1] rows 0-4, [2] rows 5-9 + row 7's
 // scratch write, [3] barrier, [4] items, [5] tail after the loop, [6] workgroups, [7] staging wave 0: cycles from item barrier to item barrier spent in store + issue
 static __device__ unsigned long long wz_prof[8];
@@ -581,8 +565,5 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
     }
     fin_tail(a.fin, a.stat_partials, smem);
 }
-
-int conv3_wz_launch(const Conv3Args& a, const void* wzfrag, hipStream_t s);
-size_t conv3_wz_frag_bytes(int Cin_conv, int Cout_conv);
 
 }  // namespace ru

@@ -1,7 +1,8 @@
-// conv3_wz_pack.hpp -- fragment conventions of the Winograd-z convolution (conv3_wz.hpp) and the device function that packs one weight tensor
-// into them; shared with the batched pack kernel of conv3_sb.hip (one launch packs every 3x3x3 weight of the network in both forms).
+// conv3_wz_pack.hpp -- fragment conventions of the Winograd-z convolution (conv3_wz.hpp), the device function that packs one weight tensor into them
+// and the shape rule of the kernel: what conv3_sb.hip needs (its batched pack kernel packs every 3x3x3 weight of the network in both forms, its launch
+// routine routes by shape) without instantiating the kernel template.
 #pragma once
-#include "ru_common.h"
+#include "conv3_sb_common.hpp"
 
 namespace ru {
 
@@ -69,5 +70,23 @@ __device__ __forceinline__ void wz_pack_one(const float* __restrict__ w, wz_u32x
 static inline size_t wz_frag_bytes(int Cin_conv, int Cout_conv) {
     return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ_UNITS * 64 * 16 : 0;
 }
+
+// shapes the kernel takes: voxel-major in and out, several input chunks, whole 32-channel output blocks, an even number of planes, and at least
+// one (2,8,16) tile x 32-cout block per CU (below that the one-stage kernel's smaller tiles fill the chip better)
+static inline bool conv3_wz_shape_ok(int N, int Cin, int Cout, int D, int H, int W) {
+    if (Cin < 32 || Cin % 16 != 0 || Cout % 32 != 0 || (D & 1)) return false;
+    if ((size_t)D * H * W * 64 >= ((size_t)1 << 31)) return false;
+    const long items = (long)N * (D / 2) * cdiv(H, 8) * cdiv(W, 16) * (Cout / 32);
+    return items >= sb_ncu();
+}
+static inline long wz_grid_x(int N, int Cout, int D, int H, int W) {
+    const int ncu = sb_ncu(), ncog = Cout / 32;
+    const long ntile = (long)N * (D / 2) * cdiv(H, 8) * cdiv(W, 16);
+    long gx = ncu / (ncog < ncu ? ncog : ncu);
+    if (gx < 1) gx = 1;
+    return gx > ntile ? ntile : gx;
+}
+
+int conv3_wz_launch(const Conv3Args& a, const void* wzfrag, hipStream_t s);
 
 }  // namespace ru
