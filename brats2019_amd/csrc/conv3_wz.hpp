@@ -225,6 +225,35 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             else if (xform) body(std::integral_constant<int, 1>{});
             else body(std::integral_constant<int, 0>{});
         };
+        // Row operands of the epilogue (BST: the forward tensor y; ADD: the residual): the combining waves read them one fragment step ahead of their
+        // use, which hides an L1 / L2 hit but not a trip to HBM -- loaded cold they cost 28-40 us per launch (tools: devtools bit 512).  The staging
+        // waves therefore TOUCH the 32 operand rows of a tile one item before it is combined: LDS-DMA loads (no VGPRs, never dead-code) of one row
+        // (16 voxels x 64 bytes of a 16-channel block = 1 KB = one wave-wide 16-byte load) each, landing in a 1 KB pad nobody reads.
+        auto prefetch_rows = [&](int item) {
+            if constexpr (BST || ADD) {
+                if constexpr ((dbg & 1024) != 0) return;
+                const int step = item / nchunk;
+                int n, z0, y0, x0;
+                tile_origin(swz + step * G, n, z0, y0, x0);
+                auto pad = (__attribute__((address_space(3))) void*)(stat_lds + SB_STAT_LDS_FLOATS);
+                const int xv = x0 + (lane >> 2);                         // this lane's voxel of the row
+                static_for<(BST ? 1 : 0) + (ADD ? 1 : 0)>([&](auto T) __attribute__((always_inline)) {
+                    const float* base = (BST && decltype(T)::value == 0) ? a.bst_y : a.add;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float* blk = base + ((size_t)(n * (a.Cout >> 4) + cog32 * 2 + g) * DHW) * 16;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blk), 0, (int)(DHW * 64), 0x00020000);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {                    // 16 (plane, row) pairs of this group: four per staging wave
+                            const int pr = rw * 4 + q, pzz = pr >> 3, yy = y0 + (pr & 7);
+                            const bool ok = (yy < H) & (xv < W);
+                            const unsigned ofs = ok ? (unsigned)((((z0 + pzz) * H + yy) * W + x0) * 64 + lane * 16) : 0x80000000u;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, pad, 16, ofs, 0, 0, 0);
+                        }
+                    }
+                });
+            }
+        };
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, 1> S1{};
         if (nitems > 0) issue(S0, 0);
@@ -238,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
         for (int w = 0; w < nitems; w += 2) {            // item w+1 lives in set 1, item w+2 in set 0
             unsigned long long t0 = 0;
             if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
+            if (w % nchunk == nchunk - 1) prefetch_rows(w);      // (the consumers are on item w: its tile is combined during item w+1)
             if (w + 1 < nitems) {
                 store(S1, lds + BUF);
                 if (w + 3 < nitems) issue(S1, w + 3);
@@ -246,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             __syncthreads();
             if (w + 1 >= nitems) break;
             if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
+            if ((w + 1) % nchunk == nchunk - 1) prefetch_rows(w + 1);
             if (w + 2 < nitems) {
                 store(S0, lds);
                 if (w + 4 < nitems) issue(S0, w + 4);
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
         SbOut fso{};
         int fy = 0;
         f32x4 fm[3];
-        float4 fradd = make_float4(0.f, 0.f, 0.f, 0.f), frbst = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 fradd2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)}, frbst2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // row i lives in slot i & 1
         const int ia = pz, ib = pz + 1, ic = pz + 2;                      // plane 0: M0 + M1 + M2; plane 1: M1 - M2 - M3
         const float sg = pz ? -1.f : 1.f;
         auto fin_prepare = [&](int n, int tz, int ty, int tx) {
@@ -357,11 +388,15 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             fm[0] = S[((ia * 2 + og) * MT + i) * 64 + lane];
             fm[1] = S[((ib * 2 + og) * MT + i) * 64 + lane];
             fm[2] = S[((ic * 2 + og) * MT + i) * 64 + lane];
-            if constexpr (ADD || BST) {
+        };
+        // the row operands of the epilogue (BST: forward tensor y, ADD: residual) are requested a FULL row ahead of their use (two register slots):
+        // one fragment step (~300 cycles) covers an LDS read, not the L2 hit the staging waves' prefetch turns these loads into
+        auto fin_load_ops = [&](int i) __attribute__((always_inline)) {
+            if constexpr ((ADD || BST) && !(dbg & 512)) {     // (devtools bit 512: the row operands are not loaded -- what do these loads cost?)
                 const int yy = fy + i;
                 const size_t ri = (fso.ok && yy < H) ? sb_out_index<true>(a, fso, yy) : 0;
-                if constexpr (ADD) fradd = *reinterpret_cast<const float4*>(a.add + ri);
-                if constexpr (BST) frbst = *reinterpret_cast<const float4*>(a.bst_y + ri);
+                if constexpr (ADD) fradd2[i & 1] = *reinterpret_cast<const float4*>(a.add + ri);
+                if constexpr (BST) frbst2[i & 1] = *reinterpret_cast<const float4*>(a.bst_y + ri);
             }
         };
         // (component by component: as whole-vector expressions these lower to v_pk_add_f32 / v_pk_fma_f32, and inside the matrix wave a packed-f32
@@ -373,6 +408,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             if constexpr ((dbg & 32) != 0) { s1[0] += vv[0] + vv[1] + vv[2] + vv[3]; return; }          // (devtools bit 32: the row is combined but neither counted nor stored)
             const int yy = fy + i;
             if (!(fso.ok && yy < H)) return;
+            const float4 fradd = fradd2[i & 1], frbst = frbst2[i & 1];
             if constexpr (ADD) { vv[0] += fradd.x; vv[1] += fradd.y; vv[2] += fradd.z; vv[3] += fradd.w; }      // residual first: the sums are those of the STORED tensor
             if constexpr (BST) {                         // sb_out_tile_bst's arithmetic: u = y*k1 + k2, dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
                 const float yv[4] = {frbst.x, frbst.y, frbst.z, frbst.w};
@@ -419,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
             const bool fin = pending && !(dbg & (8 | 256));      // the previous tile is combined and stored under this item's matrix work
             // (devtools bit 256: no combine and no scratch writes -- compile-time, so the FIN / LAST tests vanish from the stream -- but the accumulators
             // are kept alive by one store after the loop: what the matrix loop costs without its row bookkeeping)
-            if (fin) fin_prepare(pn, ptz, pty, ptx);
+            if (fin) { fin_prepare(pn, ptz, pty, ptx); fin_load_ops(0); }
             pending = false;
             if (chunk == 0) {
 #pragma unroll
@@ -493,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
                     }
                     // ---- row bookkeeping between the MFMAs
                     if constexpr (f == 0 && r < MT) {           // previous tile, row r: operands one step ahead of their use
-                        if (FIN) fin_load(r);
+                        if (FIN) { fin_load(r); if constexpr (r + 1 < MT) fin_load_ops(r + 1); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (f == 1 && r < MT) {
@@ -543,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
         if (pending && !(dbg & 8)) {                     // the last tile of this workgroup: nothing left to hide it under
             fin_prepare(pn, ptz, pty, ptx);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) { fin_load(i); fin_row(i); }
+            for (int i = 0; i < MT; ++i) { fin_load_ops(i); fin_load(i); fin_row(i); }
         }
         __syncthreads();                                 // (a flush inside that fin_prepare is in LDS now)
         commit_stats();

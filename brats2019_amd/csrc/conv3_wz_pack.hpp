@@ -14,7 +14,7 @@ constexpr int WZ_PLANE = WZ_HY * WZ_HX;                  // 180 halo positions p
 constexpr int WZ_HVOLP = 4 * WZ_PLANE;                   // packets per [hi/lo][channel half] section: 4 transformed planes
 constexpr int WZ_BUF = 4 * WZ_HVOLP;                     // packets per image buffer (46 080 bytes)
 constexpr int WZ_SCRATCH_FLOATS = 4 * 2 * 8 * 64 * 4;    // [wave][group][row][lane] float4: the four waves' M accumulators of one tile
-constexpr int WZ_LDS_BYTES = 2 * WZ_BUF * 16 + WZ_SCRATCH_FLOATS * 4 + SB_STAT_LDS_FLOATS * 4;
+constexpr int WZ_LDS_BYTES = 2 * WZ_BUF * 16 + WZ_SCRATCH_FLOATS * 4 + SB_STAT_LDS_FLOATS * 4 + 1024;      // images, M scratch, statistics scratch, 1 KB landing pad of the operand prefetch
 constexpr int WZ_UNITS = 4 * 2 * WZ_KSTEPS * 2;          // 16-byte x 64-lane fragment units per (32-cout block, 16-cin chunk): [xi][group][K-step][hi/lo]
 
 // tap dy*3 + dx (or -1: phantom, zero weights) in K-slot `slot` of K-step ks of one transformed plane
