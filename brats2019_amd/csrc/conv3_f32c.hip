@@ -53,6 +53,21 @@ static inline long f32c_grid_x(int N, int Cout, int D, int H, int W, int tz, int
 
 // weight fragments: unit (cog, chunk, tap) = 64 lanes x float4: lane l (col = l & 15, kq = l >> 4) holds, for q = 0..3,
 // W[cout = cog*16 + col][cin = chunk*16 + 4q + kq][tap] (mode 1: mirrored taps, exchanged channel roles) -- zeros beyond the real channels
+// HEAD form (at most 4 output channels and one input chunk: conv_output, model.py:348): a 16-wide N tile for 3 channels wastes 13/16 of the matrix
+// work, so the N columns carry (dy, cout) pairs instead -- column n = 4 dy + co.  The operand row of halo row R then feeds, in ONE MFMA per (dz, dx) and
+// 4-channel group, the three output rows R, R-1, R-2 (taps dy = 0, 1, 2): 9 * 4 * (MT + 2) MFMAs per wave and item instead of 27 * 4 * MT (360 for 864);
+// the three contributions of an output row sit in three accumulators' columns (co, dy) and are summed across lanes in the epilogue (two 4-lane shifts).
+// Fragment unit (g9 = dz*3 + dx, q): lane l (n = l & 15, kq = l >> 4) holds W[co = n & 3][cin = 4q + kq][dz][dy = n >> 2][dx], zero for dy = 3 or co >= Cout.
+static inline bool f32c_head_form(int Cin_conv, int Cout_conv) { return Cout_conv <= 4 && Cin_conv <= 16; }
+__global__ void conv3_f32c_pack_head_kernel(const float* __restrict__ w, float* __restrict__ wh, int Cin_f, int Cout_f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 36 * 64) return;
+    const int lane = i & 63, u = i >> 6, g9 = u >> 2, q = u & 3;
+    const int n = lane & 15, kq = lane >> 4, dy = n >> 2, co = n & 3, ci = 4 * q + kq;
+    float v = 0.f;
+    if (dy < 3 && co < Cout_f && ci < Cin_f) v = w[((size_t)co * Cin_f + ci) * 27 + (g9 / 3) * 9 + dy * 3 + g9 % 3];
+    wh[i] = v;
+}
 __global__ void conv3_f32c_pack_kernel(const float* __restrict__ w, float4* __restrict__ wfr, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncog * nchunk * 27 * 64) return;
@@ -75,6 +90,11 @@ __global__ void conv3_f32c_pack_kernel(const float* __restrict__ w, float4* __re
 size_t conv3_f32c_frag_bytes(int Cin_conv, int Cout_conv) { return (size_t)cdiv(Cout_conv, 16) * cdiv(Cin_conv, 16) * 27 * 64 * 16; }
 int conv3_f32c_pack_weights(const float* w, void* wfr, int Cin_f, int Cout_f, int mode, hipStream_t s) {
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    if (mode == 0 && f32c_head_form(cin_conv, cout_conv)) {
+        hipLaunchKernelGGL(conv3_f32c_pack_head_kernel, dim3(9), dim3(256), 0, s, w, (float*)wfr, Cin_f, Cout_f);
+        RU_CHECK_LAUNCH("conv3_f32c_pack_head_kernel");
+        return RU_OK;
+    }
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
     const int total = ncog * nchunk * 27 * 64;
     hipLaunchKernelGGL(conv3_f32c_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, (float4*)wfr, Cin_f, Cout_f, mode, nchunk, ncog);
@@ -82,8 +102,9 @@ int conv3_f32c_pack_weights(const float* w, void* wfr, int Cin_f, int Cout_f, in
     return RU_OK;
 }
 
-template <int TZ, int TY, bool IN16, bool OUT16>
+template <int TZ, int TY, bool IN16, bool OUT16, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, const float4* __restrict__ wfr, int ntz, int nty, int ntx, int nchunk) {
+    static_assert(!HEAD || (IN16 && !OUT16), "head form: voxel-major in, NCDHW out");
     using P = F32C<TZ, TY>;
     constexpr int HY = P::HY, HX = P::HX, HVOL = P::HVOL, CS = P::CS, MT = P::MT, BUF = P::BUF_FLOATS, NR = P::NR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -170,17 +191,10 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                     if constexpr ((r + 1) * 256 > HVOL) ok = ok & (r * 256 + ptid < HVOL);
                     vmask |= ok ? (1u << r) : 0u;
                     const size_t pos = ok ? (size_t)((base + dlt[r]) >> 2) : 0;
+                    float t[4];                                                // only the k-group the matrix loop reads (channels 0-3) is staged
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float t[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c = chunk * 16 + q * 4 + j;
-                            const int cc = c < a.Cin ? c : 0;                      // (clamped: unconditional loads)
-                            t[j] = q < kgroups ? a.x[((size_t)n * a.Cin + cc) * DHW + pos] : 0.f;
-                        }
-                        v[r][q] = make_float4(t[0], t[1], t[2], t[3]);
-                    }
+                    for (int j = 0; j < 4; ++j) t[j] = a.x[((size_t)n * a.Cin + (j < a.Cin ? j : 0)) * DHW + pos];      // (clamped: unconditional loads)
+                    v[r][0] = make_float4(t[0], t[1], t[2], t[3]);
                 });
             }
         };
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                 if ((r + 1) * 256 > HVOL && p >= HVOL) continue;
                 const bool live = (vmask >> r) & 1u;                                // the zero padding applies to the ACTIVATED tensor
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < kgroups; ++q) {
                     const float f[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -237,14 +251,19 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
         const int mz = (rw * MT) / TY, my0 = (rw * MT) % TY;
         const int kq = lane >> 4;
         const int abase = kq * CS + (mz * HY + my0) * HX + (lane & 15);          // + 4q*CS + (dz*HY + r)*HX + dx
-        float4 wreg[27];
+        float4 wreg[HEAD ? 1 : 27];
+        float wh[HEAD ? 36 : 1];                         // head form: one float per (dz, dx) group and 4-channel k-group
         auto wptr = [&](int chunk) { return wfr + ((size_t)(cog * nchunk + chunk) * 27) * 64 + lane; };
-        {
+        if constexpr (HEAD) {
+            const float* wp = reinterpret_cast<const float*>(wfr) + lane;
+#pragma unroll
+            for (int u = 0; u < 36; ++u) wh[u] = wp[u * 64];
+        } else {
             const float4* wp = wptr(0);
 #pragma unroll
             for (int t = 0; t < 27; ++t) wreg[t] = wp[t * 64];
         }
-        f32x4 acc[MT];
+        f32x4 acc[HEAD ? MT + 2 : MT];                   // head form: one accumulator per HALO row (its columns are (dy, cout) pairs)
         auto mm = [](float av, float wv, const f32x4& c) -> f32x4 {
             if constexpr (OUT16) return __builtin_amdgcn_mfma_f32_16x16x4f32(wv, av, c, 0, 0, 0);      // D[m = cout][n = voxel]
             else return __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, c, 0, 0, 0);
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
             commit_stats();
             if (chunk == 0) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < (HEAD ? MT + 2 : MT); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             // (dz, dx) groups x 4-channel k-groups = KQ * 9 blocks: the MT + 2 operand rows of a block are read once and serve its three dy taps.
             // The rows of block b+1 are requested BEFORE block b's MFMAs (two register sets): issued right in front of their first use, the LDS
@@ -305,6 +324,10 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
             static_for<NB>([&](auto B) {
                 constexpr int b = decltype(B)::value, g9 = b / KQ, q = b % KQ, dz = g9 / 3, dx = g9 % 3;
                 if constexpr (b + 1 < NB) load_block(std::integral_constant<int, (b + 1 < NB ? b + 1 : 0)>{}, fr[(b + 1) & 1]);
+                if constexpr (HEAD) {                    // one MFMA per halo row: columns (dy, co) take its contribution to output rows R, R-1, R-2
+#pragma unroll
+                    for (int r = 0; r < MT + 2; ++r) acc[r] = mm(fr[b & 1][r], wh[g9 * 4 + q], acc[r]);
+                } else {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const float4 w4 = wreg[dz * 9 + dy * 3 + dx];
@@ -312,7 +335,8 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[i] = mm(fr[b & 1][i + dy], wv, acc[i]);
                 }
-                if constexpr (q == KQ - 1) {
+                }
+                if constexpr (q == KQ - 1 && !HEAD) {
                     if (nchunk > 1) {                    // the three taps of this group are dead for this item: the next chunk's go into their registers
 #pragma unroll
                         for (int dy = 0; dy < 3; ++dy) wreg[dz * 9 + dy * 3 + dx] = wnext[(dz * 9 + dy * 3 + dx) * 64];
@@ -329,7 +353,18 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                 const int ybase = cty * TY + my0;
                 const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) sb2_out_row<OUT16, false>(a, so, ybase + i, acc[i], zero4, s1, s2);
+                for (int i = 0; i < MT; ++i) {
+                    if constexpr (HEAD) {
+                        // output row i = column (co, 0) of halo row i + column (co, 1) of halo row i+1 + column (co, 2) of halo row i+2: the lanes of
+                        // columns 4 dy + co hold them, four and eight lanes up (same 16-lane group: same four x positions)
+                        f32x4 v = acc[i];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (v[r] + __shfl_down(acc[i + 1][r], 4)) + __shfl_down(acc[i + 2][r], 8);
+                        sb2_out_row<OUT16, false>(a, so, ybase + i, v, zero4, s1, s2);      // (lanes of columns >= Cout are masked by so.ok)
+                    } else {
+                        sb2_out_row<OUT16, false>(a, so, ybase + i, acc[i], zero4, s1, s2);
+                    }
+                }
             }
             if (++chunk == nchunk) {
                 chunk = 0;
@@ -351,18 +386,18 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
     }
 }
 
-template <int TZ, int TY, bool IN16, bool OUT16>
+template <int TZ, int TY, bool IN16, bool OUT16, bool HEAD = false>
 static int f32c_cfg(const Conv3Args& a, const void* wfr, hipStream_t s) {
     using P = F32C<TZ, TY>;
     static PerDevice attr_done;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f32c_kernel<TZ, TY, IN16, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_f32c_kernel<TZ, TY, IN16, OUT16, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, P::LDS_BYTES);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_f32c)");
         attr_done.set();
     }
     const int ntz = cdiv(a.D, TZ), nty = cdiv(a.H, TY), ntx = cdiv(a.W, 16);
     dim3 grid((unsigned)f32c_grid_x(a.N, a.Cout, a.D, a.H, a.W, TZ, TY), (unsigned)cdiv(a.Cout, 16));
-    hipLaunchKernelGGL((conv3_f32c_kernel<TZ, TY, IN16, OUT16>), grid, dim3(512), P::LDS_BYTES, s, a, (const float4*)wfr, ntz, nty, ntx, cdiv(a.Cin, 16));
+    hipLaunchKernelGGL((conv3_f32c_kernel<TZ, TY, IN16, OUT16, HEAD>), grid, dim3(512), P::LDS_BYTES, s, a, (const float4*)wfr, ntz, nty, ntx, cdiv(a.Cin, 16));
     RU_CHECK_LAUNCH("conv3_f32c_kernel");
     return RU_OK;
 }
@@ -388,7 +423,7 @@ int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s) {
 #define RU_F32C_CASE(TZ, TY)                                                                                   \
     if (c.tz == TZ && c.ty == TY) {                                                                            \
         if (a.in_c16 && a.out_c16) return f32c_cfg<TZ, TY, true, true>(a, wfr, s);                             \
-        if (a.in_c16) return f32c_cfg<TZ, TY, true, false>(a, wfr, s);                                         \
+        if (a.in_c16) return f32c_head_form(a.Cin, a.Cout) ? f32c_cfg<TZ, TY, true, false, true>(a, wfr, s) : f32c_cfg<TZ, TY, true, false>(a, wfr, s); \
         return f32c_cfg<TZ, TY, false, true>(a, wfr, s);                                                       \
     }
     RU_F32C_CASE(4, 8)
