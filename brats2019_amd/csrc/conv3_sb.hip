@@ -591,6 +591,28 @@ __device__ __forceinline__ void sb_pack_one(const float* __restrict__ w, u32x4* 
     wfrag[(unit + 0) * 64 + lane] = hi;
     wfrag[(unit + 1) * 64 + lane] = lo;
 }
+// head-form unit u = f*2 + hl (f = 0..4), behind the direct fragments: lane l (col = l&15 = 4 dy + co, k-group g = l>>4) holds, for e = 0..7,
+// W[cout = co][cin = (g&1)*8 + e][tap = sb_head_tap(f, g>>1, dy)] (conv3_sb_common.hpp, sb_head_shape)
+__device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u32x4* __restrict__ hfrag, int Cin_f, int Cout_f, int mode, int i) {
+    if (i >= SB_HEAD_KSTEPS * 64) return;
+    const int lane = i & 63, f = i >> 6;
+    const int col = lane & 15, g = lane >> 4, dy = col >> 2, co = col & 3;
+    const int tap = sb_head_tap(f, g >> 1, dy);
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = (g & 1) * 8 + e;
+        float v = 0.f;
+        if (tap >= 0 && ci < cin_conv && co < cout_conv)
+            v = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+        t[e] = v;
+    }
+    u32x4 hi, lo;
+    split8(t, hi, lo);
+    hfrag[((size_t)f * 2 + 0) * 64 + lane] = hi;
+    hfrag[((size_t)f * 2 + 1) * 64 + lane] = lo;
+}
 // Every weight is packed in BOTH forms where the channel counts allow the Winograd-z kernel (conv3_wz.hpp): the direct fragments, and right behind
 // them (conv3_sb_frag_bytes_direct) the transformed ones -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
 // every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones.
@@ -598,12 +620,14 @@ __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4*
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
     if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
     wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct);
 }
 static inline int sb_pack_threads(int cin_conv, int cout_conv) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0);
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0)
+         + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0);
 }
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
     sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, blockIdx.x * blockDim.x + threadIdx.x);
@@ -638,8 +662,13 @@ int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, in
 size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv) {
     return (size_t)cdiv(Cout_conv, 16) * cdiv(Cin_conv, 16) * SB_KSTEPS * 2 * 64 * 16;
 }
-size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments behind them)
-    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv);
+size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments | <= 4 couts: the head form) behind them
+    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv)
+         + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0);
+}
+bool conv3_sb_head_form_enabled() {
+    const char* e = getenv("RU_HEAD_FORM");
+    return !(e && e[0] == '0');
 }
 
 int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {

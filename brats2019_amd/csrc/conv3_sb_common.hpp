@@ -29,6 +29,19 @@ __host__ __device__ constexpr int sb_tap(int ks, int slot) {
     return dy < 3 ? 2 * 9 + dy * 3 + 2 : -1;
 }
 
+// HEAD form (at most 4 output channels, one input chunk, NCDHW output: conv_output, model.py:348).  A 16-wide N tile for 3 channels wastes 13/16 of the
+// matrix work, so the N columns carry (dy, cout) pairs: column n = 4 dy + co.  The fragment F(f, r) of halo row r then feeds, in ONE MFMA per product,
+// the three output rows r, r-1, r-2 -- 5 fragments x 10 halo rows x 3 products = 150 MFMAs per wave and item instead of 336 -- into the accumulator of
+// HALO row r; an output row is the sum of three accumulators' column groups, taken across lanes in the epilogue.  K-step f (f < 4) holds chains 2f and
+// 2f+1 as in sb_tap; K-step 4 the ninth chain in slot 0 (slot 1 zero).  The fragments sit behind the direct (and Winograd-z) ones of the same weight.
+constexpr int SB_HEAD_KSTEPS = 5;
+__host__ __device__ constexpr bool sb_head_shape(int Cin_conv, int Cout_conv) { return Cout_conv <= 4 && Cin_conv <= 16; }
+__host__ __device__ constexpr int sb_head_tap(int f, int slot, int dy) {
+    if (dy > 2) return -1;
+    if (f < 4) return sb_tap(3 * f + dy, slot);
+    return slot == 0 ? 2 * 9 + dy * 3 + 2 : -1;
+}
+
 template <int TZ, int TY>
 struct SB {
     static constexpr int HZ = TZ + 2, HY = TY + 2, HX = 18;
@@ -259,7 +272,7 @@ static __device__ unsigned long long sb2_prof[8];     // (one per translation un
 // NP: MFMA products per operand pair.  3 = split-bf16 (hi*hi + lo*hi + hi*lo, ~2^-17 relative).  1 = plain bf16 operands (hi*hi only,
 // fp32 accumulate): the gradient precision RU_PREC_BF16 of the engine's backward -- the staging writes and the consumers read the hi
 // planes only, the weights' lo fragments are never fetched.  Voxel-major input only.
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST, bool ADD, int NP = 3>
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST, bool ADD, int NP = 3, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk, int dbg_arg) {
     // dbg (RU_SB2_DEBUG, ablation only; results are wrong when set): 1 = producers skip transform/split/LDS store,
     // 2 = producers skip global loads, 4 = consumers skip the MFMAs, 8 = consumers skip the epilogue.
@@ -683,18 +696,21 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         }
         fbase[4] = (kg & 1) * HVOLP + ((mz + 2) * HY + my0 + (kg >> 1)) * HX + 2 + (lane & 15);   // ninth chain (dz 2, dx 2): slot 0 = row r, slot 1 = row r+1
         fbase[5] = (kg & 1) * HVOLP + ((mz + 2) * HY + my0) * HX + 2 + (lane & 15);               // rows 8, 9: both slots row r (slot 1 meets zero weights)
-        u32x4 wreg[SB_KSTEPS][2];
-        auto wptr = [&](int chunk) { return wfrag + ((size_t)(cog * nchunk + chunk) * (SB_KSTEPS * 2)) * 64 + lane; };
+        static_assert(!HEAD || (!OUT16 && !MULTI && !BST && !ADD), "head form: one input chunk, NCDHW output, plain epilogue");
+        constexpr int NKS = HEAD ? SB_HEAD_KSTEPS : SB_KSTEPS;
+        u32x4 wreg[NKS][2];
+        auto wptr = [&](int chunk) { return wfrag + ((size_t)(cog * nchunk + chunk) * (NKS * 2)) * 64 + lane; };
         auto load_w = [&](int chunk) {
             const u32x4* wp = wptr(chunk);
 #pragma unroll
-            for (int ks = 0; ks < SB_KSTEPS; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 wreg[ks][0] = wp[(ks * 2 + 0) * 64];
                 if constexpr (NP == 3) wreg[ks][1] = wp[(ks * 2 + 1) * 64];
             }
         };
         load_w(0);                                      // one chunk: the weights stay in registers for the whole run of tiles
-        f32x4 acc[MT];
+        f32x4 acc[HEAD ? 1 : MT];
+        f32x4 hacc[HEAD ? NP : 1][HEAD ? MT + 2 : 1];   // head form: one accumulator per HALO row and product (consecutive MFMAs never share one)
         // OUT16: operands swapped -> D[m = cout][n = voxel] (lane owns 4 couts of one voxel, see sb_out_tile)
         auto mm = [](const bf16x8& av, const bf16x8& wv, const f32x4& c) -> f32x4 {
             if constexpr (OUT16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, av, c, 0, 0, 0);
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if (prof) { t1 = __builtin_readcyclecounter(); pt[0] += t1 - t0; t0 = t1; }
             auto frag_ofs = [&](auto S) __attribute__((always_inline)) {
                 constexpr int r = decltype(S)::value / 5, f = decltype(S)::value % 5;
-                return fbase[f < 4 ? f : (r < 8 ? 4 : 5)] + r * HX;
+                return fbase[f < 4 ? f : (r < 8 && !HEAD ? 4 : 5)] + r * HX;      // (head form: slot 1 of the ninth chain meets zero weights in every row)
             };
             constexpr int RING = (dbg & 16384) ? 4 : 3;  // (devtools bit 16384: one more step of look-ahead; +8 VGPRs)
             constexpr int AH = RING - 1;                 // steps of look-ahead
@@ -809,9 +825,33 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             for (int j = 0; j < 3; ++j) { radd[j] = make_float4(0.f, 0.f, 0.f, 0.f); rbst[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
             auto store_tile = [&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
-                if constexpr ((dbg & 8) != 0) { dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3]; return; }   // ablation: the MFMAs stay, the row is dropped
-                if constexpr (BST) sb_out_tile_bst(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
-                else sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
+                if constexpr (HEAD) {
+                    // output row i = columns (co, dy 0) of halo row i + columns (co, 1) of halo row i+1 + columns (co, 2) of halo row i+2: four and eight
+                    // lanes up in the same 16-lane row (same x positions) -- DPP row shifts, no LDS
+                    f32x4 v[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        v[j] = hacc[0][i + j];
+#pragma unroll
+                        for (int pr = 1; pr < NP; ++pr) v[j] += hacc[pr][i + j];
+                    }
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (the element goes through a scalar first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+                        const float t1 = v[1][e], t2 = v[2][e];
+                        const float u1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x104, 0xf, 0xf, true));   // row_shl:4
+                        const float u2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0x108, 0xf, 0xf, true));   // row_shl:8
+                        o[e] = (v[0][e] + u1) + u2;
+                    }
+                    sb2_out_row<OUT16, has_r>(a, so, ybase + i, o, radd[i % 3], s1, s2);       // (lanes of columns >= Cout are masked by so.ok)
+                } else if constexpr ((dbg & 8) != 0) {
+                    dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];                  // ablation: the MFMAs stay, the row is dropped
+                } else if constexpr (BST) {
+                    sb_out_tile_bst(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
+                } else {
+                    sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
+                }
             };
             // devtools bits 20-22 (value k = 1..3): the consumers drop the last k fragment families of every halo row -- their MFMAs AND their
             // LDS reads (k = 1: the ninth chain, 288 of 336 MFMAs left; 2: 216; 3: 144).  Results are wrong; the staging is unchanged.  It
@@ -834,7 +874,21 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     }
                     fetched = true;
                 };
-                if (!(dbg & 4) && f < NF_KEEP) {
+                if constexpr (HEAD) {
+                    // one MFMA per product: the columns (dy, co) of halo row r's accumulator take its contribution to output rows r, r-1, r-2
+                    static_for<NP>([&](auto PR) {
+                        constexpr int pr = decltype(PR)::value;
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[f][0]);
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[f][1]);
+                        const f32x4 c = f == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : hacc[pr][r];
+                        if constexpr (NP == 1) hacc[pr][r] = mm(ah, bh, c);
+                        else if constexpr (pr == 0) hacc[pr][r] = mm(al, bh, c);
+                        else if constexpr (pr == 1) hacc[pr][r] = mm(ah, bl, c);
+                        else hacc[pr][r] = mm(ah, bh, c);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!fetched) fetch();
+                    });
+                } else if (!(dbg & 4) && f < NF_KEEP) {
                     if constexpr (f < 4) {
                         // tiles r-2 (dy 2), r-1 (dy 1), r (dy 0); products lo*hi, hi*lo, hi*hi -- product-major, so MFMAs on one accumulator
                         // are three apart
@@ -951,13 +1005,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
 
 
 
-template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, bool ADD = false, int NP = 3>
+template <int TZ, int TY, bool IN16, bool OUT16, bool MULTI, bool BST = false, bool ADD = false, int NP = 3, bool HEAD = false>
 static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     using P = SB<TZ, TY>;
     static PerDevice attr_done;
     constexpr int LDS2 = 2 * P::LDS_BYTES + SB_STAT_LDS_FLOATS * 4;
     if (!attr_done.get()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv3_sb2)");
         attr_done.set();
     }
@@ -970,7 +1024,9 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.nblk == (int)grid.x && a.fin.N == a.N && a.fin.C == a.Cout && fin_tail_lds_bytes(a.fin) <= (size_t)LDS2),
                "conv3_sb2: tail descriptor does not match the launch");
     RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");
-    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP>), grid, dim3(512), LDS2, s, a, (const u32x4*)a.wfrag, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
+    // head form: its fragments sit behind the direct ones of the same weight (conv3_sb_frag_bytes_direct; channel counts below 32 have no Winograd-z form)
+    const u32x4* wfr = (const u32x4*)a.wfrag + (HEAD ? (size_t)cdiv(a.Cout, 16) * cdiv(a.Cin, 16) * SB_KSTEPS * 2 * 64 : 0);
+    hipLaunchKernelGGL((conv3_sb2_kernel<TZ, TY, IN16, OUT16, MULTI, BST, ADD, NP, HEAD>), grid, dim3(512), LDS2, s, a, wfr, ntz, nty, ntx, cdiv(a.Cin, 16), dbg);
     RU_CHECK_LAUNCH("conv3_sb2_kernel");
     return RU_OK;
 }
@@ -981,6 +1037,9 @@ static int sb2_cfg(const Conv3Args& a, hipStream_t s) {
         if (a.bst_y) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, true, false, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, true, false, NP>(a, s);
     }
     if (a.add) return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, true, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, true, NP>(a, s);
+    if constexpr (IN16 && !OUT16) {
+        if (sb_head_shape(a.Cin, a.Cout) && conv3_sb_head_form_enabled()) return sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, false, NP, true>(a, s);
+    }
     return a.Cin > 16 ? sb2_cfg_m<TZ, TY, IN16, OUT16, true, false, false, NP>(a, s) : sb2_cfg_m<TZ, TY, IN16, OUT16, false, false, false, NP>(a, s);
 }
 

@@ -158,6 +158,7 @@ int conv3_f32c_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
 int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s);
 // split-bf16 path (conv3_sb.hip)
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
+bool conv3_sb_head_form_enabled();                // RU_HEAD_FORM=0 keeps the <= 4-output-channel convolutions on the 16-column kernel (A/B runs, parity tests)
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);
 bool conv3_sb_wz_plain_dgrad();                   // RU_WZ=3: gradients entering such a data-gradient convolution are published as plain float32
 bool conv3_sb_wz_takes_split();                   // RU_WZ=2: split-form (data-gradient) inputs take the Winograd-z kernel as well                 // the launch takes the Winograd-z kernel (conv3_wz.hpp)

@@ -44,6 +44,38 @@ def test_conv3_layouts_equal_ncdhw(shape, in16, out16):
     assert float((y - exact).abs().max()) <= 2e-4 * float(exact.abs().max())
 
 
+HEAD_SHAPES = [(2, 3, 32, 32, 64), (1, 3, 128, 128, 128), (4, 4, 22, 36, 40), (2, 1, 17, 60, 72), (2, 2, 8, 128, 128)]
+
+
+@pytest.mark.parametrize("shape", HEAD_SHAPES, ids=["%dx16-%d_%dx%dx%d" % s for s in HEAD_SHAPES])
+def test_conv3_head_form_equals_the_sixteen_column_kernel_class(shape):
+    """The head convolution (model.py:348: 16 -> 3 channels, voxel-major in, NCDHW out) packs (row tap, output channel) pairs into the 16 matrix
+    columns (conv3_sb_common.hpp, sb_head_shape: 150 instead of 336 MFMAs per tile).  Same products, another summation order: held to a float64
+    convolution of the same operands within the bar of the 16-column kernel (RU_HEAD_FORM=0) on the same inputs, and the two must differ
+    (the shape really took the other kernel).  Shapes: full tiles, the 128^3 level, ragged extents on every face, 1 / 2 / 3 / 4 output channels."""
+    import os
+    from brats2019_amd import ops
+    n, cout, d, h, w = shape
+    x = _rand(n, 16, d, h, w, seed=21)
+    x = torch.where(x > 0, x, 0.01 * x) * 1.3 + 0.1
+    wt = _rand(cout, 16, 3, 3, 3, seed=22) * float((2.0 / (16 * 27)) ** 0.5)
+    b = _rand(cout, seed=23)
+    ref = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
+    scale = float(ref.abs().max())
+    res = {}
+    for tag, env in (("head", "1"), ("wide", "0")):
+        os.environ["RU_HEAD_FORM"] = env
+        try:
+            y = ops.conv3d_layout(ops.to_c16(x), wt, bias=b, in_c16=True, out_c16=False)
+        finally:
+            os.environ.pop("RU_HEAD_FORM", None)
+        res[tag] = (float((y.double().cpu() - ref).abs().max()) / scale, y)
+    print("  %s: max error / max |y|  head form %.2e  16-column kernel %.2e" % (shape, res["head"][0], res["wide"][0]))
+    assert not torch.equal(res["head"][1], res["wide"][1]), "the shape did not take the head-form kernel"
+    assert res["head"][0] <= 3e-5 and res["head"][0] <= 1.3 * res["wide"][0] + 1e-6, res
+    assert torch.equal(res["wide"][1], ops.conv3d(x, wt, b, precision="bf16x3"))
+
+
 WZ_SHAPES = [(2, 32, 32, 32, 32, 32), (1, 64, 64, 32, 32, 32), (1, 128, 128, 16, 32, 32), (2, 64, 64, 22, 20, 24), (3, 32, 64, 16, 24, 40), (1, 64, 32, 64, 28, 36)]
 
 
