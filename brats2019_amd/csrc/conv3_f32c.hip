@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                         // columns 4 dy + co hold them, four and eight lanes up (same 16-lane group: same four x positions)
                         f32x4 v = acc[i];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (v[r] + __shfl_down(acc[i + 1][r], 4)) + __shfl_down(acc[i + 2][r], 8);
+                        for (int r = 0; r < 4; ++r) v[r] = (v[r] + sb_row_shl<4>(acc[i + 1][r])) + sb_row_shl<8>(acc[i + 2][r]);
                         sb2_out_row<OUT16, false>(a, so, ybase + i, v, zero4, s1, s2);      // (lanes of columns >= Cout are masked by so.ok)
                     } else {
                         sb2_out_row<OUT16, false>(a, so, ybase + i, acc[i], zero4, s1, s2);

@@ -35,6 +35,12 @@ __host__ __device__ constexpr int sb_tap(int ks, int slot) {
 // HALO row r; an output row is the sum of three accumulators' column groups, taken across lanes in the epilogue.  K-step f (f < 4) holds chains 2f and
 // 2f+1 as in sb_tap; K-step 4 the ninth chain in slot 0 (slot 1 zero).  The fragments sit behind the direct (and Winograd-z) ones of the same weight.
 constexpr int SB_HEAD_KSTEPS = 5;
+// lane l takes the value of lane l + SH of its 16-lane row (zero past the row's end): a DPP row shift -- one VALU move, no LDS.  The value goes through a
+// scalar argument on purpose: __builtin_bit_cast applied to a vector ELEMENT (v[e]) reads element 0 whatever the index (hipcc 7.2).
+template <int SH>
+__device__ __forceinline__ float sb_row_shl(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + SH, 0xf, 0xf, true));
+}
 __host__ __device__ constexpr bool sb_head_shape(int Cin_conv, int Cout_conv) { return Cout_conv <= 4 && Cin_conv <= 16; }
 __host__ __device__ constexpr int sb_head_tap(int f, int slot, int dy) {
     if (dy > 2) return -1;
@@ -838,11 +844,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        // (the element goes through a scalar first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
-                        const float t1 = v[1][e], t2 = v[2][e];
-                        const float u1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x104, 0xf, 0xf, true));   // row_shl:4
-                        const float u2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0x108, 0xf, 0xf, true));   // row_shl:8
-                        o[e] = (v[0][e] + u1) + u2;
+                        o[e] = (v[0][e] + sb_row_shl<4>(v[1][e])) + sb_row_shl<8>(v[2][e]);
                     }
                     sb2_out_row<OUT16, has_r>(a, so, ybase + i, o, radd[i % 3], s1, s2);       // (lanes of columns >= Cout are masked by so.ok)
                 } else if constexpr ((dbg & 8) != 0) {
