@@ -187,7 +187,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         int st_n = 0, st_y0 = 0, st_x0 = 0;
         float4 sc4[2], sh4[2];
         unsigned mx = 0, md = 0, mx2 = 0;                // (mx2: XS == 2, validity of the second 4-channel group of this half)
-        int st_ring0 = 0, st_k = 0;                      // of the item whose loads are in the registers
+        // The x part and the dy part of an item are staged one after the other, and each part's loads for the NEXT item to be staged are issued as soon as
+        // its registers have been converted -- x loads fly while the dy part converts, dy loads while the next x part does: a head start of a whole item
+        // minus the part's own conversion, with ONE register set.  (All loads issued behind the whole conversion, as before, were needed right behind the
+        // next barrier: the staging waves -- the pole of the 16-channel kernels, ~160 MFMAs per item beside them -- sat out a memory round trip per item;
+        // profiles/r05_notes.txt, sections 6 and 10.)  State of the item whose x / dy loads are in the registers:
+        int stx_ring0 = 0, stx_k = 0, std_k = 0;
+        int nx_n = 0, nx_k = 0, nx_y0 = 0, nx_x0 = 0;    // the item issue_x was last called for: issue_d stages the same one
         // issue() is called for items 0, 1, 2, ... in order: (column, step) advance as counters and the column origin is recomputed
         // once per column, not with four integer divisions per item in this wave's VALU stream
         int is_k = 0, is_n = 0, is_y0 = 0, is_x0 = 0, is_ring0 = 0;
@@ -200,14 +206,20 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 for (int t = 0; t < 6; ++t) gc4[4 + t] = *reinterpret_cast<const float4*>(a.gb_coef + go * 3 + 4 * t);
             }
         };
-        auto issue = [&](int item) {
-            if (is_k == 0) item_origin(item, is_n, is_k, is_y0, is_x0, is_ring0);
-            const int n = is_n, k = is_k, y0 = is_y0, x0 = is_x0, ring0 = is_ring0;
-            if (++is_k == ntz) is_k = 0;
-            st_ring0 = ring0; st_k = k;
+        // (item >= nitems: the loads of the last item are issued once more and never staged -- no branch around a batch of loads, so the compiler's
+        // s_waitcnt vmcnt counts stay exact: with `if (w + 2 < nitems) issue(...)` the wait for the dy registers had to assume NO younger loads, i.e. vmcnt(0),
+        // and sat out the x loads issued a moment earlier)
+        auto issue_x = [&](int item) {
+            if (item < nitems) {
+                if (is_k == 0) item_origin(item, is_n, is_k, is_y0, is_x0, is_ring0);
+                nx_n = is_n; nx_k = is_k; nx_y0 = is_y0; nx_x0 = is_x0;
+                stx_ring0 = is_ring0; stx_k = is_k;
+                if (++is_k == ntz) is_k = 0;
+            }
+            const int n = nx_n, k = nx_k, y0 = nx_y0, x0 = nx_x0;
             const int hp0 = k == 0 ? 0 : 2 * k + 2, npl = k == 0 ? 4 : 2;       // new halo planes hp0 .. hp0 + npl - 1 (halo plane hp <-> z = hp - 1)
             const float* xb = a.x + ((size_t)(n * CBi + cgp) * DHW) * 16 + hsel * 8;
-            mx = 0; md = 0; mx2 = 0;
+            mx = 0; mx2 = 0;
             // rounds 0 .. NR2-1 cover the two planes every step loads; rounds NR2 .. NRX-1 only exist at the start of a column (four
             // planes): ONE wave-uniform branch around them, none inside the unrolled loops (a branch per round splits the load batch)
             auto xround = [&](auto R) {
@@ -245,6 +257,16 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             };
             wt_static_for<NR2>(xround);
             if (k == 0) wt_static_for<NRX - NR2>([&](auto R) { xround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
+            if (xform) {
+                const int cofs = n * a.Cin + cgp * 16 + hsel * 8;
+                sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
+                sh4[0] = *reinterpret_cast<const float4*>(a.in_shift + cofs); sh4[1] = *reinterpret_cast<const float4*>(a.in_shift + cofs + 4);
+            }
+        };
+        auto issue_d = [&]() {
+            const int n = nx_n, k = nx_k, y0 = nx_y0, x0 = nx_x0;
+            std_k = k;
+            md = 0;
 #pragma unroll
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
@@ -281,23 +303,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     vd[r][1] = *reinterpret_cast<const float4*>(db + ofs + 4);
                 }
             }
-            if (xform) {
-                const int cofs = n * a.Cin + cgp * 16 + hsel * 8;
-                sc4[0] = *reinterpret_cast<const float4*>(a.in_scale + cofs); sc4[1] = *reinterpret_cast<const float4*>(a.in_scale + cofs + 4);
-                sh4[0] = *reinterpret_cast<const float4*>(a.in_shift + cofs); sh4[1] = *reinterpret_cast<const float4*>(a.in_shift + cofs + 4);
-            }
             if constexpr (DS == 3) {
                 if constexpr (OT == 1) load_gc(n, 0);    // one output block: its constants travel with the loads (two blocks: fetched per block
                 st_n = n; st_y0 = y0; st_x0 = x0;        // in store(), 40 registers live instead of 80 held across the whole item)
             }
         };
-        auto store = [&](char* dbuf) {
+        auto store_x = [&]() {
             float sc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (xform) {
                 sc[0] = sc4[0].x; sc[1] = sc4[0].y; sc[2] = sc4[0].z; sc[3] = sc4[0].w; sc[4] = sc4[1].x; sc[5] = sc4[1].y; sc[6] = sc4[1].z; sc[7] = sc4[1].w;
                 sh[0] = sh4[0].x; sh[1] = sh4[0].y; sh[2] = sh4[0].z; sh[3] = sh4[0].w; sh[4] = sh4[1].x; sh[5] = sh4[1].y; sh[6] = sh4[1].z; sh[7] = sh4[1].w;
             }
-            const int hp0 = st_k == 0 ? 0 : 2 * st_k + 2, npl = st_k == 0 ? 4 : 2;
+            const int hp0 = stx_k == 0 ? 0 : 2 * stx_k + 2, npl = stx_k == 0 ? 4 : 2;
             auto xbody = [&](auto XFORM) {                // one wave-uniform dispatch, then a branch-free unrolled loop
                 constexpr bool XF = decltype(XFORM)::value;
             auto sround = [&](auto R) {
@@ -322,16 +339,18 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 u32x4 hi, lo;
                 if constexpr (NP == 3) wt_split8(t, hi, lo);
                 else wt_hi8(t, hi);                      // one product: only the hi image exists
-                const int slot = (st_ring0 + hp0 + pl) & (P::NSLOT - 1);
+                const int slot = (stx_ring0 + hp0 + pl) & (P::NSLOT - 1);
                 char* dst = lds + slot * P::PLANE + p * 32 + hsel * 16;
                 *reinterpret_cast<u32x4*>(dst + P::X_OFF) = hi;
                 if constexpr (NP == 3) *reinterpret_cast<u32x4*>(dst + P::XLO_OFF) = lo;
             };
             wt_static_for<NR2>(sround);
-            if (st_k == 0) wt_static_for<NRX - NR2>([&](auto R) { sround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
+            if (stx_k == 0) wt_static_for<NRX - NR2>([&](auto R) { sround(std::integral_constant<int, NR2 + decltype(R)::value>{}); });
             };
             if (xform) xbody(std::true_type{});
             else xbody(std::false_type{});
+        };
+        auto store_d = [&](char* dbuf) {
 #pragma unroll
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                 if constexpr (DS == 3) {                 // publish dy in split form (every position is staged once by input-channel group 0)
                     if (ok && cgp == 0 && a.gb_out) {    // (no output tensor: nobody but this weight gradient consumes the gradient, e.g. the stem)
                         const int row = p >> 4, z = row / TY;
-                        const size_t vox = (size_t)((2 * st_k + z) * H + st_y0 + (row - z * TY)) * W + st_x0 + (p & 15);
+                        const size_t vox = (size_t)((2 * std_k + z) * H + st_y0 + (row - z * TY)) * W + st_x0 + (p & 15);
                         u32x4* op = reinterpret_cast<u32x4*>(a.gb_out) + ((size_t)(st_n * CBo + og * OT + q) * DHW + vox) * 4;
                         op[hsel] = hi;
                         op[2 + hsel] = lo;
@@ -381,15 +400,20 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             }
         };
         if (nitems > 0) {
-            issue(0);
-            store(lds + P::D_OFF);
-            if (nitems > 1) issue(1);
+            issue_x(0);
+            issue_d();
+            store_x();
+            issue_x(1);
+            store_d(lds + P::D_OFF);
+            issue_d();
         }
         __syncthreads();
         for (int w = 0; w < nitems; ++w) {
             if (w + 1 < nitems) {
-                store(lds + P::D_OFF + ((w + 1) & 1) * P::DBUF);
-                if (w + 2 < nitems) issue(w + 2);
+                store_x();
+                issue_x(w + 2);
+                store_d(lds + P::D_OFF + ((w + 1) & 1) * P::DBUF);
+                issue_d();
             }
             __syncthreads();
         }
