@@ -613,20 +613,22 @@ __device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u3
     hfrag[((size_t)f * 2 + 0) * 64 + lane] = hi;
     hfrag[((size_t)f * 2 + 1) * 64 + lane] = lo;
 }
-// Every weight is packed in BOTH forms where the channel counts allow the Winograd-z kernel (conv3_wz.hpp): the direct fragments, and right behind
-// them (conv3_sb_frag_bytes_direct) the transformed ones -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
-// every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones.
+// Every weight is packed in ALL forms where the channel counts allow the Winograd-z kernels (conv3_wz.hpp, conv3_wz32.hpp): the direct fragments, and right
+// behind them (conv3_sb_frag_bytes_direct) the transformed ones of the 16x16x32 form, then (wz_frag_bytes further) those of the 32x32x16 form -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
+// every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones, [direct + wz, direct + wz + wz32) the 32x32x16 ones.
 __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int i) {
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
     if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
-    wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct);
+    const int wz = (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64;
+    if (i - direct < wz) { wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct); return; }
+    wz32_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct - wz);
 }
 static inline int sb_pack_threads(int cin_conv, int cout_conv) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0)
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (4 * 2 * WZ_KSTEPS + 4 * 9) * 64 : 0)
          + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0);
 }
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
@@ -663,7 +665,7 @@ size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv) {
     return (size_t)cdiv(Cout_conv, 16) * cdiv(Cin_conv, 16) * SB_KSTEPS * 2 * 64 * 16;
 }
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments | <= 4 couts: the head form) behind them
-    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv)
+    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv) + wz32_frag_bytes(Cin_conv, Cout_conv)
          + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0);
 }
 bool conv3_sb_head_form_enabled() {

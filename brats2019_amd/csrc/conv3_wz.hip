@@ -27,6 +27,8 @@ int conv3_wz_launch(const Conv3Args& a, const void* wzfrag, hipStream_t s) {
     RU_REQUIRE(a.N <= 32 || !a.stat_partials, "conv3_wz: at most 32 samples per call when statistics are requested");
     RU_REQUIRE(!a.in_s16 || !a.in_scale, "conv3_wz: a split-form input has no fused transform");
     RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials), "conv3_wz: fused GroupNorm-backward statistics need the coefficients and a partial buffer");
+    if (!a.bst_y && !a.add && conv3_wz32_enabled())      // the forward form: matrix waves on 32x32x16 MFMAs (conv3_wz32.hpp), fragments behind these
+        return conv3_wz32_launch(a, static_cast<const char*>(wzfrag) + wz_frag_bytes(a.Cin, a.Cout), s);
     if (a.bst_y) return a.add ? wz_cfg<true, true>(a, wzfrag, s) : wz_cfg<true, false>(a, wzfrag, s);
     return a.add ? wz_cfg<false, true>(a, wzfrag, s) : wz_cfg<false, false>(a, wzfrag, s);
 }

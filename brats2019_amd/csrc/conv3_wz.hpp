@@ -34,6 +34,240 @@ namespace ru {
 // devtools bit 128: consumer wave 0 of every workgroup adds s_memtime section sums here (cycles): [0] item setup, [1] rows 0-4, [2] rows 5-9 + row 7's
 // scratch write, [3] barrier, [4] items, [5] tail after the loop, [6] workgroups, [7] staging wave 0: cycles from item barrier to item barrier spent in store + issue
 static __device__ unsigned long long wz_prof[8];
+// The staging waves (waves 4..7 of a workgroup) of both Winograd-z kernels (conv3_wz_kernel here, conv3_wz32_kernel in conv3_wz32.hpp): the transformed,
+// split image of item w+1 is written while the matrix waves work on item w; one __syncthreads per item, two closing ones.  `pad_lds`: 1 KB of LDS
+// nobody reads (landing zone of the operand-row prefetch of the BST / ADD variants).
+template <bool BST, bool ADD, int dbg>
+__device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, float* pad_lds, int rw, int lane, int cog32, int swz, int G, int nitems, int nchunk,
+                                               int tiles_per_sample, int nty, int ntx) {
+    constexpr int HX = WZ_HX, HVOLP = WZ_HVOLP, BUF = WZ_BUF;
+    const int D = a.D, H = a.H, W = a.W;
+    const size_t DHW = (size_t)D * H * W;
+    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+        int b = tile;
+        n = b / tiles_per_sample;
+        b -= n * tiles_per_sample;
+        const int tx = b % ntx; b /= ntx;
+        const int ty = b % nty;
+        const int tz = b / nty;
+        z0 = tz * 2; y0 = ty * 8; x0 = tx * 16;
+    };
+    // ---------------------------------------------------------------- producers
+    const bool xform = a.in_scale != nullptr;
+    const bool s16 = a.in_s16 != 0;
+    const float slope = xform ? a.in_slope : 1.f;
+    // lane = (position within a block of 16, channel quad): the four lanes of a position load its 64 bytes as ONE contiguous line piece
+    // (a first version gave a lane pair half a voxel and two wave-rounds per block: every load touched 32 lines and used half of each,
+    // and the staging ran at the speed of the L1 / address pipeline -- 7 900 cycles per item against the consumers' 6 500, tools/wz_sections.py)
+    const int quad = lane & 3, q0 = quad & 1, hf = quad >> 1;
+    int dlt[3], pyx[3], ppos[3];
+    bool pin[3];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const int pb = rd * 4 + rw;                                  // 12 wave-rounds = 12 blocks of 16 halo positions (180 of 192 slots used)
+        const int p = pb * 16 + (lane >> 2);
+        const int hy = p / HX, xc = p - hy * HX;
+        pin[rd] = p < WZ_PLANE;
+        ppos[rd] = p;
+        pyx[rd] = hy | (xc << 8);
+        dlt[rd] = (hy * W + xc) * 64 + (s16 ? hf * 16 + q0 * 8 : quad * 16);
+    }
+    // TWO register sets of loads in flight: the loads of item w+3 are issued when item w+1 has been converted, and consumed two item
+    // barriers later.  With one set (issue(w+2) right before the barrier, store(w+2) right behind it) the staging waves -- the pole of this
+    // kernel: ~400 VALU instructions per item beside a wave that issues 240 MFMAs -- sat out a full L2 / HBM round trip every item.
+    float4 vv[2][3][4];
+    float4 sc4s[2][3], sh4s[2][3];
+    unsigned okmasks[2] = {0u, 0u};                                  // bit rd: (y, x) of this lane's position is inside the volume
+    bool zok0s[2] = {true, true}, zok3s[2] = {true, true};           // planes z0-1 / z0+2 inside the volume (wave-uniform)
+    auto issue = [&](auto SET, int item) {
+        constexpr int set = decltype(SET)::value;
+        auto& v = vv[set];
+        auto& sc4 = sc4s[set];
+        auto& sh4 = sh4s[set];
+        unsigned& okmask = okmasks[set];
+        bool& zok0 = zok0s[set];
+        bool& zok3 = zok3s[set];
+        if constexpr ((dbg & 2) != 0) return;
+        const int step = item / nchunk, chunk = item - step * nchunk;
+        int n, z0, y0, x0;
+        tile_origin(swz + step * G, n, z0, y0, x0);
+        const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
+        const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
+        const int base = ((zm1 * H + ym1) * W + xm1) * 64;
+        const int pstride = H * W * 64;
+        zok0 = zm1 >= 0; zok3 = z0 + 2 < D;
+        okmask = 0;
+        static_for<3>([&](auto R) __attribute__((always_inline)) {
+            constexpr int rd = decltype(R)::value;
+            const int gy = ym1 + (pyx[rd] & 0xff), gx = xm1 + (pyx[rd] >> 8);
+            const bool ok = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & pin[rd];
+            okmask |= ok ? (1u << rd) : 0u;
+            static_for<4>([&](auto PZ) __attribute__((always_inline)) {
+                constexpr int pz = decltype(PZ)::value;
+                const bool okz = ok & ((unsigned)(zm1 + pz) < (unsigned)D);
+                const unsigned ofs = okz ? (unsigned)(base + dlt[rd] + pz * pstride) : 0x80000000u;
+                if (s16) {                                           // hi dwords at +0, lo dwords at +32 (gn_bwd_apply16's packet layout)
+                    // four dword loads: __builtin_amdgcn_raw_buffer_load_b64 compiles to ONE buffer_load_dword on this toolchain (ROCm 7.2
+                    // hipcc: the second element is never loaded) -- found by tests/test_hip_c16.py::test_conv3_split_form_input
+                    v[rd][pz] = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 0, 0)),
+                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 4, 0)),
+                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 32, 0)),
+                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 36, 0)));
+                } else {
+                    v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
+                }
+            });
+            if (xform) {
+                const int cofs = n * a.Cin + chunk * 16 + quad * 4;
+                sc4[rd] = *reinterpret_cast<const float4*>(a.in_scale + cofs);
+                sh4[rd] = *reinterpret_cast<const float4*>(a.in_shift + cofs);
+            }
+        });
+    };
+    auto store = [&](auto SET, u32x4* buf) {
+        constexpr int set = decltype(SET)::value;
+        auto& v = vv[set];
+        auto& sc4 = sc4s[set];
+        auto& sh4 = sh4s[set];
+        const unsigned okmask = okmasks[set];
+        const bool zok0 = zok0s[set], zok3 = zok3s[set];
+        if constexpr ((dbg & 1) != 0) {
+            if constexpr ((dbg & 2) == 0) {
+                float acc0 = 0.f;
+#pragma unroll
+                for (int rd = 0; rd < 3; ++rd)
+#pragma unroll
+                    for (int pz = 0; pz < 4; ++pz) acc0 += v[rd][pz].x;
+                if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u};
+            }
+            return;
+        }
+        uint2* b2 = reinterpret_cast<uint2*>(buf);
+        const float mz0 = zok0 ? 1.f : 0.f, mz3 = zok3 ? 1.f : 0.f;
+        auto body = [&](auto MODE) __attribute__((always_inline)) {
+            constexpr int mode = decltype(MODE)::value;                      // 0 plain fp32, 1 fused affine + LeakyReLU, 2 split form
+#pragma unroll
+            for (int rd = 0; rd < 3; ++rd) {
+                if (!pin[rd]) continue;
+                const int o = (hf * HVOLP + ppos[rd]) * 2 + q0;             // uint2 index of transformed plane 0, hi; lo: + 2*HVOLP*2
+                float d[4][4];
+                if constexpr (mode == 1) {
+                    if (!((okmask >> rd) & 1u)) {                            // outside the volume in (y, x): the ACTIVATED tensor is zero-padded
+                        const uint2 z = make_uint2(0u, 0u);
+#pragma unroll
+                        for (int xi = 0; xi < 4; ++xi) { b2[o + xi * WZ_PLANE * 2] = z; b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = z; }
+                        continue;
+                    }
+                    const float s[4] = {sc4[rd].x, sc4[rd].y, sc4[rd].z, sc4[rd].w}, t[4] = {sh4[rd].x, sh4[rd].y, sh4[rd].z, sh4[rd].w};
+#pragma unroll
+                    for (int pz = 0; pz < 4; ++pz) {
+                        const float f[4] = {v[rd][pz].x, v[rd][pz].y, v[rd][pz].z, v[rd][pz].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            // planes 0 / 3 outside the volume (wave-uniform): scale and shift become zero, so does the activated value
+                            const float sc = pz == 0 ? s[c] * mz0 : (pz == 3 ? s[c] * mz3 : s[c]);
+                            const float sh = pz == 0 ? t[c] * mz0 : (pz == 3 ? t[c] * mz3 : t[c]);
+                            const float u = fmaf(f[c], sc, sh);
+                            d[pz][c] = fmaxf(u, u * slope);
+                        }
+                    }
+                } else if constexpr (mode == 2) {
+#pragma unroll
+                    for (int pz = 0; pz < 4; ++pz) {
+                        const unsigned h0 = __builtin_bit_cast(unsigned, v[rd][pz].x), h1 = __builtin_bit_cast(unsigned, v[rd][pz].y);
+                        const unsigned l0 = __builtin_bit_cast(unsigned, v[rd][pz].z), l1 = __builtin_bit_cast(unsigned, v[rd][pz].w);
+                        d[pz][0] = __builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16);
+                        d[pz][1] = __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u);
+                        d[pz][2] = __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16);
+                        d[pz][3] = __builtin_bit_cast(float, h1 & 0xffff0000u) + __builtin_bit_cast(float, l1 & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int pz = 0; pz < 4; ++pz) { d[pz][0] = v[rd][pz].x; d[pz][1] = v[rd][pz].y; d[pz][2] = v[rd][pz].z; d[pz][3] = v[rd][pz].w; }
+                }
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    float u[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        u[c] = xi == 0 ? d[0][c] - d[2][c] : (xi == 1 ? d[1][c] + d[2][c] : (xi == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c]));
+                    uint2 hi, lo;
+                    split_pair(u[0], u[1], hi.x, lo.x);
+                    split_pair(u[2], u[3], hi.y, lo.y);
+                    b2[o + xi * WZ_PLANE * 2] = hi;
+                    b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = lo;
+                }
+            }
+        };
+        if (s16) body(std::integral_constant<int, 2>{});
+        else if (xform) body(std::integral_constant<int, 1>{});
+        else body(std::integral_constant<int, 0>{});
+    };
+    // Row operands of the epilogue (BST: the forward tensor y; ADD: the residual): the combining waves read them one fragment step ahead of their
+    // use, which hides an L1 / L2 hit but not a trip to HBM -- loaded cold they cost 28-40 us per launch (tools: devtools bit 512).  The staging
+    // waves therefore TOUCH the 32 operand rows of a tile one item before it is combined: LDS-DMA loads (no VGPRs, never dead-code) of one row
+    // (16 voxels x 64 bytes of a 16-channel block = 1 KB = one wave-wide 16-byte load) each, landing in a 1 KB pad nobody reads.
+    auto prefetch_rows = [&](int item) {
+        if constexpr (BST || ADD) {
+            if constexpr ((dbg & 1024) != 0) return;
+            const int step = item / nchunk;
+            int n, z0, y0, x0;
+            tile_origin(swz + step * G, n, z0, y0, x0);
+            auto pad = (__attribute__((address_space(3))) void*)(pad_lds);
+            const int xv = x0 + (lane >> 2);                         // this lane's voxel of the row
+            static_for<(BST ? 1 : 0) + (ADD ? 1 : 0)>([&](auto T) __attribute__((always_inline)) {
+                const float* base = (BST && decltype(T)::value == 0) ? a.bst_y : a.add;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float* blk = base + ((size_t)(n * (a.Cout >> 4) + cog32 * 2 + g) * DHW) * 16;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blk), 0, (int)(DHW * 64), 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {                    // 16 (plane, row) pairs of this group: four per staging wave
+                        const int pr = rw * 4 + q, pzz = pr >> 3, yy = y0 + (pr & 7);
+                        const bool ok = (yy < H) & (xv < W);
+                        const unsigned ofs = ok ? (unsigned)((((z0 + pzz) * H + yy) * W + x0) * 64 + lane * 16) : 0x80000000u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, pad, 16, ofs, 0, 0, 0);
+                    }
+                }
+            });
+        }
+    };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    if (nitems > 0) issue(S0, 0);
+    if (nitems > 1) issue(S1, 1);
+    if (nitems > 0) {
+        store(S0, lds);
+        if (nitems > 2) issue(S0, 2);
+    }
+    __syncthreads();
+    unsigned long long ppt = 0;
+    for (int w = 0; w < nitems; w += 2) {            // item w+1 lives in set 1, item w+2 in set 0
+        unsigned long long t0 = 0;
+        if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
+        if (w % nchunk == nchunk - 1) prefetch_rows(w);      // (the consumers are on item w: its tile is combined during item w+1)
+        if (w + 1 < nitems) {
+            store(S1, lds + BUF);
+            if (w + 3 < nitems) issue(S1, w + 3);
+        }
+        if constexpr ((dbg & 128) != 0) ppt += __builtin_readcyclecounter() - t0;
+        __syncthreads();
+        if (w + 1 >= nitems) break;
+        if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
+        if ((w + 1) % nchunk == nchunk - 1) prefetch_rows(w + 1);
+        if (w + 2 < nitems) {
+            store(S0, lds);
+            if (w + 4 < nitems) issue(S0, w + 4);
+        }
+        if constexpr ((dbg & 128) != 0) ppt += __builtin_readcyclecounter() - t0;
+        __syncthreads();
+    }
+    if constexpr ((dbg & 128) != 0) { if (rw == 0 && lane == 0) atomicAdd(&wz_prof[7], ppt); }
+    __syncthreads();                                 // closing barriers of the consumers: the last tile's combine, the last statistics flush
+    __syncthreads();
+}
+
 template <bool BST, bool ADD>
 __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx, int nchunk) {
     constexpr int HY = WZ_HY, HX = WZ_HX, HVOLP = WZ_HVOLP, BUF = WZ_BUF, MT = 8;
@@ -54,239 +288,16 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
     const bool producer = wave >= 4;
     const int rw = wave & 3;
     const int cog32 = blockIdx.y;
-    const int D = a.D, H = a.H, W = a.W;
-    const size_t DHW = (size_t)D * H * W;
+    const int H = a.H;
     const int tiles_per_sample = ntz * nty * ntx;
     const int ntile = a.N * tiles_per_sample;
     const int G = gridDim.x;
     const int swz = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;      // XCD-compact tile order (conv3_sb2_kernel)
     const int nsteps = swz < ntile ? (ntile - swz + G - 1) / G : 0;
     const int nitems = nsteps * nchunk;
-    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-        int b = tile;
-        n = b / tiles_per_sample;
-        b -= n * tiles_per_sample;
-        const int tx = b % ntx; b /= ntx;
-        const int ty = b % nty;
-        const int tz = b / nty;
-        z0 = tz * 2; y0 = ty * 8; x0 = tx * 16;
-    };
 
     if (producer) {
-        // ---------------------------------------------------------------- producers
-        const bool xform = a.in_scale != nullptr;
-        const bool s16 = a.in_s16 != 0;
-        const float slope = xform ? a.in_slope : 1.f;
-        // lane = (position within a block of 16, channel quad): the four lanes of a position load its 64 bytes as ONE contiguous line piece
-        // (a first version gave a lane pair half a voxel and two wave-rounds per block: every load touched 32 lines and used half of each,
-        // and the staging ran at the speed of the L1 / address pipeline -- 7 900 cycles per item against the consumers' 6 500, tools/wz_sections.py)
-        const int quad = lane & 3, q0 = quad & 1, hf = quad >> 1;
-        int dlt[3], pyx[3], ppos[3];
-        bool pin[3];
-#pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-            const int pb = rd * 4 + rw;                                  // 12 wave-rounds = 12 blocks of 16 halo positions (180 of 192 slots used)
-            const int p = pb * 16 + (lane >> 2);
-            const int hy = p / HX, xc = p - hy * HX;
-            pin[rd] = p < WZ_PLANE;
-            ppos[rd] = p;
-            pyx[rd] = hy | (xc << 8);
-            dlt[rd] = (hy * W + xc) * 64 + (s16 ? hf * 16 + q0 * 8 : quad * 16);
-        }
-        // TWO register sets of loads in flight: the loads of item w+3 are issued when item w+1 has been converted, and consumed two item
-        // barriers later.  With one set (issue(w+2) right before the barrier, store(w+2) right behind it) the staging waves -- the pole of this
-        // kernel: ~400 VALU instructions per item beside a wave that issues 240 MFMAs -- sat out a full L2 / HBM round trip every item.
-        float4 vv[2][3][4];
-        float4 sc4s[2][3], sh4s[2][3];
-        unsigned okmasks[2] = {0u, 0u};                                  // bit rd: (y, x) of this lane's position is inside the volume
-        bool zok0s[2] = {true, true}, zok3s[2] = {true, true};           // planes z0-1 / z0+2 inside the volume (wave-uniform)
-        auto issue = [&](auto SET, int item) {
-            constexpr int set = decltype(SET)::value;
-            auto& v = vv[set];
-            auto& sc4 = sc4s[set];
-            auto& sh4 = sh4s[set];
-            unsigned& okmask = okmasks[set];
-            bool& zok0 = zok0s[set];
-            bool& zok3 = zok3s[set];
-            if constexpr ((dbg & 2) != 0) return;
-            const int step = item / nchunk, chunk = item - step * nchunk;
-            int n, z0, y0, x0;
-            tile_origin(swz + step * G, n, z0, y0, x0);
-            const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
-            const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
-            const int base = ((zm1 * H + ym1) * W + xm1) * 64;
-            const int pstride = H * W * 64;
-            zok0 = zm1 >= 0; zok3 = z0 + 2 < D;
-            okmask = 0;
-            static_for<3>([&](auto R) __attribute__((always_inline)) {
-                constexpr int rd = decltype(R)::value;
-                const int gy = ym1 + (pyx[rd] & 0xff), gx = xm1 + (pyx[rd] >> 8);
-                const bool ok = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & pin[rd];
-                okmask |= ok ? (1u << rd) : 0u;
-                static_for<4>([&](auto PZ) __attribute__((always_inline)) {
-                    constexpr int pz = decltype(PZ)::value;
-                    const bool okz = ok & ((unsigned)(zm1 + pz) < (unsigned)D);
-                    const unsigned ofs = okz ? (unsigned)(base + dlt[rd] + pz * pstride) : 0x80000000u;
-                    if (s16) {                                           // hi dwords at +0, lo dwords at +32 (gn_bwd_apply16's packet layout)
-                        // four dword loads: __builtin_amdgcn_raw_buffer_load_b64 compiles to ONE buffer_load_dword on this toolchain (ROCm 7.2
-                        // hipcc: the second element is never loaded) -- found by tests/test_hip_c16.py::test_conv3_split_form_input
-                        v[rd][pz] = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 0, 0)),
-                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 4, 0)),
-                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 32, 0)),
-                                                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 36, 0)));
-                    } else {
-                        v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
-                    }
-                });
-                if (xform) {
-                    const int cofs = n * a.Cin + chunk * 16 + quad * 4;
-                    sc4[rd] = *reinterpret_cast<const float4*>(a.in_scale + cofs);
-                    sh4[rd] = *reinterpret_cast<const float4*>(a.in_shift + cofs);
-                }
-            });
-        };
-        auto store = [&](auto SET, u32x4* buf) {
-            constexpr int set = decltype(SET)::value;
-            auto& v = vv[set];
-            auto& sc4 = sc4s[set];
-            auto& sh4 = sh4s[set];
-            const unsigned okmask = okmasks[set];
-            const bool zok0 = zok0s[set], zok3 = zok3s[set];
-            if constexpr ((dbg & 1) != 0) {
-                if constexpr ((dbg & 2) == 0) {
-                    float acc0 = 0.f;
-#pragma unroll
-                    for (int rd = 0; rd < 3; ++rd)
-#pragma unroll
-                        for (int pz = 0; pz < 4; ++pz) acc0 += v[rd][pz].x;
-                    if (acc0 == 12345.678f) buf[0] = u32x4{1u, 2u, 3u, 4u};
-                }
-                return;
-            }
-            uint2* b2 = reinterpret_cast<uint2*>(buf);
-            const float mz0 = zok0 ? 1.f : 0.f, mz3 = zok3 ? 1.f : 0.f;
-            auto body = [&](auto MODE) __attribute__((always_inline)) {
-                constexpr int mode = decltype(MODE)::value;                      // 0 plain fp32, 1 fused affine + LeakyReLU, 2 split form
-#pragma unroll
-                for (int rd = 0; rd < 3; ++rd) {
-                    if (!pin[rd]) continue;
-                    const int o = (hf * HVOLP + ppos[rd]) * 2 + q0;             // uint2 index of transformed plane 0, hi; lo: + 2*HVOLP*2
-                    float d[4][4];
-                    if constexpr (mode == 1) {
-                        if (!((okmask >> rd) & 1u)) {                            // outside the volume in (y, x): the ACTIVATED tensor is zero-padded
-                            const uint2 z = make_uint2(0u, 0u);
-#pragma unroll
-                            for (int xi = 0; xi < 4; ++xi) { b2[o + xi * WZ_PLANE * 2] = z; b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = z; }
-                            continue;
-                        }
-                        const float s[4] = {sc4[rd].x, sc4[rd].y, sc4[rd].z, sc4[rd].w}, t[4] = {sh4[rd].x, sh4[rd].y, sh4[rd].z, sh4[rd].w};
-#pragma unroll
-                        for (int pz = 0; pz < 4; ++pz) {
-                            const float f[4] = {v[rd][pz].x, v[rd][pz].y, v[rd][pz].z, v[rd][pz].w};
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                // planes 0 / 3 outside the volume (wave-uniform): scale and shift become zero, so does the activated value
-                                const float sc = pz == 0 ? s[c] * mz0 : (pz == 3 ? s[c] * mz3 : s[c]);
-                                const float sh = pz == 0 ? t[c] * mz0 : (pz == 3 ? t[c] * mz3 : t[c]);
-                                const float u = fmaf(f[c], sc, sh);
-                                d[pz][c] = fmaxf(u, u * slope);
-                            }
-                        }
-                    } else if constexpr (mode == 2) {
-#pragma unroll
-                        for (int pz = 0; pz < 4; ++pz) {
-                            const unsigned h0 = __builtin_bit_cast(unsigned, v[rd][pz].x), h1 = __builtin_bit_cast(unsigned, v[rd][pz].y);
-                            const unsigned l0 = __builtin_bit_cast(unsigned, v[rd][pz].z), l1 = __builtin_bit_cast(unsigned, v[rd][pz].w);
-                            d[pz][0] = __builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16);
-                            d[pz][1] = __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u);
-                            d[pz][2] = __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16);
-                            d[pz][3] = __builtin_bit_cast(float, h1 & 0xffff0000u) + __builtin_bit_cast(float, l1 & 0xffff0000u);
-                        }
-                    } else {
-#pragma unroll
-                        for (int pz = 0; pz < 4; ++pz) { d[pz][0] = v[rd][pz].x; d[pz][1] = v[rd][pz].y; d[pz][2] = v[rd][pz].z; d[pz][3] = v[rd][pz].w; }
-                    }
-#pragma unroll
-                    for (int xi = 0; xi < 4; ++xi) {
-                        float u[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            u[c] = xi == 0 ? d[0][c] - d[2][c] : (xi == 1 ? d[1][c] + d[2][c] : (xi == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c]));
-                        uint2 hi, lo;
-                        split_pair(u[0], u[1], hi.x, lo.x);
-                        split_pair(u[2], u[3], hi.y, lo.y);
-                        b2[o + xi * WZ_PLANE * 2] = hi;
-                        b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = lo;
-                    }
-                }
-            };
-            if (s16) body(std::integral_constant<int, 2>{});
-            else if (xform) body(std::integral_constant<int, 1>{});
-            else body(std::integral_constant<int, 0>{});
-        };
-        // Row operands of the epilogue (BST: the forward tensor y; ADD: the residual): the combining waves read them one fragment step ahead of their
-        // use, which hides an L1 / L2 hit but not a trip to HBM -- loaded cold they cost 28-40 us per launch (tools: devtools bit 512).  The staging
-        // waves therefore TOUCH the 32 operand rows of a tile one item before it is combined: LDS-DMA loads (no VGPRs, never dead-code) of one row
-        // (16 voxels x 64 bytes of a 16-channel block = 1 KB = one wave-wide 16-byte load) each, landing in a 1 KB pad nobody reads.
-        auto prefetch_rows = [&](int item) {
-            if constexpr (BST || ADD) {
-                if constexpr ((dbg & 1024) != 0) return;
-                const int step = item / nchunk;
-                int n, z0, y0, x0;
-                tile_origin(swz + step * G, n, z0, y0, x0);
-                auto pad = (__attribute__((address_space(3))) void*)(stat_lds + SB_STAT_LDS_FLOATS);
-                const int xv = x0 + (lane >> 2);                         // this lane's voxel of the row
-                static_for<(BST ? 1 : 0) + (ADD ? 1 : 0)>([&](auto T) __attribute__((always_inline)) {
-                    const float* base = (BST && decltype(T)::value == 0) ? a.bst_y : a.add;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const float* blk = base + ((size_t)(n * (a.Cout >> 4) + cog32 * 2 + g) * DHW) * 16;
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blk), 0, (int)(DHW * 64), 0x00020000);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {                    // 16 (plane, row) pairs of this group: four per staging wave
-                            const int pr = rw * 4 + q, pzz = pr >> 3, yy = y0 + (pr & 7);
-                            const bool ok = (yy < H) & (xv < W);
-                            const unsigned ofs = ok ? (unsigned)((((z0 + pzz) * H + yy) * W + x0) * 64 + lane * 16) : 0x80000000u;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, pad, 16, ofs, 0, 0, 0);
-                        }
-                    }
-                });
-            }
-        };
-        constexpr std::integral_constant<int, 0> S0{};
-        constexpr std::integral_constant<int, 1> S1{};
-        if (nitems > 0) issue(S0, 0);
-        if (nitems > 1) issue(S1, 1);
-        if (nitems > 0) {
-            store(S0, lds);
-            if (nitems > 2) issue(S0, 2);
-        }
-        __syncthreads();
-        unsigned long long ppt = 0;
-        for (int w = 0; w < nitems; w += 2) {            // item w+1 lives in set 1, item w+2 in set 0
-            unsigned long long t0 = 0;
-            if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
-            if (w % nchunk == nchunk - 1) prefetch_rows(w);      // (the consumers are on item w: its tile is combined during item w+1)
-            if (w + 1 < nitems) {
-                store(S1, lds + BUF);
-                if (w + 3 < nitems) issue(S1, w + 3);
-            }
-            if constexpr ((dbg & 128) != 0) ppt += __builtin_readcyclecounter() - t0;
-            __syncthreads();
-            if (w + 1 >= nitems) break;
-            if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
-            if ((w + 1) % nchunk == nchunk - 1) prefetch_rows(w + 1);
-            if (w + 2 < nitems) {
-                store(S0, lds);
-                if (w + 4 < nitems) issue(S0, w + 4);
-            }
-            if constexpr ((dbg & 128) != 0) ppt += __builtin_readcyclecounter() - t0;
-            __syncthreads();
-        }
-        if constexpr ((dbg & 128) != 0) { if (rw == 0 && lane == 0) atomicAdd(&wz_prof[7], ppt); }
-        __syncthreads();                                 // closing barriers of the consumers: the last tile's combine, the last statistics flush
-        __syncthreads();
+        wz_stage_waves<BST, ADD, dbg>(a, lds, stat_lds + SB_STAT_LDS_FLOATS, rw, lane, cog32, swz, G, nitems, nchunk, tiles_per_sample, nty, ntx);
     } else {
         // ---------------------------------------------------------------- consumers
         const int xi = rw;

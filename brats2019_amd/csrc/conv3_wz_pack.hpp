@@ -67,6 +67,42 @@ __device__ __forceinline__ void wz_pack_one(const float* __restrict__ w, wz_u32x
     wzfrag[(unit + 1) * 64 + lane] = lo;
 }
 
+// ---- the 32x32x16 form of the matrix waves (conv3_wz32.hpp): one K-step per tap, 32 output channels per fragment row
+constexpr int WZ32_UNITS = 4 * 9 * 2;                    // 16-byte x 64-lane fragment units per (32-cout block, 16-cin chunk): [xi][tap dy*3+dx][hi/lo]
+// thread i of ncog32 * nchunk * 4 * 9 * 64: unit u = (((cog32*nchunk + chunk)*4 + xi)*9 + tap)*2 + hl; lane l (row = l&31, K half kh = l>>5) holds,
+// for e = 0..7, G_xi[cout = cog32*32 + row][cin = chunk*16 + kh*8 + e][tap] (G_xi as in wz_pack_one)
+__device__ __forceinline__ void wz32_pack_one(const float* __restrict__ w, wz_u32x4* __restrict__ frag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog32, int i) {
+    const int total = ncog32 * nchunk * 4 * 9 * 64;
+    if (i >= total) return;
+    const int lane = i & 63;
+    int u = i >> 6;
+    const int tap2 = u % 9; u /= 9;
+    const int xi = u & 3; u >>= 2;
+    const int chunk = u % nchunk;
+    const int cog32 = u / nchunk;
+    const int co = cog32 * 32 + (lane & 31), kh = lane >> 5;
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = chunk * 16 + kh * 8 + e;
+        float gz[3];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int tap = dz * 9 + tap2;
+            gz[dz] = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+        }
+        t[e] = xi == 0 ? gz[0] : (xi == 3 ? gz[2] : (xi == 1 ? 0.5f * ((gz[0] + gz[2]) + gz[1]) : 0.5f * ((gz[0] + gz[2]) - gz[1])));
+    }
+    wz_u32x4 hi, lo;
+    split_n<4>(t, hi, lo);
+    const size_t unit = ((((size_t)(cog32 * nchunk + chunk) * 4 + xi) * 9 + tap2)) * 2;
+    frag[(unit + 0) * 64 + lane] = hi;
+    frag[(unit + 1) * 64 + lane] = lo;
+}
+static inline size_t wz32_frag_bytes(int Cin_conv, int Cout_conv) {
+    return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ32_UNITS * 64 * 16 : 0;
+}
+
 static inline size_t wz_frag_bytes(int Cin_conv, int Cout_conv) {
     return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ_UNITS * 64 * 16 : 0;
 }
@@ -88,5 +124,7 @@ static inline long wz_grid_x(int N, int Cout, int D, int H, int W) {
 }
 
 int conv3_wz_launch(const Conv3Args& a, const void* wzfrag, hipStream_t s);
+int conv3_wz32_launch(const Conv3Args& a, const void* wz32frag, hipStream_t s);      // conv3_wz32.hip: forward form only (no residual, no GroupNorm-backward sums)
+bool conv3_wz32_enabled();                               // RU_WZ32=0 keeps the 16x16x32 matrix form (same-box A/B)
 
 }  // namespace ru
