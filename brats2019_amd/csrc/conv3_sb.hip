@@ -616,36 +616,52 @@ __device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u3
 // Every weight is packed in ALL forms where the channel counts allow the Winograd-z kernels (conv3_wz.hpp, conv3_wz32.hpp): the direct fragments, and right
 // behind them (conv3_sb_frag_bytes_direct) the transformed ones of the 16x16x32 form, then (wz_frag_bytes further) those of the 32x32x16 form -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
 // every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones, [direct + wz, direct + wz + wz32) the 32x32x16 ones.
-__device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int i) {
+// forms: bit 0 = the 16x16x32 Winograd-z fragments, bit 1 = the 32x32x16 ones (SB_FORMS_ALL: op-level packs and inference, whose frozen packs must serve
+// every later launch; a training step repacks per forward and packs what that forward's launches take -- sb_pack_forms)
+constexpr int SB_FORMS_ALL = 3;
+__device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int forms, int i) {
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
     if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
-    const int wz = (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64;
-    if (i - direct < wz) { wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct); return; }
-    wz32_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, i - direct - wz);
+    const int wz = (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64;      // (the fragments keep their places whatever `forms` says: a skipped form leaves its bytes as they are)
+    int r = i - direct;
+    if (forms & 1) {
+        if (r < wz) { wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r); return; }
+        r -= wz;
+    }
+    if (forms & 2) wz32_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r);
 }
-static inline int sb_pack_threads(int cin_conv, int cout_conv) {
+static inline int sb_pack_threads(int cin_conv, int cout_conv, int forms) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (4 * 2 * WZ_KSTEPS + 4 * 9) * 64 : 0)
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((forms & 1) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0)) * 64 : 0)
          + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0);
 }
+// what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 switches
+// (conv3_sb_uses_wz, conv3_sb_wz_takes_split, conv3_sb_wz_plain_dgrad, conv3_wz32_enabled: read per call, as the launches read them)
+static int sb_pack_forms(int mode) {
+    const char* e = getenv("RU_WZ");
+    if (e && *e == '0') return 0;
+    const bool dgrad_wz = conv3_sb_wz_takes_split() || conv3_sb_wz_plain_dgrad();
+    if (mode == 1) return dgrad_wz ? SB_FORMS_ALL : 0;     // (a data-gradient launch without residual / GroupNorm-backward sums takes the forward form)
+    return conv3_wz32_enabled() ? 2 : 1;                    // forward launches have neither residual nor GroupNorm-backward sums: ONE form
+}
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
-    sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, blockIdx.x * blockDim.x + threadIdx.x);
+    sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, SB_FORMS_ALL, blockIdx.x * blockDim.x + threadIdx.x);
 }
 // all 3x3x3 weights of a network in ONE launch (blockIdx.y = entry): the ~50 pack launches of a training step were 4.5 us each,
 // almost all of it launch latency (5 % of a batch-1 forward)
 __global__ void conv3_sb_pack_batch_kernel(const SbPackBatch b) {
     const SbPackEntry& e = b.e[blockIdx.y];
-    sb_pack_both(e.w, reinterpret_cast<u32x4*>(e.wfrag), e.Cin_f, e.Cout_f, e.mode, e.nchunk, e.ncog, blockIdx.x * blockDim.x + threadIdx.x);
+    sb_pack_both(e.w, reinterpret_cast<u32x4*>(e.wfrag), e.Cin_f, e.Cout_f, e.mode, e.nchunk, e.ncog, e.forms, blockIdx.x * blockDim.x + threadIdx.x);
 }
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
     if (b.n == 0) return RU_OK;
     int maxtotal = 0;
     for (int i = 0; i < b.n; ++i) {
         const SbPackEntry& e = b.e[i];
-        const int t = sb_pack_threads(e.mode == 0 ? e.Cin_f : e.Cout_f, e.mode == 0 ? e.Cout_f : e.Cin_f);
+        const int t = sb_pack_threads(e.mode == 0 ? e.Cin_f : e.Cout_f, e.mode == 0 ? e.Cout_f : e.Cin_f, e.forms);
         if (t > maxtotal) maxtotal = t;
     }
     hipLaunchKernelGGL(conv3_sb_pack_batch_kernel, dim3(cdiv(maxtotal, 256), b.n), dim3(256), 0, s, b);
@@ -653,11 +669,12 @@ int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
     b.n = 0;
     return RU_OK;
 }
-int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
+int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s) {
     if (b.n == RU_PACK_BATCH) { const int rc = conv3_sb_pack_batch(b, s); if (rc) return rc; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     SbPackEntry& e = b.e[b.n++];
     e.w = w; e.wfrag = wfrag; e.Cin_f = Cin_f; e.Cout_f = Cout_f; e.mode = mode; e.nchunk = cdiv(cin_conv, 16); e.ncog = cdiv(cout_conv, 16);
+    e.forms = all_forms ? SB_FORMS_ALL : sb_pack_forms(mode);
     return RU_OK;
 }
 
@@ -676,7 +693,7 @@ bool conv3_sb_head_form_enabled() {
 int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    const int total = sb_pack_threads(cin_conv, cout_conv);
+    const int total = sb_pack_threads(cin_conv, cout_conv, SB_FORMS_ALL);
     hipLaunchKernelGGL(conv3_sb_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, (u32x4*)wfrag, Cin_f, Cout_f, mode, nchunk, ncog);
     RU_CHECK_LAUNCH("conv3_sb_pack_kernel");
     return RU_OK;

@@ -466,7 +466,7 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     batch.n = 0;
     // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments, all in one launch)
     auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
-        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
+        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, !h->training, s));
         // exact-f32 voxel-major inference: per-lane f32 fragments in the same slot (never larger than the split-bf16 ones)
         if (h->precision == RU_PREC_F32 && h->c16) RU_RUN(conv3_f32c_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
         // outside the voxel-major flow the f32 layout is always kept: ragged W falls back to the f32 kernel

@@ -171,9 +171,9 @@ bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W);           
 int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);   // mode 0 fwd, 1 data-gradient
 // the same for many weights in one launch: add entries, then flush (add flushes by itself when the table is full)
 constexpr int RU_PACK_BATCH = 64;
-struct SbPackEntry { const float* w; void* wfrag; int Cin_f, Cout_f, mode, nchunk, ncog; };
+struct SbPackEntry { const float* w; void* wfrag; int Cin_f, Cout_f, mode, nchunk, ncog, forms; };
 struct SbPackBatch { SbPackEntry e[RU_PACK_BATCH]; int n; };
-int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);
+int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s);   // all_forms false: only the Winograd-z forms a training step launches
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s);
 // pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:
 // the packed conv maps Cout_f input channels to Cin_f output channels).
