@@ -81,7 +81,7 @@ WZ_SHAPES = [(2, 32, 32, 32, 32, 32), (1, 64, 64, 32, 32, 32), (1, 128, 128, 16,
 
 @pytest.mark.parametrize("shape", WZ_SHAPES, ids=["%dx%d-%d_%dx%dx%d" % s for s in WZ_SHAPES])
 def test_conv3_winograd_z_against_float64(shape):
-    """conv3_wz_kernel (Winograd F(2,3) along z, (y, x) taps direct; the voxel-major 3x3x3 convolutions of the 32..128-channel levels:
+    """conv3_wz32_kernel / conv3_wz_kernel (Winograd F(2,3) along z, (y, x) taps direct; the voxel-major 3x3x3 convolutions of the 32..128-channel levels:
     model.py:72-73 as used by model.py:89-91) against a float64 convolution of the same fp32 operands: max error / output RMS within 6e-5
     (CPU emulation: 2.7e-5, the direct split-bf16 kernel 2.4e-5 -- profiles/r05_winograd_gate.txt), and within 1.5x of what the DIRECT kernel
     (RU_WZ=0) leaves on the same inputs.  Shapes: full tiles at the three deep levels, ragged extents (H, W not multiples of the tile,
@@ -95,16 +95,21 @@ def test_conv3_winograd_z_against_float64(shape):
     ref = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), padding=1)
     rms = float(ref.pow(2).mean().sqrt())
     res = {}
-    for tag, env in (("wz", "1"), ("direct", "0")):
+    # both matrix forms of the Winograd-z kernel: 32x32x16 MFMAs (conv3_wz32_kernel, the default of the forward form) and 16x16x32 (conv3_wz_kernel, RU_WZ32=0)
+    for tag, env, env32 in (("wz32", "1", "1"), ("wz", "1", "0"), ("direct", "0", "1")):
         os.environ["RU_WZ"] = env
+        os.environ["RU_WZ32"] = env32
         try:
             y = ops.from_c16(ops.conv3d_layout(ops.to_c16(x), wt, in_c16=True, out_c16=True))
         finally:
             os.environ.pop("RU_WZ", None)
+            os.environ.pop("RU_WZ32", None)
         res[tag] = (float((y.double().cpu() - ref).abs().max()) / rms, y)
-    print("  %s: max error / rms  winograd-z %.2e  direct %.2e" % (shape, res["wz"][0], res["direct"][0]))
-    assert not torch.equal(res["wz"][1], res["direct"][1]), "the shape did not take the Winograd-z kernel"
-    assert res["wz"][0] <= 6e-5 and res["wz"][0] <= 1.5 * res["direct"][0] + 1e-6, res
+    print("  %s: max error / rms  winograd-z 32x32x16 %.2e  16x16x32 %.2e  direct %.2e" % (shape, res["wz32"][0], res["wz"][0], res["direct"][0]))
+    assert not torch.equal(res["wz"][1], res["direct"][1]) and not torch.equal(res["wz32"][1], res["direct"][1]), "the shape did not take the Winograd-z kernel"
+    assert not torch.equal(res["wz32"][1], res["wz"][1]), "RU_WZ32 did not switch the matrix form"
+    for tag in ("wz32", "wz"):
+        assert res[tag][0] <= 6e-5 and res[tag][0] <= 1.5 * res["direct"][0] + 1e-6, (tag, res)
 
 
 @pytest.mark.parametrize("x16,dy16", [(True, True), (True, False), (False, True)])
