@@ -685,6 +685,15 @@ size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fra
     return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv) + wz32_frag_bytes(Cin_conv, Cout_conv)
          + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0);
 }
+// The inference head: the last Residual block's output x + lrelu(norm2(conv2)) (model.py:112-116) is formed in the head conv's staging instead of a pass of its
+// own (Conv3Args::in_res).  Exists in the head-form variant of the persistent kernel only: the same tests as conv3_sb_launch's way there.  RU_HEAD_RES=0: off (A/B).
+bool conv3_sb_head_takes_residual(int N, int Cin, int Cout, int D, int H, int W) {
+    const char* e = getenv("RU_HEAD_RES");
+    if (e && *e == '0') return false;
+    if (!conv3_sb_head_form_enabled() || !sb_head_shape(Cin, Cout) || Cin % 16 != 0 || (W & 3) != 0) return false;
+    if ((size_t)D * H * W * 64 >= ((size_t)1 << 31)) return false;
+    return sb_use_v2(sb_choose(N, Cout, D, H, W));
+}
 bool conv3_sb_head_form_enabled() {
     const char* e = getenv("RU_HEAD_FORM");
     return !(e && e[0] == '0');
@@ -777,6 +786,8 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     RU_REQUIRE(!a.bst_y || (a.bst_k && a.stat_partials && (a.in_c16 || a.in_c4) && a.out_c16 && !a.bias && !a.sigmoid && (!a.add || !a.in_c4) &&
                             conv3_sb_bst_usable(a.N, a.Cout, a.D, a.H, a.W)),
                "conv3_sb: fused GroupNorm-backward statistics need the persistent voxel-major kernel, a partial buffer and no bias / activation");
+    RU_REQUIRE(!a.in_res || (a.in_c16 && !a.out_c16 && !a.in_c4 && !a.add && a.in_scale && conv3_sb_head_takes_residual(a.N, a.Cin, a.Cout, a.D, a.H, a.W)),
+               "conv3_sb: a residual of the input is staged by the head-form kernel only (conv3_sb_head_takes_residual)");
     if (a.in_c4) {
         RU_REQUIRE(a.Cin <= 4 && !a.in_scale, "conv3_sb: the 4-channel kernel takes Cin <= 4 and no fused input transform");
         RU_REQUIRE(!a.out_c16 || a.Cout % 16 == 0, "conv3_sb: C16 output needs Cout %% 16 == 0");

@@ -467,6 +467,13 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         const int hsel = (ptid >> 3) & 1;
         const int pslot = (ptid >> 4) * 8 + (ptid & 7);
         float4 v16[NR][2];
+        // head form: the residual of the input (Conv3Args::in_res), same positions.  A RING of RD rounds, requested inside store() RD rounds ahead of their
+        // use: a full item of them in flight beside v16 (72 + 72 registers) spilled the staging waves (head conv 493 -> 890 us at 8 x 128^3)
+        constexpr int RD = 4;
+        float4 r16[HEAD ? RD : 1][2];
+        const bool res = HEAD && a.in_res != nullptr;
+        __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);      // of the item whose loads are in the registers
+        int res_base = 0;
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
         // Per thread and round the halo position p = r*128 + pslot is FIXED for the whole kernel: its coordinates (hz, hy, xc) and its byte
@@ -504,6 +511,12 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
             const int base = ((zm1 * H + ym1) * W + xm1) * 64;            // may be negative: only used where the position is inside
             vmask = 0;
+            if constexpr (HEAD) {
+                if (res) {
+                    res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_res + ((size_t)(n * nchunk + chunk) * DHW) * 16), 0, (int)(DHW * 64), 0x00020000);
+                    res_base = base;
+                }
+            }
             st_chain = zwalk && !MULTI && !(dbg & 512) && CR > 0 && (step % ntz) != 0;
             auto ld_round = [&](auto R) __attribute__((always_inline)) {
                 constexpr int r = decltype(R)::value;
@@ -559,10 +572,22 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             // ONE wave-uniform dispatch per item, then a branch-free unrolled loop: mode 0 plain, 1 fused transform, 2 split-form copy
             auto body = [&](auto MODE, auto R0) {
                 constexpr int mode = decltype(MODE)::value;
-#pragma unroll
-                for (int r = decltype(R0)::value; r < NR; ++r) {
+                constexpr int r0 = decltype(R0)::value;
+                auto res_load = [&](auto RR) __attribute__((always_inline)) {           // round rr of the item in the registers -> ring slot (rr - r0) % RD
+                    constexpr int rr = decltype(RR)::value;
+                    if constexpr (mode == 3 && rr < NR) {
+                        const unsigned ofs = ((vmask >> rr) & 1u) ? (unsigned)(res_base + dlt[rr]) : 0x80000000u;
+                        r16[(rr - r0) % RD][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, ofs, 0, 0));
+                        r16[(rr - r0) % RD][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, ofs, 16, 0));
+                    }
+                };
+                if constexpr (mode == 3) static_for<RD>([&](auto J) { res_load(std::integral_constant<int, r0 + decltype(J)::value>{}); });
+                static_for<NR - r0>([&](auto RI) __attribute__((always_inline)) {
+                    constexpr int r = r0 + decltype(RI)::value;
+                    constexpr int rslot = (r - r0) % RD;
+                    [&]() __attribute__((always_inline)) {
                     const int p = r * 128 + pslot;
-                    if ((r + 1) * 128 > NPOS && p >= NPOS) continue;
+                    if ((r + 1) * 128 > NPOS && p >= NPOS) return;
                     u32x4 hi, lo = u32x4{0u, 0u, 0u, 0u};
                     if constexpr (mode == 2) {                               // positions outside the volume were loaded as zeros
                         hi = __builtin_bit_cast(u32x4, v16[r][0]);
@@ -570,19 +595,24 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     } else {
                         const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
                         float t[8];
-                        if constexpr (mode == 1) {
+                        if constexpr (mode == 1 || mode == 3) {
                             // the zero padding applies to the ACTIVATED tensor: lanes outside the volume skip the arithmetic under the
                             // exec mask and store zeros (plain VALU only here -- packed-f32 instructions starve beside the MFMA waves)
                             if (!((vmask >> r) & 1u)) {
                                 const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                                 buf[hsel * HVOLP + p] = z;
                                 if constexpr (NP == 3) buf[(2 + hsel) * HVOLP + p] = z;
-                                continue;
+                                return;
                             }
 #pragma unroll
                             for (int c = 0; c < 8; ++c) {
                                 const float u = fmaf(f[c], sc[c], sh[c]);
                                 t[c] = fmaxf(u, u * slope);
+                            }
+                            if constexpr (mode == 3) {                       // + the residual of the input (the last Residual block's x: model.py:114)
+                                const float g[8] = {r16[rslot][0].x, r16[rslot][0].y, r16[rslot][0].z, r16[rslot][0].w, r16[rslot][1].x, r16[rslot][1].y, r16[rslot][1].z, r16[rslot][1].w};
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) t[c] = g[c] + t[c];      // (gn_apply16_kernel's order: x + activation)
                             }
                         } else {
 #pragma unroll
@@ -602,9 +632,14 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                     }
                     buf[hsel * HVOLP + p] = hi;
                     if constexpr (NP == 3) buf[(2 + hsel) * HVOLP + p] = lo;
-                }
+                    }();
+                    res_load(std::integral_constant<int, r + RD>{});             // into the slot this round has just read
+                });
             };
             auto dispatch = [&](auto R0) __attribute__((always_inline)) {
+                if constexpr (HEAD) {
+                    if (res) { body(std::integral_constant<int, 3>{}, R0); return; }       // (launch check: in_res comes with the fused transform)
+                }
                 if (s16) body(std::integral_constant<int, 2>{}, R0);
                 else if (xform) body(std::integral_constant<int, 1>{}, R0);
                 else body(std::integral_constant<int, 0>{}, R0);
@@ -1023,6 +1058,7 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     dim3 grid((unsigned)sb2_grid_x(a.N, a.Cout, a.D, a.H, a.W), (unsigned)cdiv(a.Cout, 16));
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
+    RU_REQUIRE(!a.in_res || (HEAD && a.in_scale && !a.in_s16), "conv3_sb2: a residual of the INPUT exists in the head form only, together with the fused input transform");
     RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.nblk == (int)grid.x && a.fin.N == a.N && a.fin.C == a.Cout && fin_tail_lds_bytes(a.fin) <= (size_t)LDS2),
                "conv3_sb2: tail descriptor does not match the launch");
     RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");

@@ -111,6 +111,10 @@ struct Conv3Args {
     const float* in_scale;   // [N][Cin] fused input transform v -> lrelu(v*scale+shift, in_slope), or null
     const float* in_shift;
     float in_slope;
+    // Residual of the INPUT (inference head only: conv3_sb_head_takes_residual): the conv reads lrelu(x*scale+shift, in_slope) + in_res -- the output of
+    // the last Residual block (model.py:112-116: x + relu2(norm2(conv2))) formed in the staging, so that block's residual pass never runs.  Voxel-major,
+    // same extents as x; zero padding applies to the SUM.  Null everywhere else.
+    const float* in_res;
     float* stat_partials;    // [N][Cout][nblk][2] per-tile (sum, sumsq) of y, or null
     int sigmoid;             // apply 1/(1+exp(-v)) in the epilogue
     int N, Cin, Cout, D, H, W;
@@ -160,6 +164,7 @@ int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s);
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
 bool conv3_sb_head_form_enabled();                // RU_HEAD_FORM=0 keeps the <= 4-output-channel convolutions on the 16-column kernel (A/B runs, parity tests)
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);
+bool conv3_sb_head_takes_residual(int N, int Cin, int Cout, int D, int H, int W);   // the 16 -> <=4 voxel-major-in / NCDHW-out conv of this shape takes the head-form kernel, which stages Conv3Args::in_res (RU_HEAD_RES=0: never)
 bool conv3_sb_wz_plain_dgrad();                   // RU_WZ=3: gradients entering such a data-gradient convolution are published as plain float32
 bool conv3_sb_wz_takes_split();                   // RU_WZ=2: split-form (data-gradient) inputs take the Winograd-z kernel as well                 // the launch takes the Winograd-z kernel (conv3_wz.hpp)
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s);

@@ -348,6 +348,35 @@ def test_unet128_forward_bf16x3_mask_and_probs(golden):
     assert (d > 1.0 - 1e-4).all()
 
 
+@pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 64, 128, 112), (3, 32, 32, 32)], ids=["1x128^3", "2x64x128x112", "3x32^3-one-stage"])
+def test_inference_head_forms_the_last_residual_in_its_staging(shape):
+    """Inference, split-bf16 engine: the last Residual block's output x + relu2(norm2(conv2(.))) (model.py:108-116) is formed in the head conv's staging
+    (Conv3Args::in_res, conv3_sb2_kernel<..., HEAD>) instead of a pass of its own.  Same arithmetic as that pass (fma, LeakyReLU, x + .), so the
+    probabilities are BIT-IDENTICAL to RU_HEAD_RES=0 (the pass, then the conv); shapes: whole tiles, ragged extents with several samples, and a shape
+    whose head conv takes the one-stage kernel (no deferral there: the switch must change nothing).  The oracle holds both to 1e-3 / 2e-4 elsewhere
+    (test_unet128_forward_bf16x3_mask_and_probs runs the deferred path by default)."""
+    import os
+    n, d, hh, w = shape
+    net, _ = build_model(O.DEFAULT_CFG, 77, "bf16x3")
+    x = T(O.make_input(n, d, hh, w, seed=77)).cuda()
+    net.eval()
+    res = {}
+    for tag in ("0", "1"):
+        os.environ["RU_HEAD_RES"] = tag
+        try:
+            with torch.no_grad():
+                res[tag] = net([x])[0].clone()
+        finally:
+            os.environ.pop("RU_HEAD_RES", None)
+    assert torch.isfinite(res["1"]).all()
+    assert torch.equal(res["0"], res["1"]), float((res["0"] - res["1"]).abs().max())
+    # the training forward keeps the block's output (the head's weight gradient reads it): same probabilities again
+    net.train()
+    with torch.no_grad():
+        pt = net([x])[0]
+    assert torch.equal(pt, res["1"]), float((pt - res["1"]).abs().max())
+
+
 def test_precision_switch_reallocates_workspace():
     """the two precisions keep different scratch tensors: switching on an unchanged shape must not reuse the other's arena size
     (the library reports a too-small workspace loudly; the engine wrapper has to size per precision)"""
