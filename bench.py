@@ -317,7 +317,7 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
             row["frac_executed"] = round(b["bound_ms_executed"] / ms, 4) if ms > 0 else None
         out.append(row)
     kernels = {"conv3_l0": "conv3_sb2_kernel<4,8,C16,C16,one chunk> + conv3_sb2c4_kernel (3x3x3 fwd / data gradient, 16-channel level)",
-               "conv3_deep": "conv3_sb2_kernel<4,8,C16,C16,MULTI> (3x3x3 fwd / data gradient, 32-128 channels)",
+               "conv3_deep": "conv3_wz32_kernel (forward: Winograd-z on 32x32x16 MFMAs) + conv3_sb2_kernel<4,8,C16,C16,MULTI> (data gradient), 32-128 channels",
                "wgrad3_l0": "wgrad3_tz_kernel<1,...> (3x3x3 weight gradient + fused GroupNorm-backward apply, 16-channel level)",
                "wgrad3_deep": "wgrad3_tz_kernel<2,0,1> (3x3x3 weight gradient, 32-128 channels)",
                "groupnorm": "gn_apply16 / gn_bwd_apply16_split / gn_bwd_reduce16 / finalize kernels",

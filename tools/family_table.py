@@ -39,9 +39,9 @@ def kernel_rows(out, pattern, want):
 def main():
     lines = ["# kernel family table (tools/family_table.py): batch %d, voxel-major tensors, split-bf16 x3; peaks: %.1f PF dense bf16, %.1f TB/s HBM" % (N, BF16_PEAK / 1e15, HBM_PEAK / 1e12),
              "# kind   shape        kernel                          avg_us  alg_GB  alg_GB/s  hbm_frac  counter_GB (fetch x2 + write)  MFMA_busy%%  exec_MFMA_TF  exec_frac"]
-    # "conv fwd": the kernel the engine runs at that shape (round 5: conv3_wz_kernel -- Winograd F(2,3) along z -- at 32..128 channels);
+    # "conv fwd": the kernel the engine runs at that shape (round 5: conv3_wz32_kernel -- Winograd F(2,3) along z on 32x32x16 MFMAs -- at 32..128 channels);
     # "conv dir": the direct persistent kernel at the same shapes (RU_WZ=0), kept beside it for comparison
-    for kind, kpats, flags, more_env in (("conv fwd", ("conv3_sb2_kernel", "conv3_wz_kernel"), "3", {}), ("conv dir", ("conv3_sb2_kernel",), "3", {"RU_WZ": "0"}),
+    for kind, kpats, flags, more_env in (("conv fwd", ("conv3_sb2_kernel", "conv3_wz_kernel", "conv3_wz32_kernel"), "3", {}), ("conv dir", ("conv3_sb2_kernel",), "3", {"RU_WZ": "0"}),
                                          ("wgrad", ("wgrad3_tz_kernel",), "3", {})):
         for c, size in SHAPES:
             if kind == "conv dir" and c < 32:
@@ -62,9 +62,9 @@ def main():
             vox = N * size ** 3
             alg_bytes = 2.0 * c * vox * 4                                                    # conv: x + y; weight gradient: x + dy (fp32)
             flops = 2.0 * 27 * c * c * vox
-            # executed MFMA products per algorithmic one: direct kernels 3 x 28/27 (one phantom tap); Winograd-z 3 x 40/54 (four transformed planes x
-            # 10 tap slots, one of them phantom, per two output planes)
-            exec_tf = flops * (3 * 40 / 54 if "conv3_wz" in name else 3 * 28 / 27) / (us * 1e-6) / 1e12
+            # executed MFMA products per algorithmic one: direct kernels 3 x 28/27 (one phantom tap); Winograd-z on 16x16x32 MFMAs 3 x 40/54 (four
+            # transformed planes x 10 tap slots, one of them phantom, per two output planes); on 32x32x16 MFMAs 3 x 36/54 (one K-step per tap)
+            exec_tf = flops * (3 * 36 / 54 if "conv3_wz32" in name else (3 * 40 / 54 if "conv3_wz" in name else 3 * 28 / 27)) / (us * 1e-6) / 1e12
             counter_gb = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024 / 1e9
             busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
             if kind == "conv fwd" and c == 16 and "--json" in sys.argv:
