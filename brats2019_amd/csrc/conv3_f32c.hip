@@ -152,6 +152,13 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
         float4 scq[4], shq[4];                             // fused input transform of the item in flight: requested with its loads, one item ahead
         unsigned vmask = 0;
         int n_cur = 0, chunk_cur = 0;
+        // head form: the residual of the input (Conv3Args::in_res: the last Residual block's x, model.py:114) -- its rows come through a ring of RD rounds
+        // requested inside store(), RD rounds ahead of their use (conv3_sb2_kernel's head form, same reason: registers)
+        constexpr int RD = 2;
+        float4 rq[HEAD ? RD : 1][4];
+        const bool res = HEAD && a.in_res != nullptr;
+        __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
+        int res_base = 0;
         auto issue = [&](int item) {
             const int step = item / nchunk, chunk = item - step * nchunk;
             int n, z0, y0, x0;
@@ -170,6 +177,12 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                 const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
                 const int base = ((zm1 * H + ym1) * W + xm1) * 64;
+                if constexpr (HEAD) {
+                    if (res) {
+                        res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_res + ((size_t)(n * nchunk + chunk) * DHW) * 16), 0, (int)(DHW * 64), 0x00020000);
+                        res_base = base;
+                    }
+                }
                 static_for<NR>([&](auto R) __attribute__((always_inline)) {
                     constexpr int r = decltype(R)::value;
                     const int gz = zm1 + (pk[r] & 0xff), gy = ym1 + ((pk[r] >> 8) & 0xff), gx = xm1 + ((pk[r] >> 16) & 0xff);
@@ -215,22 +228,40 @@ __global__ __launch_bounds__(512, 2) void conv3_f32c_kernel(const Conv3Args a, c
                     if (xform && cok) { sc[c] = a.in_scale[n_cur * a.Cin + cg]; sh[c] = a.in_shift[n_cur * a.Cin + cg]; }
                 }
             }
+            auto res_load = [&](auto RR) __attribute__((always_inline)) {             // round rr of the item in the registers -> ring slot rr % RD
+                constexpr int rr = decltype(RR)::value;
+                if constexpr (HEAD && rr < NR) {
+                    if (res) {
+                        const unsigned ofs = ((vmask >> rr) & 1u) ? (unsigned)(res_base + dlt[rr]) : 0x80000000u;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int p = r * 256 + ptid;
-                if ((r + 1) * 256 > HVOL && p >= HVOL) continue;
-                const bool live = (vmask >> r) & 1u;                                // the zero padding applies to the ACTIVATED tensor
-#pragma unroll
-                for (int q = 0; q < kgroups; ++q) {
-                    const float f[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float u = fmaf(f[j], sc[q * 4 + j], sh[q * 4 + j]);
-                        const float t = fmaxf(u, u * slope);
-                        buf[(q * 4 + j) * CS + p] = live ? t : 0.f;
+                        for (int q = 0; q < 4; ++q) rq[rr % RD][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, ofs, q * 16, 0));
                     }
                 }
-            }
+            };
+            static_for<RD>([&](auto J) { res_load(J); });
+            static_for<NR>([&](auto R) __attribute__((always_inline)) {
+                constexpr int r = decltype(R)::value;
+                const int p = r * 256 + ptid;
+                if (!((r + 1) * 256 > HVOL && p >= HVOL)) {
+                    const bool live = (vmask >> r) & 1u;                            // the zero padding applies to the ACTIVATED tensor (and to the sum)
+#pragma unroll
+                    for (int q = 0; q < kgroups; ++q) {
+                        const float f[4] = {v[r][q].x, v[r][q].y, v[r][q].z, v[r][q].w};
+                        float g[4] = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (HEAD) {
+                            if (res) { g[0] = rq[r % RD][q].x; g[1] = rq[r % RD][q].y; g[2] = rq[r % RD][q].z; g[3] = rq[r % RD][q].w; }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float u = fmaf(f[j], sc[q * 4 + j], sh[q * 4 + j]);
+                            float t = fmaxf(u, u * slope);
+                            if constexpr (HEAD) { if (res) t = g[j] + t; }          // (gn_apply16_kernel's order: x + activation)
+                            buf[(q * 4 + j) * CS + p] = live ? t : 0.f;
+                        }
+                    }
+                }
+                res_load(std::integral_constant<int, r + RD>{});                    // into the slot this round has just read
+            });
         };
         if (nitems > 0) {
             issue(0);
@@ -409,8 +440,16 @@ int conv3_f32c_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W) {
     return (int)f32c_grid_x(N, Cout, D, H, W, c.tz, c.ty);
 }
 
+// the 16 -> <= 4 voxel-major-in / NCDHW-out conv takes the head form, whose staging forms Conv3Args::in_res (RU_HEAD_RES=0: never; conv3_sb_head_takes_residual)
+bool conv3_f32c_head_takes_residual(int Cin, int Cout, int W) {
+    const char* e = getenv("RU_HEAD_RES");
+    return !(e && *e == '0') && f32c_head_form(Cin, Cout) && Cin % 16 == 0 && (W & 3) == 0;
+}
+
 int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s) {
     RU_REQUIRE(a.in_c16 || a.out_c16, "conv3_f32c: at least one voxel-major side (the NCDHW kernel is conv3_f32_kernel)");
+    RU_REQUIRE(!a.in_res || (a.in_c16 && !a.out_c16 && a.in_scale && !a.in_sum_out && f32c_head_form(a.Cin, a.Cout)),
+               "conv3_f32c: a residual of the input is staged by the head form only (inference: nothing is written back)");
     RU_REQUIRE(wfr != nullptr, "conv3_f32c: packed weight fragments missing");
     RU_REQUIRE(!a.add && !a.bst_y && !a.in_s16 && !a.in_c4 && !a.fin.ticket, "conv3_f32c: forward convolution only (no residual / fused backward sums / split-form input / tail)");
     RU_REQUIRE(!a.in_c16 || a.Cin % 16 == 0, "conv3_f32c: voxel-major input needs Cin %% 16 == 0");

@@ -473,6 +473,8 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         float4 r16[HEAD ? RD : 1][2];
         const bool res = HEAD && a.in_res != nullptr;
         __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);      // of the item whose loads are in the registers
+        __amdgpu_buffer_rsrc_t out_rs = res_rs;
+        const bool sum_out = HEAD && res && a.in_sum_out != nullptr;
         int res_base = 0;
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
@@ -484,6 +486,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         const bool s16 = a.in_s16 != 0;                  // split form in HBM (gn_bwd_apply16_launch): the staging is a plain copy of hi / lo packets
         const unsigned lofs = (s16 ? hsel * 4 : hsel * 8) * 4, second = s16 ? 32u : 16u;
         int pk[NR], dlt[NR];                             // (hz | hy << 8 | xc << 16), byte offset of (hz, hy, xc) + this lane's half
+        // head form, Conv3Args::in_sum_out: which of this thread's positions it WRITES -- bit r of own_in: round r is a voxel of the tile itself; of own_nx:
+        // a voxel of the NEXT tile down z whose image rows the z-walk copies from this item's planes 4 / 5 instead of converting them again
+        unsigned own_in = 0, own_nx = 0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int p = r * 128 + pslot;
@@ -491,6 +496,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             const int hz = row / HY, hy = row - hz * HY;
             pk[r] = hz | (hy << 8) | (xc << 16);
             dlt[r] = ((hz * H + hy) * W + xc) * 64 + (int)lofs;
+            const bool inyx = hy >= 1 && hy <= TY && xc >= 1 && xc <= 16 && p < NPOS;
+            own_in |= (inyx && hz >= 1 && hz <= TZ) ? (1u << r) : 0u;
+            own_nx |= (inyx && hz == TZ + 1 && p - TZ * HY * HX < ((2 * HY * HX) / 128) * 128) ? (1u << r) : 0u;
         }
         const bool plast = (NR - 1) * 128 + pslot < NPOS;    // the last round covers positions beyond the image
         // z-walk order, one chunk: the tile of this step sits right below the previous one, so its halo planes 0 and 1 ARE planes 4 and 5
@@ -498,6 +506,7 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
         // < CR*128 <= 2 planes) are copied LDS -> LDS from the other buffer instead of being loaded and converted again
         constexpr int CR = (2 * HY * HX) / 128;
         bool st_chain = false;                           // of the item whose loads are in the registers
+        bool nx_chain = false;                           // ... and whether the item after it will copy its planes 0 / 1 from this one's 4 / 5
         auto issue = [&](int item) {
             if (dbg & 2) return;
             const int step = item / nchunk;
@@ -514,10 +523,12 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
             if constexpr (HEAD) {
                 if (res) {
                     res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in_res + ((size_t)(n * nchunk + chunk) * DHW) * 16), 0, (int)(DHW * 64), 0x00020000);
+                    if (sum_out) out_rs = __builtin_amdgcn_make_buffer_rsrc(a.in_sum_out + ((size_t)(n * nchunk + chunk) * DHW) * 16, 0, (int)(DHW * 64), 0x00020000);
                     res_base = base;
                 }
             }
             st_chain = zwalk && !MULTI && !(dbg & 512) && CR > 0 && (step % ntz) != 0;
+            nx_chain = zwalk && !MULTI && !(dbg & 512) && CR > 0 && ((step + 1) % ntz) != 0;
             auto ld_round = [&](auto R) __attribute__((always_inline)) {
                 constexpr int r = decltype(R)::value;
                 const int gz = zm1 + (pk[r] & 0xff), gy = ym1 + ((pk[r] >> 8) & 0xff), gx = xm1 + ((pk[r] >> 16) & 0xff);
@@ -613,6 +624,12 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                                 const float g[8] = {r16[rslot][0].x, r16[rslot][0].y, r16[rslot][0].z, r16[rslot][0].w, r16[rslot][1].x, r16[rslot][1].y, r16[rslot][1].z, r16[rslot][1].w};
 #pragma unroll
                                 for (int c = 0; c < 8; ++c) t[c] = g[c] + t[c];      // (gn_apply16_kernel's order: x + activation)
+                                if (sum_out) {                               // training: the block output the backward reads, every voxel from exactly one thread
+                                    const bool mine = ((own_in >> r) & 1u) || (nx_chain && ((own_nx >> r) & 1u));
+                                    const unsigned ofs = mine ? (unsigned)(res_base + dlt[r]) : 0x80000000u;
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(t[0], t[1], t[2], t[3])), out_rs, ofs, 0, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(t[4], t[5], t[6], t[7])), out_rs, ofs, 16, 0);
+                                }
                             }
                         } else {
 #pragma unroll
@@ -1059,6 +1076,7 @@ static int sb2_cfg_m(const Conv3Args& a, hipStream_t s) {
     constexpr int dbg = 0;                           // (kernel argument kept for ABI stability of the launch; switches are compile-time)
     RU_REQUIRE(ADD == (a.add != nullptr), "conv3_sb2: residual operand and kernel variant disagree");
     RU_REQUIRE(!a.in_res || (HEAD && a.in_scale && !a.in_s16), "conv3_sb2: a residual of the INPUT exists in the head form only, together with the fused input transform");
+    RU_REQUIRE(!a.in_sum_out || a.in_res, "conv3_sb2: the staged sum is written only where it is formed (in_res)");
     RU_REQUIRE(!a.fin.ticket || (a.stat_partials && a.fin.nblk == (int)grid.x && a.fin.N == a.N && a.fin.C == a.Cout && fin_tail_lds_bytes(a.fin) <= (size_t)LDS2),
                "conv3_sb2: tail descriptor does not match the launch");
     RU_REQUIRE(!IN16 || (size_t)a.D * a.H * a.W * 64 < ((size_t)1 << 31), "conv3_sb2: a 16-channel block of the voxel-major input must be smaller than 2 GiB (buffer addressing)");

@@ -564,8 +564,9 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
 
 // xin_gn: the block input is GroupNorm(+activation) of the RAW tensor xprev, applied on the fly (voxel-major flow, no down-sampling
 // conv): the first conv and its weight gradient stage it with the fused transform, the residual add applies it per element
-// defer_out (inference, the block in front of the head conv): the residual pass does not run -- *out stays null and the caller hands (y2, norm2's scale / shift,
-// the block input x) to the head conv, whose staging forms x + lrelu(norm2(y2)) itself (Conv3Args::in_res); nothing of the block is rewound.
+// defer_out (the block in front of the head conv): the residual pass does not run -- the caller hands (y2, norm2's scale / shift, the block input x) to the
+// head conv, whose staging forms x + lrelu(norm2(y2)) itself (Conv3Args::in_res) and, in training, writes it to sv.out on the way (in_sum_out: the head's
+// weight gradient reads it); in inference *out stays null and nothing of the block is rewound.
 static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, const BlockP& bp, const float* xprev,
                      int N, int D, int H, int W /* extents of xprev */, BlockSave& sv, const float** out, const GNSave* xin_gn = nullptr, bool defer_out = false) {
     sv = BlockSave();
@@ -611,9 +612,9 @@ static int block_fwd(ru_unet* h, const float* params, Arena& A, hipStream_t s, c
     rc = conv3_gn(h, A, s, sv.y1, h->pack + bp.pk_f2, h->fpack + bp.fk_f2, sv.y2, &sv.g1, P(h, params, bp.n2w), P(h, params, bp.n2b), sv.g2, N, C, C, D, H, W);
     if (rc) return rc;
     if (defer_out) {
-        RU_REQUIRE(h->c16 && !h->training && !xin_gn, "block_fwd: the deferred residual pass exists in voxel-major inference only");
-        sv.out = nullptr;
-        *out = nullptr;
+        RU_REQUIRE(h->c16 && !xin_gn, "block_fwd: the deferred residual pass exists in the voxel-major flow only");
+        sv.out = h->training ? A.alloc((size_t)N * C * V) : nullptr;          // training: the head conv's staging WRITES it (Conv3Args::in_sum_out) for the backward
+        *out = sv.out;
         return RU_OK;
     }
     sv.out = recycle ? out_early : A.alloc((size_t)N * C * V);
@@ -744,10 +745,11 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         cur = ds.c;
         h->dec_s[i].assign(h->dec_blocks[i].size(), BlockSave());
         for (size_t j = 0; j < h->dec_blocks[i].size(); ++j) {
-            // inference: the block in front of the head conv leaves its residual pass to that conv's staging (one read of y2 and x instead of
-            // read y2 + read x + write out + read out: 0.54 GB less per 128^3 volume)
-            const bool defer = i == 0 && j + 1 == h->dec_blocks[i].size() && !h->training && h->c16 && h->precision == RU_PREC_BF16X3 &&
-                               conv3_sb_head_takes_residual(N, C0, h->nout, Dl[0], Hl[0], Wl[0]);
+            // the block in front of the head conv leaves its residual pass to that conv's staging (inference: one read of y2 and x instead of read y2 +
+            // read x + write out + read out, 0.54 GB less per 128^3 volume; training: the staging also writes out, 0.27 GB less)
+            const bool defer = i == 0 && j + 1 == h->dec_blocks[i].size() && h->c16 &&
+                               (h->precision == RU_PREC_BF16X3 ? conv3_sb_head_takes_residual(N, C0, h->nout, Dl[0], Hl[0], Wl[0])
+                                                               : (!h->training && conv3_f32c_head_takes_residual(C0, h->nout, Wl[0])));       // (exact f32: the voxel-major flow is inference only)
             rc = block_fwd(h, params, A, s, h->dec_blocks[i][j], cur, N, Dl[i], Hl[i], Wl[i], h->dec_s[i][j], &cur, nullptr, defer);
             if (rc) return rc;
             if (defer) head_block = &h->dec_s[i][j];
@@ -765,6 +767,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     a.N = N; a.Cin = C0; a.Cout = h->nout; a.D = Dl[0]; a.H = Hl[0]; a.W = Wl[0];
     if (head_block) {                                    // x + lrelu(norm2(conv2)) of the last block, formed in this conv's staging
         a.x = head_block->y2; a.in_scale = head_block->g2.scale; a.in_shift = head_block->g2.shift; a.in_slope = kSlope; a.in_res = head_block->x;
+        a.in_sum_out = head_block->out;                  // (training: the block output, written on the way; null in inference)
     }
     RU_RUN(conv3_launch(a, s));
     if (!A.dry) { h->packed_params = h->training ? nullptr : params; h->packed_base = h->pack; h->packed_prec = h->precision; h->packed_c16 = h->c16; }   // a training forward is followed by an optimizer step

@@ -115,6 +115,7 @@ struct Conv3Args {
     // the last Residual block (model.py:112-116: x + relu2(norm2(conv2))) formed in the staging, so that block's residual pass never runs.  Voxel-major,
     // same extents as x; zero padding applies to the SUM.  Null everywhere else.
     const float* in_res;
+    float* in_sum_out;       // with in_res (training): the staged sum is also WRITTEN here (voxel-major, every voxel exactly once) -- the block output the backward reads
     float* stat_partials;    // [N][Cout][nblk][2] per-tile (sum, sumsq) of y, or null
     int sigmoid;             // apply 1/(1+exp(-v)) in the epilogue
     int N, Cin, Cout, D, H, W;
@@ -160,6 +161,7 @@ size_t conv3_f32c_frag_bytes(int Cin_conv, int Cout_conv);
 int conv3_f32c_pack_weights(const float* w, void* wfr, int Cin_f, int Cout_f, int mode, hipStream_t s);
 int conv3_f32c_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W);
 int conv3_f32c_launch(const Conv3Args& a, const void* wfr, hipStream_t s);
+bool conv3_f32c_head_takes_residual(int Cin, int Cout, int W);
 // split-bf16 path (conv3_sb.hip)
 int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int products = 3);    // products: Conv3Args::products of the launch
 bool conv3_sb_head_form_enabled();                // RU_HEAD_FORM=0 keeps the <= 4-output-channel convolutions on the 16-column kernel (A/B runs, parity tests)

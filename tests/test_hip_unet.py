@@ -348,11 +348,12 @@ def test_unet128_forward_bf16x3_mask_and_probs(golden):
     assert (d > 1.0 - 1e-4).all()
 
 
-@pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 64, 128, 112), (3, 32, 32, 32)], ids=["1x128^3", "2x64x128x112", "3x32^3-one-stage"])
+@pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 128, 128, 128), (2, 64, 128, 112), (3, 32, 32, 32)], ids=["1x128^3", "2x128^3-z-walk", "2x64x128x112", "3x32^3-one-stage"])
 def test_inference_head_forms_the_last_residual_in_its_staging(shape):
     """Inference, split-bf16 engine: the last Residual block's output x + relu2(norm2(conv2(.))) (model.py:108-116) is formed in the head conv's staging
     (Conv3Args::in_res, conv3_sb2_kernel<..., HEAD>) instead of a pass of its own.  Same arithmetic as that pass (fma, LeakyReLU, x + .), so the
-    probabilities are BIT-IDENTICAL to RU_HEAD_RES=0 (the pass, then the conv); shapes: whole tiles, ragged extents with several samples, and a shape
+    probabilities are BIT-IDENTICAL to RU_HEAD_RES=0 (the pass, then the conv); shapes: whole tiles, a shape that takes the z-walk tile order (image planes
+    copied from the tile above instead of staged again), ragged extents with several samples, and a shape
     whose head conv takes the one-stage kernel (no deferral there: the switch must change nothing).  The oracle holds both to 1e-3 / 2e-4 elsewhere
     (test_unet128_forward_bf16x3_mask_and_probs runs the deferred path by default)."""
     import os
@@ -370,11 +371,40 @@ def test_inference_head_forms_the_last_residual_in_its_staging(shape):
             os.environ.pop("RU_HEAD_RES", None)
     assert torch.isfinite(res["1"]).all()
     assert torch.equal(res["0"], res["1"]), float((res["0"] - res["1"]).abs().max())
-    # the training forward keeps the block's output (the head's weight gradient reads it): same probabilities again
-    net.train()
-    with torch.no_grad():
-        pt = net([x])[0]
-    assert torch.equal(pt, res["1"]), float((pt - res["1"]).abs().max())
+    # exact-f32 inference (conv3_f32c_kernel<..., HEAD>: every tile size has the head form, so the small shape defers too): bit-identical as well
+    net.set_precision("f32")
+    net.eval()
+    rf = {}
+    for tag in ("0", "1"):
+        os.environ["RU_HEAD_RES"] = tag
+        try:
+            with torch.no_grad():
+                rf[tag] = net([x])[0].clone()
+        finally:
+            os.environ.pop("RU_HEAD_RES", None)
+    assert torch.isfinite(rf["1"]).all() and torch.equal(rf["0"], rf["1"]), float((rf["0"] - rf["1"]).abs().max())
+    assert float((rf["1"] - res["1"]).abs().max()) < 1e-3
+    net.set_precision("bf16x3")
+    # training: the staging also WRITES the block's output (Conv3Args::in_sum_out; the head's weight gradient reads it) -- every voxel exactly once, from the
+    # tile that owns it or, for the image rows the z-walk copies from the tile above, from that tile: probabilities and EVERY gradient bit-identical to the pass
+    from brats2019_amd import loss as L
+    g = T(O.make_target(n, d, hh, w, seed=77)).cuda()
+    tr = {}
+    for tag in ("0", "1"):
+        os.environ["RU_HEAD_RES"] = tag
+        try:
+            net.train()
+            net.zero_grad()
+            out = net([x])
+            loss = L.FusedCriterion()(out, [g])
+            loss.backward()
+            torch.cuda.synchronize()
+            tr[tag] = (out[0].detach().clone(), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
+        finally:
+            os.environ.pop("RU_HEAD_RES", None)
+    assert torch.equal(tr["1"][0], res["1"]) and torch.equal(tr["0"][0], res["1"])
+    for k, v in tr["0"][1].items():
+        assert torch.isfinite(tr["1"][1][k]).all() and torch.equal(tr["1"][1][k], v), (k, float((tr["1"][1][k] - v).abs().max()))
 
 
 def test_precision_switch_reallocates_workspace():
