@@ -142,13 +142,17 @@ def family_bounds(batch, size, precision):
     # Second, ACHIEVABLE-FUSION bound of the GroupNorm family for fp32 tensors (the SURVEY bound above gives it 0 bytes): the passes that
     # cannot ride on a convolution's traffic in this dataflow --
     #   forward: `out = x + lrelu(gn(y2))` of every Residual block (read y2, read x, write out: 3 tensors).  y2 must exist before its
-    #     statistics do and `out` has two readers (the next conv, the next residual add), so recomputing it in both costs more bytes;
+    #     statistics do and `out` has two readers (the next conv, the next residual add), so recomputing it in both costs more bytes
+    #     (one reader only in front of the head: see below; the hand-over to a stride-2 conv was built and is slower, r05_notes section 15);
     #   backward, levels below the first: the GroupNorm-backward apply (read y, read d, write dy: 3 tensors) of both norms of a block --
     #     at the 16-channel level it is computed inside the weight gradient's staging (0 bytes here); at 32+ channels that fusion recomputes
     #     the apply once per input-channel group and measured slower than the pass;
     #   the backward REDUCE passes are not in it (they ride in the epilogue of the kernel that produces the gradient).
     blocks = [(ch[0], v[0], enc[0] + 1)] + [(ch[i + 1], v[i + 1], enc[i + 1] + (1 if i < 2 else 0)) for i in range(3)]     # (C, voxels, Residual blocks: encoder + decoder)
     ach = sum(3 * 4.0 * c * vox * nb for c, vox, nb in blocks)                          # forward residual passes
+    # ... except the block in FRONT OF THE HEAD (round 5): its output has one conv reader, whose staging forms it (and, training, writes it for the
+    # backward): read y2 + read x + write out where the conv-only bound already counts one read -- two extra tensors, not three
+    ach -= 4.0 * ch[0] * v[0]
     ach += sum(2 * 3 * 4.0 * c * vox * nb for c, vox, nb in blocks[1:])                 # backward apply passes below the 16-channel level
     fam["groupnorm"]["achievable_gbytes"] = ach / 1e9
     fam["groupnorm"]["bound_ms_achievable_fusion"] = 1e3 * ach / bw

@@ -335,7 +335,7 @@ def test_unet_parameter_cache_follows_replaced_parameters():
 
 def test_bench_roofline_bookkeeping():
     """bench.py's bounds are arithmetic on SURVEY 8(d)'s figures -- pinned so that a change of the layer table shows: algorithmic FLOPs of a
-    step = 4 x 890.87 GFLOP, fused-lower-bound bytes 37.9 GB, whole-step algorithmic bound 4.94 ms, GroupNorm achievable-fusion bytes 8.05 GB;
+    step = 4 x 890.87 GFLOP, fused-lower-bound bytes 37.9 GB, whole-step algorithmic bound 4.94 ms, GroupNorm achievable-fusion bytes 7.52 GB (8.05 before the head conv took over the last residual pass);
     the committed PMC family table parses into eight rows."""
     import bench
     fb = bench.family_bounds(4, 128, "bf16x3")
@@ -344,16 +344,16 @@ def test_bench_roofline_bookkeeping():
     assert abs(gflop - 4 * bench.FWDBWD_GFLOP_PER_VOL) < 1.0, gflop
     assert abs(gbytes - 37.91) < 0.05, gbytes
     assert abs(sum(f["bound_ms_algorithmic"] for f in fb.values()) - 4.936) < 0.01
-    assert abs(fb["groupnorm"]["achievable_gbytes"] - 8.053) < 0.01 and abs(fb["groupnorm"]["bound_ms_achievable_fusion"] - 1.0066) < 0.001
+    assert abs(fb["groupnorm"]["achievable_gbytes"] - 7.516) < 0.01 and abs(fb["groupnorm"]["bound_ms_achievable_fusion"] - 0.9395) < 0.001
     assert bench.step_roofline_ms(4, 128, "bf16x3") > sum(f["bound_ms_algorithmic"] for f in fb.values())          # executed products cost more than algorithmic ones
-    # the achievable bounds of the line (round 5): + GroupNorm passes no fusion removes (8.05 GB), + the y re-read of the 25 norms' backward sums
+    # the achievable bounds of the line (round 5): + GroupNorm passes no fusion removes (7.52 GB), + the y re-read of the 25 norms' backward sums
     # (one tensor each: 3.76 GB) and the (y, d) reads of the 16-channel level's apply inside its weight gradient (2 tensors x 4 norms: 4.29 GB)
     ex = fb["groupnorm"]["achievable_extra_gbytes"]
     assert abs(ex["bst_y_reread"] - 3.758) < 0.005 and abs(ex["wgrad_l0_fused_apply"] - 4.295) < 0.005
     ab = bench.achievable_bounds(fb)
-    assert abs(ab["algorithmic_ms"] - 4.936) < 0.01 and abs(ab["achievable_ms"] - 5.942) < 0.01 and abs(ab["achievable_all_ms"] - 6.949) < 0.01
-    assert abs(ab["gbytes_fused_lower_bound"] - 37.91) < 0.05 and abs(ab["gbytes_achievable"] - 45.96) < 0.05 and abs(ab["gbytes_achievable_all"] - 54.01) < 0.05
-    assert abs(ab["achievable_ms"] / 15.833 - 0.375) < 0.002                                                     # the round-4 driver line, recomputed by its judge as 0.376
+    assert abs(ab["algorithmic_ms"] - 4.936) < 0.01 and abs(ab["achievable_ms"] - 5.875) < 0.01 and abs(ab["achievable_all_ms"] - 6.882) < 0.01
+    assert abs(ab["gbytes_fused_lower_bound"] - 37.91) < 0.05 and abs(ab["gbytes_achievable"] - 45.42) < 0.05 and abs(ab["gbytes_achievable_all"] - 53.48) < 0.05
+    assert abs((ab["achievable_ms"] + 4.0 * 16 * 4 * 128 ** 3 / 8e12 * 1e3) / 15.833 - 0.375) < 0.002      # with the last residual pass counted (round 4's dataflow): the round-4 driver line, recomputed by its judge as 0.376
     ft = bench.committed_family_table()
     assert ft is not None and len(ft["rows"]) >= 8 and {r["channels"] for r in ft["rows"]} == {16, 32, 64, 128}
     assert all(0 < r["mfma_busy_pct"] < 100 and r["avg_us"] > 0 for r in ft["rows"])

@@ -303,11 +303,12 @@ def test_tta_merge_box_equals_merge_then_crop():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,density", [((37, 41, 29), 0.03), ((37, 41, 29), 0.08), ((37, 41, 29), 0.2), ((96, 100, 80), 0.06),
-                                           ((30, 30, 30), 0.9), ((155, 240, 240), 0.04)])
+                                           ((30, 30, 30), 0.9), ((155, 240, 240), 0.04), ((160, 192, 160), 0.8)])
 def test_component_rejection_on_device_bit_exact(shape, density):
     """ru_cc_reject (union-find on the device) against scipy's 26-connected labelling + test.py:51-62, bit for bit: sparse noise (thousands of
     small components), densities around the percolation threshold (one giant component beside many small ones), a foreground larger than
-    the background (counts.max() is then a COMPONENT, test.py:55), and one BraTS-native 155 x 240 x 240 volume."""
+    the background (counts.max() is then a COMPONENT, test.py:55), one BraTS-native 155 x 240 x 240 volume, and the dense noise of a random-init
+    network's prediction at the padded crop bench.py's predict_case leg labels (4 million foreground voxels in one giant component)."""
     from brats2019_amd import inference as I, ops
     rng = np.random.default_rng(hash((shape, density)) % (2 ** 31))
     u = rng.random(shape)
@@ -328,7 +329,7 @@ def test_component_rejection_on_device_bit_exact(shape, density):
         assert np.array_equal(want, I.postprocess_labels(lab))
     got = ops.cc_reject(T(lab.copy()).cuda(), 0.1).cpu().numpy()
     assert np.array_equal(got, want), "%d voxels differ" % int((got != want).sum())
-    assert (want != lab).any() or density >= 0.9           # the rule removed something (except in the all-foreground case)
+    assert (want != lab).any() or density >= 0.8           # the rule removed something (except in the dense cases: one component holds every voxel)
 
 
 @pytest.mark.gpu
