@@ -220,12 +220,9 @@ __global__ __launch_bounds__(512, 2) void conv3_wz32_kernel(const Conv3Args a, c
             const bool fin = pending && !(dbg & 8);      // the previous tile is combined and stored under this item's matrix work
             if (fin) fin_prepare(pn, ptz, pty, ptx);
             pending = false;
-            if (chunk == 0) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-            }
+            // (the accumulators of a tile are not zeroed: the FIRST MFMA of a row pair in the tile's first chunk takes a zero C operand -- an inline constant,
+            // one wave-uniform branch per row pair -- instead of 64 v_mov per tile in the matrix wave's stream)
+            const bool first_chunk = chunk == 0;
             {
                 const bool FIN = fin, LAST = last;
                 auto frag_ofs = [&](auto S) __attribute__((always_inline)) { return fb + (decltype(S)::value / 3) * HX + decltype(S)::value % 3; };
@@ -262,7 +259,12 @@ __global__ __launch_bounds__(512, 2) void conv3_wz32_kernel(const Conv3Args a, c
                             if constexpr (dy >= 0 && t >= 0 && t < 4) {
                                 const bf16x8 bh = __builtin_bit_cast(bf16x8, wreg[dy * 3 + dx][0]);
                                 const bf16x8 bl = __builtin_bit_cast(bf16x8, wreg[dy * 3 + dx][1]);
-                                if constexpr (pr == 0) acc[t] = mm(al, bh, acc[t]);
+                                if constexpr (pr == 0 && dx == 0 && dy == 0) {               // the row pair's first MFMA of this item
+                                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                    if (first_chunk) acc[t] = mm(al, bh, zero);
+                                    else acc[t] = mm(al, bh, acc[t]);
+                                }
+                                else if constexpr (pr == 0) acc[t] = mm(al, bh, acc[t]);
                                 else if constexpr (pr == 1) acc[t] = mm(ah, bl, acc[t]);
                                 else acc[t] = mm(ah, bh, acc[t]);
                                 __builtin_amdgcn_sched_barrier(0);
