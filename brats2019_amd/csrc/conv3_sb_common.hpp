@@ -157,7 +157,8 @@ __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, 
         }
     }
     if constexpr ((kSb2RowDbg & 512) != 0) { s2[0] += v[1] + v[2] + v[3]; return; }
-    *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (OUT16) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<OUT16>(a, o, yy)));
+    else *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
 // GroupNorm-backward sums are taken on the way: u = y*k1 + k2 (= sign(gamma)*xhat), dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
@@ -172,7 +173,7 @@ __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut&
     for (int r = 0; r < 4; ++r) dh[r] = u[r] > kc[2][r] ? v[r] : vs[r];
     s1 += dh;
     s2 += dh * u;
-    *reinterpret_cast<float4*>(a.y + sb_out_index<true>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<true>(a, o, yy)));
 }
 // Statistics partials: ONE per (workgroup, sample), [N][Cout][nblk][2].  A consumer wave folds its lanes and leaves its 16 channels'
 // (sum, sum2) in an LDS scratch row (sb_stats_to_lds: sc = this wave's 32 floats); after a workgroup barrier one wave adds the four

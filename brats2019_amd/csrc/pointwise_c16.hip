@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict
             }
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        yp[f] = o;
+        __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(yp + f));
     }
 }
 int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s,
