@@ -138,7 +138,9 @@ constexpr int kSb2RowDbg = RU_SB2_DBG;      // ablation builds only: 256 = no st
 #else
 constexpr int kSb2RowDbg = 0;
 #endif
-template <bool OUT16, bool HAS_R>
+// NT: the row goes out with a nontemporal store -- the 16-channel level, whose 0.5 GB tensors nobody reads while they could still sit in L2 / MALL (the
+// deep levels' outputs ARE read again from there: profiles/r05_notes.txt, section 20)
+template <bool OUT16, bool HAS_R, bool NT = false>
 __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& radd, f32x4& s1, f32x4& s2) {
     if (!(o.ok && yy < a.H)) return;
     if constexpr (!OUT16) v += f32x4{o.bias.x, o.bias.y, o.bias.z, o.bias.w};
@@ -157,11 +159,12 @@ __device__ __forceinline__ void sb2_out_row(const Conv3Args& a, const SbOut& o, 
         }
     }
     if constexpr ((kSb2RowDbg & 512) != 0) { s2[0] += v[1] + v[2] + v[3]; return; }
-    if constexpr (OUT16) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<OUT16>(a, o, yy)));
+    if constexpr (OUT16 && NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<OUT16>(a, o, yy)));
     else *reinterpret_cast<float4*>(a.y + sb_out_index<OUT16>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // Conv3Args::bst_*: this conv's output d is the gradient w.r.t. the activation after GroupNorm(y); the row is stored unchanged and the
 // GroupNorm-backward sums are taken on the way: u = y*k1 + k2 (= sign(gamma)*xhat), dh = u > thr ? d : d*slope, S1 += dh, S2' += dh*u
+template <bool NT = false>
 __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut& o, int yy, f32x4 v, const float4& yv, const f32x4 (&kc)[3], float slope,
                                                 f32x4& s1, f32x4& s2, const float4* radd = nullptr) {
     if (!(o.ok && yy < a.H)) return;
@@ -173,7 +176,8 @@ __device__ __forceinline__ void sb_out_tile_bst(const Conv3Args& a, const SbOut&
     for (int r = 0; r < 4; ++r) dh[r] = u[r] > kc[2][r] ? v[r] : vs[r];
     s1 += dh;
     s2 += dh * u;
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<true>(a, o, yy)));
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.y + sb_out_index<true>(a, o, yy)));
+    else *reinterpret_cast<float4*>(a.y + sb_out_index<true>(a, o, yy)) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // Statistics partials: ONE per (workgroup, sample), [N][Cout][nblk][2].  A consumer wave folds its lanes and leaves its 16 channels'
 // (sum, sum2) in an LDS scratch row (sb_stats_to_lds: sc = this wave's 32 floats); after a workgroup barrier one wave adds the four
@@ -903,9 +907,9 @@ __global__ __launch_bounds__(512, 2) void conv3_sb2_kernel(const Conv3Args a, co
                 } else if constexpr ((dbg & 8) != 0) {
                     dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];                  // ablation: the MFMAs stay, the row is dropped
                 } else if constexpr (BST) {
-                    sb_out_tile_bst(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
+                    sb_out_tile_bst<!MULTI>(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
                 } else {
-                    sb2_out_row<OUT16, has_r>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
+                    sb2_out_row<OUT16, has_r, !MULTI>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
                 }
             };
             // devtools bits 20-22 (value k = 1..3): the consumers drop the last k fragment families of every halo row -- their MFMAs AND their

@@ -29,7 +29,7 @@ static inline dim3 c16_grid(size_t V, int blocks_nc, unsigned cap = 2048) {
 
 // ------------------------------------------------------------------ GroupNorm apply: y = (res) + lrelu(x*scale[n,c] + shift[n,c])
 // RES: 0 none, 1 plain residual, 2 residual = lrelu(res*rscale[n,c] + rshift[n,c]) (a GroupNorm output that was never written)
-template <int RES>
+template <int RES, bool NT = false>
 __global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ res, float* __restrict__ y, int C, size_t V, float slope,
                                                          const float* __restrict__ rscale, const float* __restrict__ rshift, float rslope) {
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict
             }
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(yp + f));
+        if constexpr (NT) __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(yp + f));
+        else yp[f] = o;
     }
 }
 int gn_apply16_launch(const float* x, const float* scale, const float* shift, const float* res, float* y, int N, int C, size_t V, float slope, hipStream_t s,
@@ -66,8 +67,12 @@ int gn_apply16_launch(const float* x, const float* scale, const float* shift, co
     RU_REQUIRE(C % 16 == 0, "gn_apply16: C must be a multiple of 16");
     RU_REQUIRE(!rscale || (res && rshift), "gn_apply16: a residual transform needs the residual and both of its vectors");
     const dim3 grid = c16_grid(V, N * (C / 16));
+    // nontemporal stores for tensors that outlast the caches (>= 128 MB: the 16-channel level); smaller ones are read again from L2 / MALL
+    const bool nt = (size_t)N * C * V * sizeof(float) >= ((size_t)128 << 20);
     if (!res) hipLaunchKernelGGL(gn_apply16_kernel<0>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
+    else if (!rscale && nt) hipLaunchKernelGGL((gn_apply16_kernel<1, true>), grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
     else if (!rscale) hipLaunchKernelGGL(gn_apply16_kernel<1>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
+    else if (nt) hipLaunchKernelGGL((gn_apply16_kernel<2, true>), grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
     else hipLaunchKernelGGL(gn_apply16_kernel<2>, grid, dim3(256), 0, s, x, scale, shift, res, y, C, V, slope, rscale, rshift, rslope);
     RU_CHECK_LAUNCH("gn_apply16_kernel");
     return RU_OK;
