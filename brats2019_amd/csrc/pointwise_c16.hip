@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict_
     const size_t Vi = (size_t)D * H * W, Vo = Vi * 8;
     const float4* xp = reinterpret_cast<const float4*>(x) + nb * Vi * 4;
     float4* yp = reinterpret_cast<float4*>(y) + nb * Vo * 4;
+    const bool nt_out = (size_t)gridDim.y * Vo * 16 * sizeof(float) >= ((size_t)128 << 20);      // the output outlasts the caches (conv1_16_kernel's rule)
     const size_t total = (size_t)(D + 1) * (H + 1) * Wo * 4;
     for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < total; f += (size_t)gridDim.x * 256) {
         const int q = (int)(f & 3);
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void up2_fwd16_kernel(const float* __restrict_
 #define RU_UP2(c) o.c = lrelu(lz0 * (ly0 * e00.c + ly1 * e01.c) + lz1 * (ly0 * e10.c + ly1 * e11.c), slope)
                 RU_UP2(x); RU_UP2(y); RU_UP2(z); RU_UP2(w);   // slope 1: no activation
 #undef RU_UP2
-                yp[(((size_t)zo * Ho + yo) * Wo + xo) * 4 + q] = o;
+                if (nt_out) __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(yp + (((size_t)zo * Ho + yo) * Wo + xo) * 4 + q));
+                else yp[(((size_t)zo * Ho + yo) * Wo + xo) * 4 + q] = o;
             }
         }
     }
@@ -411,6 +413,8 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             for (int t3 = 0; t3 < 3; ++t3) { const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t3 * Cstat); bk[sl][t3] = f32x4_c16{q.x, q.y, q.z, q.w}; }
         }
     }
+    // nontemporal stores where the output outlasts the caches (>= 128 MB: the 16-channel level; profiles/r05_notes.txt, section 20)
+    const bool nt_out = (size_t)a.N * a.Cout * V * sizeof(float) >= ((size_t)128 << 20);
     const int vt = blockIdx.x * 4 + wave;
     const bool live = vt < nvt;
     if (!live) { if constexpr (!BST) return; }
@@ -506,7 +510,8 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
                 o.z = m.z > 0.f ? o.z : o.z * a.mask_slope; o.w = m.w > 0.f ? o.w : o.w * a.mask_slope;
             }
             if (a.add) { const float4 d = *reinterpret_cast<const float4*>(a.add + idx); o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
-            *reinterpret_cast<float4*>(ydst + idx) = o;
+            if (nt_out) __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(ydst + idx));
+            else *reinterpret_cast<float4*>(ydst + idx) = o;
             if constexpr (BST) {                         // sums of the STORED gradient (sb_out_tile_bst's arithmetic)
                 constexpr int sl = 0;
                 (void)sl;
