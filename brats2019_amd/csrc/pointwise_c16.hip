@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(const float* __restrict
     const float4* rp = reinterpret_cast<const float4*>(res) + base;
     float4* yp = reinterpret_cast<float4*>(y) + base;
     for (size_t f = (size_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (size_t)gridDim.x * 256) {
-        const float4 t = xp[f];
+        float4 t;
+        if constexpr (NT) { const f32x4_c16 tv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_c16*>(xp + f)); t = make_float4(tv[0], tv[1], tv[2], tv[3]); }
+        else t = xp[f];
         float4 o;
         o.x = lrelu(t.x * a.x + b.x, slope); o.y = lrelu(t.y * a.y + b.y, slope);
         o.z = lrelu(t.z * a.z + b.z, slope); o.w = lrelu(t.w * a.w + b.w, slope);
