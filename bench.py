@@ -638,21 +638,39 @@ def self_launch(n):
     env.setdefault("OMP_NUM_THREADS", "8")                # torch.distributed.run would set 1: the cpu_baseline leg is off at N > 1 anyway
 
     def run(argv, port, extra_env=None):
+        """Start the ranks and RELAY while they run: every stdout line is written (and flushed) as it arrives, so rank 0's JSON line is out even if the
+        ranks hang in their final barrier / RCCL teardown or the driver's time limit kills this launcher; stderr passes through as it comes, with a
+        bounded tail kept for _first_error_line.  Returns (exit code, a '{' line was relayed, stderr tail)."""
+        import collections
+        import threading
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.abspath(__file__)] + argv
-        r = subprocess.run(cmd, env=dict(env, **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        sys.stderr.write(r.stderr)
-        sys.stderr.flush()
-        return r
+        p = subprocess.Popen(cmd, env=dict(env, **(extra_env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+        tail = collections.deque(maxlen=400)
+
+        def pump_err():
+            for ln in p.stderr:
+                tail.append(ln)
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+        t = threading.Thread(target=pump_err, daemon=True)
+        t.start()
+        seen = False
+        for ln in p.stdout:
+            seen = seen or ln.startswith("{")
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        rc = p.wait()
+        t.join(timeout=10)
+        return rc, seen, "".join(tail)
 
     argv = sys.argv[1:]
-    r = run(argv, os.environ.get("MASTER_PORT") or free_port())
-    has_line = any(ln.startswith("{") for ln in r.stdout.splitlines())
+    rc, has_line, err = run(argv, os.environ.get("MASTER_PORT") or free_port())
     wants_rccl = "gloo" not in [argv[i + 1] for i, a in enumerate(argv[:-1]) if a == "--dist-backend"]
-    if r.returncode != 0 and not has_line and wants_rccl:
-        reason = _first_error_line(r.stderr)
+    if rc != 0 and not has_line and wants_rccl:
+        reason = _first_error_line(err)
         sys.stderr.write("bench.py: the %d ranks exited with code %d over the RCCL backend (%s); starting ONE fresh set of ranks with --dist-backend gloo\n"
-                         % (n, r.returncode, reason))
+                         % (n, rc, reason))
         sys.stderr.flush()
         keep, skip = [], False
         for a in argv:                                     # same arguments, minus the transport choices that need RCCL
@@ -663,10 +681,8 @@ def self_launch(n):
                 skip = True
                 continue
             keep.append(a)
-        r = run(keep + ["--dist-backend", "gloo"], free_port(), {"RU_BENCH_FALLBACK_REASON": reason, "RU_BENCH_INJECT_RCCL_FAIL": ""})
-    sys.stdout.write(r.stdout)
-    sys.stdout.flush()
-    return r.returncode
+        rc, has_line, err = run(keep + ["--dist-backend", "gloo"], free_port(), {"RU_BENCH_FALLBACK_REASON": reason, "RU_BENCH_INJECT_RCCL_FAIL": ""})
+    return rc
 
 
 def main():

@@ -1,0 +1,106 @@
+// conv3_mx_pack.hpp -- what conv3_sb.hip needs of the fp16 + MX-fp8 scheme (conv3_mx.hpp has the kernel and the description): constants, conversions, the weight
+// fragment packer, the launch rule.
+#pragma once
+#include "conv3_sb_common.hpp"
+
+namespace ru {
+
+constexpr int MX_SX = 11, MX_SWH = 8, MX_SWL = 19;
+static_assert(MX_SX + MX_SWH == MX_SWL, "one pair of hardware scales serves both cross terms");
+constexpr int MX_SCALE_ACT = (127 - MX_SX) * 0x01010101;       // E8M0 2^-11 in every byte (op_sel 0 reads byte 0)
+constexpr int MX_SCALE_W = (127 - MX_SWH) * 0x01010101;        // 2^-8
+constexpr int MX_UNITS = 28;                                   // 16-byte x 64-lane units per 16-cout group: 14 fp16 K-steps, 2 x 3 x 2 cross, 2 ninth chain
+
+typedef _Float16 mx_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mx_f16x2 __attribute__((ext_vector_type(2)));
+typedef int mx_i32x8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr bool mx_channels_ok(int Cin_conv, int Cout_conv) { return Cin_conv == 16 && Cout_conv % 16 == 0; }
+static inline size_t mx_frag_bytes(int Cin_conv, int Cout_conv) { return mx_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 16) * MX_UNITS * 64 * 16 : 0; }
+
+// tap (dz*9 + dy*3 + dx) of cross fragment X(h, .) for row tap dy, tap pair j = g >> 1, slot
+__host__ __device__ constexpr int mx_cross_tap(int h, int j, int slot, int dy) {
+    const int c = 4 * h + 2 * j + slot;
+    return (c / 3) * 9 + dy * 3 + c % 3;
+}
+// ... of the ninth-chain fragment N: (j, slot) = (0,0), (0,1), (1,0) are dy = 0, 1, 2; (1,1) is a phantom (zero weights)
+__host__ __device__ constexpr int mx_ninth_tap(int j, int slot) {
+    const int dy = 2 * j + slot;
+    return dy < 3 ? 2 * 9 + dy * 3 + 2 : -1;
+}
+
+// two floats -> two e4m3 bytes in the low / high half of a dword (round to nearest even; saturating under MODE.FP16_OVFL)
+__device__ __forceinline__ unsigned mx_cvt4(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+__device__ __forceinline__ void mx_set_saturating_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }    // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
+
+// 8 values -> 4 dwords of fp16 (RNE), 2 dwords of e4m3(lo * 2^SX) and 2 dwords of e4m3(v)
+__device__ __forceinline__ void mx_split8(const float (&t)[8], u32x4& h16, unsigned (&l8)[2], unsigned (&x8)[2]) {
+    float lo[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mx_f16x2 h;
+        h[0] = (_Float16)t[2 * c];
+        h[1] = (_Float16)t[2 * c + 1];
+        h16[c] = __builtin_bit_cast(unsigned, h);
+        lo[2 * c] = (t[2 * c] - (float)h[0]) * (float)(1 << MX_SX);
+        lo[2 * c + 1] = (t[2 * c + 1] - (float)h[1]) * (float)(1 << MX_SX);
+    }
+    l8[0] = mx_cvt4(lo[0], lo[1], lo[2], lo[3]); l8[1] = mx_cvt4(lo[4], lo[5], lo[6], lo[7]);
+    x8[0] = mx_cvt4(t[0], t[1], t[2], t[3]);     x8[1] = mx_cvt4(t[4], t[5], t[6], t[7]);
+}
+
+// ------------------------------------------------------------------ weight fragments (packed behind the direct ones of the same weight)
+// unit u of 16-cout group cog, lane l (col = l & 15 = output channel, k-group g = l >> 4):
+//   u < 14            fp16 K-step u: 8 x fp16 of W[co][ci = (g&1)*8 + e][sb_tap(u, g>>1)]                       (the direct kernel's fragment in fp16)
+//   u = 14 + (3h+dy)*2 + slot   cross: 16 x e4m3 over ci = 0..15 of tap mx_cross_tap(h, g>>1, slot, dy): (g&1) == 0 ? w * 2^8 : (w - f16(w)) * 2^19
+//   u = 26 + slot     ninth chain: the same at tap mx_ninth_tap(g>>1, slot)
+__device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* __restrict__ mxfrag, int Cin_f, int Cout_f, int mode, int ncog, int i) {
+    if (i >= ncog * MX_UNITS * 64) return;
+    mx_set_saturating_conversions();
+    const int lane = i & 63, unit = (i >> 6) % MX_UNITS, cog = (i >> 6) / MX_UNITS;
+    const int col = lane & 15, g = lane >> 4, co = cog * 16 + col;
+    const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
+    auto wat = [&](int ci, int tap) -> float {
+        if (tap < 0 || ci >= cin_conv || co >= cout_conv) return 0.f;
+        return mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+    };
+    u32x4 out;
+    if (unit < SB_KSTEPS) {
+        const int tap = sb_tap(unit, g >> 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mx_f16x2 h;
+            h[0] = (_Float16)wat((g & 1) * 8 + 2 * c, tap);
+            h[1] = (_Float16)wat((g & 1) * 8 + 2 * c + 1, tap);
+            out[c] = __builtin_bit_cast(unsigned, h);
+        }
+    } else {
+        int tap;
+        if (unit < 26) {
+            const int u = unit - SB_KSTEPS, slot = u & 1, dy = (u >> 1) % 3, h = u / 6;
+            tap = mx_cross_tap(h, g >> 1, slot, dy);
+        } else {
+            tap = mx_ninth_tap(g >> 1, unit - 26);
+        }
+        float v[16];
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+            const float x = wat(ci, tap);
+            v[ci] = (g & 1) == 0 ? x * (float)(1 << MX_SWH) : (x - (float)(_Float16)x) * (float)(1 << MX_SWL);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = mx_cvt4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    }
+    mxfrag[((size_t)cog * MX_UNITS + unit) * 64 + lane] = out;
+}
+
+// launch rule and entry (conv3_mx.hip)
+bool conv3_mx_enabled();                                 // RU_MX=0: every forward convolution keeps the three-product kernels (same-box A/B, parity tests)
+bool conv3_mx_shape_ok(int N, int Cin, int Cout, int D, int H, int W);
+int conv3_mx_launch(const Conv3Args& a, const void* mxfrag, hipStream_t s);
+
+}  // namespace ru

@@ -19,6 +19,7 @@
 //   C/D: lane holds 4 consecutive x voxels of output channel l&15 -> shared epilogue (conv3_epilogue.hpp).
 #include "conv3_sb_common.hpp"
 #include "conv3_wz_pack.hpp"
+#include "conv3_mx_pack.hpp"
 
 namespace ru {
 
@@ -617,13 +618,15 @@ __device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u3
 // behind them (conv3_sb_frag_bytes_direct) the transformed ones of the 16x16x32 form, then (wz_frag_bytes further) those of the 32x32x16 form -- which kernel a launch takes depends on its SHAPE, and frozen packs (inference) must serve
 // every shape.  Threads [0, direct) pack direct units, [direct, direct + wz) transformed ones, [direct + wz, direct + wz + wz32) the 32x32x16 ones.
 // forms: bit 0 = the 16x16x32 Winograd-z fragments, bit 1 = the 32x32x16 ones (SB_FORMS_ALL: op-level packs and inference, whose frozen packs must serve
-// every later launch; a training step repacks per forward and packs what that forward's launches take -- sb_pack_forms)
-constexpr int SB_FORMS_ALL = 3;
+// every later launch; a training step repacks per forward and packs what that forward's launches take -- sb_pack_forms); bit 2 = the fp16 + MX-fp8 fragments of
+// conv3_mx_kernel (16 input channels, whole 16-channel output blocks: shapes that have neither a Winograd-z nor a head form, so they sit right behind the direct ones)
+constexpr int SB_FORMS_ALL = 7;
 __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int forms, int i) {
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
     if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
+    if (mx_channels_ok(cin_conv, cout_conv)) { if (forms & 4) mx_pack_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, ncog, i - direct); return; }
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
     const int wz = (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64;      // (the fragments keep their places whatever `forms` says: a skipped form leaves its bytes as they are)
     int r = i - direct;
@@ -636,16 +639,17 @@ __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4*
 static inline int sb_pack_threads(int cin_conv, int cout_conv, int forms) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
     return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((forms & 1) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0)) * 64 : 0)
-         + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0);
+         + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0) + (((forms & 4) && mx_channels_ok(cin_conv, cout_conv)) ? ncog * MX_UNITS * 64 : 0);
 }
 // what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 switches
 // (conv3_sb_uses_wz, conv3_sb_wz_takes_split, conv3_sb_wz_plain_dgrad, conv3_wz32_enabled: read per call, as the launches read them)
 static int sb_pack_forms(int mode) {
+    const int mx = (mode == 0 && conv3_mx_enabled()) ? 4 : 0;      // forward convolutions only: gradients never take the fp16 + MX-fp8 scheme
     const char* e = getenv("RU_WZ");
-    if (e && *e == '0') return 0;
+    if (e && *e == '0') return mx;
     const bool dgrad_wz = conv3_sb_wz_takes_split() || conv3_sb_wz_plain_dgrad();
-    if (mode == 1) return dgrad_wz ? SB_FORMS_ALL : 0;     // (a data-gradient launch without residual / GroupNorm-backward sums takes the forward form)
-    return conv3_wz32_enabled() ? 2 : 1;                    // forward launches have neither residual nor GroupNorm-backward sums: ONE form
+    if (mode == 1) return dgrad_wz ? 3 : 0;                 // (a data-gradient launch without residual / GroupNorm-backward sums takes the forward form)
+    return (conv3_wz32_enabled() ? 2 : 1) | mx;             // forward launches have neither residual nor GroupNorm-backward sums: ONE Winograd-z form
 }
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
     sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, SB_FORMS_ALL, blockIdx.x * blockDim.x + threadIdx.x);
@@ -683,7 +687,7 @@ size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv) {
 }
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments | <= 4 couts: the head form) behind them
     return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv) + wz32_frag_bytes(Cin_conv, Cout_conv)
-         + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0);
+         + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0) + mx_frag_bytes(Cin_conv, Cout_conv);
 }
 // The inference head: the last Residual block's output x + lrelu(norm2(conv2)) (model.py:112-116) is formed in the head conv's staging instead of a pass of its
 // own (Conv3Args::in_res).  Exists in the head-form variant of the persistent kernel only: the same tests as conv3_sb_launch's way there.  RU_HEAD_RES=0: off (A/B).
@@ -809,6 +813,11 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
     if (a.in_c16 && a.out_c16 && !a.bias && !a.sigmoid && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.in_s16 && !conv3_sb_wz_takes_split() ? 1 : a.products))
         return conv3_wz_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
+    // Conv3Args::products == 2: the caller's input is an ACTIVATION tensor and it asks for the fp16 + MX-fp8 product scheme where a kernel for the shape exists
+    // (conv3_mx.hpp: the 16-channel level); everywhere else the request means three products
+    if (a.products == 2 && a.in_c16 && a.out_c16 && !a.in_s16 && !a.bias && !a.sigmoid && !a.add && !a.bst_y && !a.in_res && conv3_mx_enabled() &&
+        conv3_mx_shape_ok(a.N, a.Cin, a.Cout, a.D, a.H, a.W))
+        return conv3_mx_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
     if (sb_use_v2(c)) {
         if (a.in_c16 && a.out_c16) return a.products == 1 ? conv3_sb2_launch_c16_p1(a, s) : conv3_sb2_launch_c16(a, s);
         return conv3_sb2_launch_mixed(a, s);             // (three products whatever a.products says: the NCDHW-side variants have no one-product form)

@@ -84,14 +84,19 @@ static int trace_sync(const char* what, hipStream_t s) {
 // (bench.py's `roofline_families`): the family follows from the launcher's name, the level (16-channel level or deeper) from a hint the
 // block walkers set.  Thread-local: the sink of the handle whose ru_unet_forward / ru_unet_backward is executing on this thread.
 enum { FAM_CONV_L0 = 0, FAM_CONV_DEEP, FAM_WGRAD_L0, FAM_WGRAD_DEEP, FAM_GN, FAM_PW, FAM_OTHER, FAM_COUNT };
+// ... and, for the launches that are ONE kernel instantiation worth naming (bench.py's `roofline_top`: the largest single rows of the step's kernel table), to
+// an INSTANCE as well: the block walkers tag the launch they are about to make (t_hint_inst, consumed by the next RU_RUN)
+enum { INST_CONV16_FWD = 0, INST_CONV16_DGRAD, INST_CONV_DEEP_FWD, INST_CONV_DEEP_DGRAD, INST_WGRAD16_FUSED, INST_WGRAD16_PLAIN, INST_WGRAD_DEEP, INST_COUNT };
 struct FamilySink {
     std::vector<hipEvent_t> ev;            // pairs, reused
     std::vector<int> fam;                  // family of pair i
+    std::vector<int> inst;                 // instance of pair i (-1: none)
     size_t used = 0;
     ~FamilySink() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 static thread_local FamilySink* t_sink = nullptr;
 static thread_local int t_hint_c = 16;     // channel count of the level being walked (conv / weight-gradient family split)
+static thread_local int t_hint_inst = -1;  // instance of the NEXT launch (INST_*), reset by it
 // RU_FUSE_BATCH_WREDUCE: the running backward's queues of weight-gradient reductions -- one per stream the partials are produced on
 // (the side stream's are flushed on the side stream before the join, in the shadow of the chain; the caller's stream's at the end)
 struct RedQueues { WgradRedList main, side; hipStream_t side_stream = nullptr; };
@@ -113,8 +118,10 @@ static void sink_begin(const char* call, hipStream_t s) {
         if (hipEventCreate(&e) != hipSuccess) return;
         k.ev.push_back(e);
     }
-    if (k.fam.size() < k.ev.size() / 2) k.fam.resize(k.ev.size() / 2);
+    if (k.fam.size() < k.ev.size() / 2) { k.fam.resize(k.ev.size() / 2); k.inst.resize(k.ev.size() / 2); }
     k.fam[k.used / 2] = family_of(call);
+    k.inst[k.used / 2] = t_hint_inst;
+    t_hint_inst = -1;
     (void)hipEventRecord(k.ev[k.used], s);
 }
 static void sink_end(hipStream_t s) {
@@ -404,7 +411,8 @@ extern "C" int ru_unet_probe(ru_unet_t h, int enable) {
     return RU_OK;
 }
 extern "C" int ru_unet_probe_read_families(ru_unet_t h, double* ms, int* launches, int nfam) {
-    RU_REQUIRE(h && ms && launches && nfam == ru::FAM_COUNT, "ru_unet_probe_read_families: %d families", (int)ru::FAM_COUNT);
+    RU_REQUIRE(h && ms && launches && (nfam == ru::FAM_COUNT || nfam == ru::FAM_COUNT + ru::INST_COUNT),
+               "ru_unet_probe_read_families: %d families (+ %d instance rows behind them)", (int)ru::FAM_COUNT, (int)ru::INST_COUNT);
     for (int f = 0; f < nfam; ++f) { ms[f] = 0.0; launches[f] = 0; }
     if (!h->sink) return RU_OK;
     ru::FamilySink& k = *h->sink;
@@ -416,6 +424,8 @@ extern "C" int ru_unet_probe_read_families(ru_unet_t h, double* ms, int* launche
         if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime(family probe)");
         ms[k.fam[i / 2]] += t;
         launches[k.fam[i / 2]] += 1;
+        const int in = k.inst[i / 2];
+        if (in >= 0 && ru::FAM_COUNT + in < nfam) { ms[ru::FAM_COUNT + in] += t; launches[ru::FAM_COUNT + in] += 1; }
     }
     k.used = 0;
     return RU_OK;
@@ -521,6 +531,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
     a.stat_partials = partials;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
     a.in_c16 = h->c16 && x_c16; a.out_c16 = h->c16; a.in_c4 = x_c4;
+    a.products = 2;          // a FORWARD convolution: its input is an activation tensor, so the shapes that have the kernel take the fp16 + MX-fp8 scheme (conv3_mx.hpp; RU_MX=0: never)
     const bool probed = h->probe_on && !A.dry && h->c16 && x_c16 && !x_c4 && Cin == 16 && Cout == 16 && D == h->D && H == h->H && W == h->W;
     if (probed) {
         while (h->probe_ev.size() < h->probe_used + 2) {
@@ -550,6 +561,7 @@ static int conv3_gn(ru_unet* h, Arena& A, hipStream_t s, const float* x, const f
         RU_RUN(sum_partials_launch(part, ksplit, nel, y, s));
         RU_RUN(gn_stats_launch(y, partials, N, Cout, (size_t)D * H * W, s));
     } else {
+        t_hint_inst = (a.in_c16 && a.out_c16) ? (Cin == 16 && Cout == 16 ? INST_CONV16_FWD : (Cin >= 32 ? INST_CONV_DEEP_FWD : -1)) : -1;
         RU_RUN(conv3_launch(a, s));
     }
     if (probed) {
@@ -636,7 +648,10 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
     // fused statistics / staging-side GroupNorm + LeakyReLU / coarse-grid 1x1 / no concat as the split-bf16 flow (BASELINE configs[1]; the exact-f32
     // training path keeps the NCDHW kernels: its weight gradients exist there only).  RU_F32C=0: the NCDHW flow for the f32 forward too (A/B).
     static const bool f32c_off = [] { const char* e = getenv("RU_F32C"); return e && *e == '0'; }();
-    h->c16 = (h->precision == RU_PREC_BF16X3 || (h->precision == RU_PREC_F32 && !h->training && !f32c_off)) && (h->W & 3) == 0;
+    // (conv3_f32c_kernel addresses a 16-channel block of its input through 32-bit byte offsets and has no other kernel to fall back to: whole-volume
+    // exact-f32 inference at 2^25 voxels and more, ~322^3, keeps the NCDHW flow; the split-bf16 kernels choose the one-stage kernel there themselves)
+    const bool f32c_fits = (size_t)h->D * h->H * h->W * 64 < ((size_t)1 << 31);
+    h->c16 = (h->precision == RU_PREC_BF16X3 || (h->precision == RU_PREC_F32 && !h->training && !f32c_off && f32c_fits)) && (h->W & 3) == 0;
     for (int c : h->ch) h->c16 = h->c16 && (c % 16 == 0);
     h->pack = A.alloc(h->pk_total);
     h->fpack = reinterpret_cast<char*>(A.alloc(h->fk_total / sizeof(float) + 64));
@@ -863,6 +878,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
         w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = kSlope;
         w.gb_out = const_cast<float*>(dy); w.dy_s16 = 0;
     }
+    t_hint_inst = (x_c16 && dy_c16) ? (Cin == 16 && Cout == 16 ? (gb ? INST_WGRAD16_FUSED : INST_WGRAD16_PLAIN) : (Cin >= 32 ? INST_WGRAD_DEEP : -1)) : -1;
     RU_RUN(wgrad3_launch(w, s));
     return RU_OK;
 }
@@ -979,6 +995,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
             sums1.done = true;
         }
     }
+    t_hint_inst = c16 ? (C == 16 ? INST_CONV16_DGRAD : INST_CONV_DEEP_DGRAD) : -1;
     RU_RUN(conv3_launch(d2, s));
     float* dy1 = A.alloc((size_t)N * C * V);
     rc = gn_bwd(h, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, fuse1 ? &sums1 : nullptr,
@@ -1004,6 +1021,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
             nx->out.done = true;
         }
     }
+    t_hint_inst = c16 ? (C == 16 ? INST_CONV16_DGRAD : INST_CONV_DEEP_DGRAD) : -1;
     RU_RUN(conv3_launch(d1, s));
     if (bp.down < 0) { *dxprev_out = dx; return RU_OK; }
     // down-sampling conv backward (Appendix A2): 1x1 over the space-to-depth view
@@ -1707,6 +1725,7 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     void* wf = C.take(conv3_sb_frag_bytes(Cin, Cout) / 4 + 64);
     RU_WS_OK(C);
     const bool f32 = (flags & 16) != 0;                          // exact-f32 arithmetic on voxel-major tensors (conv3_f32c_kernel)
+    a.products = (flags & 32) ? 2 : 0;                           // the input is an activation tensor: fp16 + MX-fp8 products where the shape has that kernel (conv3_mx.hpp)
     RU_REQUIRE(!f32 || ((flags & 3) != 0 && !(flags & (4 | 8))), "ru_conv3d_fwd_l: the exact-f32 form needs a voxel-major side and takes neither the 4-channel copy nor a split-form input");
     int rc = f32 ? conv3_f32c_pack_weights(w, wf, Cin, Cout, 0, s) : conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s);
     if (rc) return rc;

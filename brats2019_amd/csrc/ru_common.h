@@ -138,6 +138,8 @@ struct Conv3Args {
     float bst_slope;
     // MFMA products per operand pair in split-bf16 mode: 0 / 3 = hi*hi + lo*hi + hi*lo; 1 = hi*hi only (plain bf16 operands: the engine's
     // gradient precision RU_PREC_BF16).  Honoured by the persistent voxel-major kernel; every other kernel keeps three products.
+    // 2 = the input is an ACTIVATION tensor (a forward convolution) and may take the fp16 + MX-fp8 scheme (conv3_mx.hpp: f16*f16 + e4m3 cross terms on
+    // v_mfma_scale_f32_16x16x128_f8f6f4) where a kernel for the shape exists; elsewhere it means three products.  Never set for gradient inputs.
     int products;
     // Split-K of the exact-f32 kernel (small shapes: fewer workgroups than two per CU, each walking ALL input-channel chunks with the
     // load latency of every chunk exposed): ksplit > 1 workgroups share a (tile, cout block), each sums CinP / ksplit input channels and

@@ -102,13 +102,21 @@ class UNetEngine:
         kernel); 2 = around EVERY launch, booked per kernel family (probe_read_families)."""
         L.check(L.load().ru_unet_probe(self.h, int(enable)), "ru_unet_probe")
 
-    def probe_read_families(self):
-        """-> {family: (total_ms, launches)} since the last read (ru_unet_probe_read_families); waits for the recorded events."""
+    # single kernel instantiations the executor tags (engine.hip INST_*): rows BEHIND the families in ru_unet_probe_read_families
+    INSTANCES = ("conv16_fwd", "conv16_dgrad", "conv_deep_fwd", "conv_deep_dgrad", "wgrad16_fused_apply", "wgrad16_plain", "wgrad_deep")
+
+    def probe_read_families(self, instances=False):
+        """-> {family: (total_ms, launches)} since the last read (ru_unet_probe_read_families); waits for the recorded events.
+        instances=True: (families, {instance: (total_ms, launches)}) -- the tagged launches are booked to their family AND to their instance."""
         import ctypes
-        n = len(self.FAMILIES)
+        names = self.FAMILIES + (self.INSTANCES if instances else ())
+        n = len(names)
         ms, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
         L.check(L.load().ru_unet_probe_read_families(self.h, ms, cnt, n), "ru_unet_probe_read_families")
-        return {f: (ms[i], cnt[i]) for i, f in enumerate(self.FAMILIES)}
+        got = {f: (ms[i], cnt[i]) for i, f in enumerate(names)}
+        if not instances:
+            return got
+        return {f: got[f] for f in self.FAMILIES}, {f: got[f] for f in self.INSTANCES}
 
     def probe_read(self):
         """-> (total_ms, launches) since the last read; waits for the recorded events (ru_unet_probe_read)."""

@@ -302,7 +302,7 @@ class UNet(nn.Module):
     def _drop_param_caches(self):
         """anything that can REPLACE nn.Parameter objects (load_state_dict(assign=True), an overwrite-on-conversion _apply, re-registration):
         the cached parameter list, its end pointers and the alias check are rebuilt from named_parameters() on the next forward"""
-        for k in ("_flat_checked", "_flat_ends", "_params_cached"):
+        for k in ("_flat_checked", "_flat_ends", "_params_cached", "_param_slots"):
             self.__dict__.pop(k, None)
 
     def load_state_dict(self, *args, **kwargs):                   # writes through the aliased flat buffer in place (assign=True: new Parameters)
@@ -312,15 +312,6 @@ class UNet(nn.Module):
             return super().load_state_dict(*args, **kwargs)
         finally:
             self._drop_param_caches()
-
-    def register_parameter(self, name, param):
-        self._drop_param_caches()
-        return super().register_parameter(name, param)
-
-    def __setattr__(self, name, value):
-        if isinstance(value, nn.Parameter):
-            self._drop_param_caches()
-        return super().__setattr__(name, value)
 
     def _param_order(self):
         self._get_engine()
@@ -336,9 +327,25 @@ class UNet(nn.Module):
     def _param_list(self):
         """the nn.Parameter objects in state-dict order (they outlive .cuda() / load_state_dict: only their .data moves)"""
         lst = self.__dict__.get("_params_cached")
+        if lst is not None:
+            # every nn.Parameter of this network lives in a SUBMODULE (Conv3d, GroupNorm), so a re-registration there -- `net.conv_output.weight = nn.Parameter(...)` --
+            # never passes through this module's own register_parameter / __setattr__: the cached objects are checked against the submodules' parameter
+            # dictionaries by identity on every use (93 dictionary look-ups, a few microseconds; named_parameters() itself walks the module tree)
+            for (d, k), p in zip(self.__dict__["_param_slots"], lst):
+                if d.get(k) is not p:
+                    self._drop_param_caches()
+                    lst = None
+                    break
         if lst is None:
-            lst = [p for _, p in self.named_parameters()]
+            lst, slots = [], []
+            for mod in self.modules():
+                for k, p in mod._parameters.items():
+                    if p is not None:
+                        slots.append((mod._parameters, k))
+                        lst.append(p)
+            assert len(lst) == len(list(self.parameters())) and all(a is b for a, b in zip(lst, self.parameters())), "parameter walk out of state-dict order"
             self.__dict__["_params_cached"] = lst
+            self.__dict__["_param_slots"] = slots
             self.__dict__.pop("_flat_checked", None)             # a new list: the alias check walks all of it once
         return lst
 
@@ -346,10 +353,10 @@ class UNet(nn.Module):
         """One flat float32 device buffer aliased by every nn.Parameter (re-built if .to()/.cuda() broke the aliasing)."""
         eng = self._get_engine()
         flat = self.__dict__.get("_flat_buf")
+        lst = self._param_list()                                  # (drops `_flat_checked` when a Parameter object was replaced since the last forward)
         if flat is not None and self.__dict__.get("_flat_checked"):
             # steady state (a forward per step or per tile): the full walk over 93 pointers ran once after the last move; between moves only
             # the first and last parameter are looked at (an optimizer updates in place; `p.data = ...` on a middle tensor is not a supported move)
-            lst = self._param_list()
             first, last = self.__dict__["_flat_ends"]
             if lst[0].data_ptr() == first and lst[-1].data_ptr() == last:
                 return flat
@@ -389,7 +396,7 @@ class UNet(nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads", "_flat_checked", "_flat_ends", "_params_cached"):     # never pickle the ctypes handle / the alias buffer
+        for k in ("_engine_obj", "_flat_buf", "_param_names", "_last_flat_grads", "_flat_checked", "_flat_ends", "_params_cached", "_param_slots"):     # never pickle the ctypes handle / the alias buffer
             state.pop(k, None)
         return state
 

@@ -389,9 +389,14 @@ def init_process_groups_with_fallback(prefer="nccl", inject_failure=False, timeo
         if inject_failure:
             raise RuntimeError("injected RCCL failure (RU_BENCH_INJECT_RCCL_FAIL=1): ncclCommInitRank would have failed here")
         torch.cuda.set_device(local if device_index is None else device_index)      # the health check's tensor and the RCCL communicator live on this rank's GPU
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        # the data group keeps torch's normal collective timeout for the run; only the HEALTH CHECK is bounded by timeout_s (a rank that died before the
+        # check leaves the others waiting here: they give up after timeout_s and fall back; a watchdog abort later in the run still ends the ranks, and
+        # only the bare launcher's fresh gloo set covers that case -- bench.self_launch)
+        group = dist.new_group(backend="nccl")
         t = torch.ones(1, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if not work.wait(datetime.timedelta(seconds=timeout_s)):
+            raise RuntimeError("RCCL health check: the all-reduce did not complete within %d s" % timeout_s)
         torch.cuda.synchronize()
         if float(t.item()) != float(world):
             raise RuntimeError("RCCL health check: all-reduce of ones over %d ranks returned %r" % (world, float(t.item())))

@@ -203,8 +203,13 @@ int ru_unet_probe_read(ru_unet_t h, double* total_ms, int* launches);
  * same at the deeper levels, 2 / 3 3x3x3 weight gradients likewise, 4 GroupNorm passes (apply, backward reduce / apply, finalizes),
  * 5 1x1 / 2x2x2 convolutions, their weight gradients and the trilinear kernels, 6 everything else (weight packing, fills, head
  * gradient, partial-sum reductions of the weight gradients).  ms[f] = summed duration, launches[f] = count since the last read.
- * The event records cost ~1 us per launch: use it in probe steps, not in a timed region. */
+ * The event records cost ~1 us per launch: use it in probe steps, not in a timed region.
+ * nfam = RU_PROBE_FAMILIES + RU_PROBE_INSTANCES additionally returns, behind the families, the launches that are ONE kernel instantiation worth naming
+ * (bench.py's `roofline_top`; each is booked to its family as well): 0 / 1 the 16 -> 16 voxel-major 3x3x3 convolution forward / data gradient, 2 / 3 the
+ * 32..128-channel ones, 4 the 16-channel level's weight gradient with the GroupNorm-backward apply fused into its staging, 5 the one without, 6 the
+ * 32..128-channel weight gradients. */
 #define RU_PROBE_FAMILIES 7
+#define RU_PROBE_INSTANCES 7
 int ru_unet_probe_read_families(ru_unet_t h, double* ms, int* launches, int nfam);
 int ru_unet_param_count(ru_unet_t h);
 const char* ru_unet_param_name(ru_unet_t h, int i);          /* state_dict key */
@@ -316,7 +321,9 @@ int ru_paste_labels(const unsigned char* lab, unsigned char* full, int D, int H,
  * entry points below exist so the tests and probes can drive the layout-aware kernels one at a time.
  * flags: bit 0 = x (input) is C16, bit 1 = y (output) is C16, bit 2 = x is NCDHW with Cin <= 4 and goes through the 4-channel
  * tap-pair kernel (needs extra workspace: 16 bytes per input voxel); bit 3 = x is voxel-major in SPLIT form (hi / lo bf16 packets); bit 4 = exact-f32
- * arithmetic (v_mfma_f32_16x16x4_f32 on voxel-major tensors: the exact-f32 inference forward of the engine; not with bits 2 / 3).  k = 3. */
+ * arithmetic (v_mfma_f32_16x16x4_f32 on voxel-major tensors: the exact-f32 inference forward of the engine; not with bits 2 / 3); bit 5 = x is an
+ * ACTIVATION tensor (a forward convolution, model.py:72-73): shapes that have the kernel (16 input channels, voxel-major both sides, a grid that fills the
+ * chip) take the fp16 + MX-fp8 product scheme the engine's forward convolutions take (f16*f16 + two e4m3 cross terms, RU_MX=0: off); never set for gradients.  k = 3. */
 int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int to_c16, ru_stream_t stream);
 int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y,
                     int N, int Cin, int Cout, int D, int H, int W, int flags,

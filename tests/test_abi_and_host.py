@@ -331,6 +331,15 @@ def test_unet_parameter_cache_follows_replaced_parameters():
         torch.__future__.set_overwrite_module_params_on_conversion(False)
     assert all(a is b for a, b in zip(net._param_list(), net.parameters()))
     assert "_flat_checked" not in net.__dict__ and "_flat_ends" not in net.__dict__
+    # round-5 advisor finding: every Parameter lives in a SUBMODULE, so re-registering one there never passes through UNet's own hooks -- the cached list is
+    # checked against the submodules' parameter dictionaries by identity on every use
+    net.float()
+    held = net._param_list()
+    net.__dict__["_flat_checked"] = True                     # (as after a forward)
+    net.conv_output.weight = torch.nn.Parameter(torch.zeros_like(net.conv_output.weight))
+    now = net._param_list()
+    assert all(a is b for a, b in zip(now, net.parameters())) and any(a is not b for a, b in zip(held, now))
+    assert "_flat_checked" not in net.__dict__
 
 
 def test_bench_roofline_bookkeeping():

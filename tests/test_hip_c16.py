@@ -112,6 +112,60 @@ def test_conv3_winograd_z_against_float64(shape):
         assert res[tag][0] <= 6e-5 and res[tag][0] <= 1.5 * res["direct"][0] + 1e-6, (tag, res)
 
 
+MX_SHAPES = [(2, 16, 16, 64, 64, 64), (1, 16, 16, 40, 60, 72), (3, 16, 32, 32, 32, 48), (1, 16, 16, 128, 128, 128)]
+
+
+@pytest.mark.parametrize("shape", MX_SHAPES, ids=["%dx%d-%d_%dx%dx%d" % s for s in MX_SHAPES])
+def test_conv3_mx_against_float64(shape):
+    """conv3_mx_kernel (the 16-channel level's forward convolutions, model.py:72-73 as used by model.py:89-91: f16 * f16 on v_mfma_f32_16x16x32_f16 plus both
+    cross terms in e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4) against a float64 convolution of the same fp32 operands: max error / output RMS within 1.2e-4
+    (CPU emulation tools/mx_gate.py: ~2x the three-product kernel's error) and within 4x of what the three-product kernel leaves on the same inputs.
+    Shapes: whole tiles, ragged extents with zero padding on every face and several samples per workgroup run, two output-channel groups, the z-walk shape
+    of the network (1 x 128^3).  RU_MX=0 and a launch that does not declare its input an activation tensor both keep the three-product kernel, bit for bit."""
+    import os
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = shape
+    x = _rand(n, cin, d, h, w, seed=21)
+    x = torch.where(x > 0, x, 0.01 * x) * 1.3 + 0.1                     # an activated GroupNorm output
+    wt = _rand(cout, cin, 3, 3, 3, seed=22) * float((2.0 / (cin * 27)) ** 0.5)
+    ref = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), padding=1)
+    rms = float(ref.pow(2).mean().sqrt())
+    x16 = ops.to_c16(x)
+    y_mx = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True, activations=True))
+    y_sb = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True))
+    os.environ["RU_MX"] = "0"
+    try:
+        y_off = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True, activations=True))
+    finally:
+        os.environ.pop("RU_MX", None)
+    e_mx = float((y_mx.double().cpu() - ref).abs().max()) / rms
+    e_sb = float((y_sb.double().cpu() - ref).abs().max()) / rms
+    print("  %s: max error / rms  fp16 + MX-fp8 %.2e  three bf16 products %.2e" % (shape, e_mx, e_sb))
+    assert torch.equal(y_off, y_sb), "RU_MX=0 did not keep the three-product kernel"
+    assert not torch.equal(y_mx, y_sb), "the shape did not take conv3_mx_kernel"
+    assert e_mx <= 1.2e-4 and e_mx <= 4 * e_sb + 1e-6, (e_mx, e_sb)
+
+
+def test_conv3_mx_saturates_instead_of_nan():
+    """Activations beyond the e4m3 range of the cross terms (|x| > 448, and residuals beyond 448 / 2^11) must degrade the cross terms, never poison the output:
+    the staging waves run with MODE.FP16_OVFL, under which v_cvt_pk_fp8_f32 / v_cvt_pk_f16_f32 saturate (tools/mx_ovfl_probe.hip; without it the e4m3
+    conversion returns NaN above 464).  A tensor with a few 1e3 .. 6e4 outliers: finite everywhere, and never worse than ONE fp16 product would be (2^-11 of the
+    largest output: the main term stays exact to fp16 rounding, what saturates is the correction to it)."""
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = 1, 16, 16, 32, 64, 64
+    x = _rand(n, cin, d, h, w, seed=23)
+    flat = x.view(-1)
+    idx = torch.arange(0, flat.numel(), 40009, device=x.device)
+    flat[idx] = torch.linspace(1e3, 6e4, idx.numel(), device=x.device) * torch.where(idx % 2 == 0, 1.0, -1.0)
+    wt = _rand(cout, cin, 3, 3, 3, seed=24) * float((2.0 / (cin * 27)) ** 0.5)
+    ref = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), padding=1)
+    y = ops.from_c16(ops.conv3d_layout(ops.to_c16(x), wt, in_c16=True, out_c16=True, activations=True))
+    assert bool(torch.isfinite(y).all())
+    rel = float((y.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    print("  outliers: max error / max |y| %.2e" % rel)
+    assert rel <= 2.0 ** -11, rel
+
+
 @pytest.mark.parametrize("x16,dy16", [(True, True), (True, False), (False, True)])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 16, 32, 32), (1, 32, 32, 16, 16, 32), (2, 16, 32, 8, 16, 16)])
 def test_wgrad3_layouts_equal_ncdhw(shape, x16, dy16):

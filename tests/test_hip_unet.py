@@ -896,21 +896,24 @@ class _BucketAsModule:
         return iter(self._items)
 
 
-def test_data_parallel_step_128_matches_reference_fixture(golden):
+@pytest.mark.parametrize("fixture,batch,seed", [("unet128_train", 2, 2024), ("unet128_train_b4", 4, 31337)], ids=["batch2", "batch4_configs2"])
+def test_data_parallel_step_128_matches_reference_fixture(golden, fixture, batch, seed):
     """The BENCHMARKED entry point -- parallel.DataParallelStep.loss_and_grads with its defaults (ru_unet_forward, ru_criterion_sums,
     ru_unet_backward_criterion with the criterion's gradient formed inside the head pass, all backward fusions on) -- held DIRECTLY to the
     reference's own 128^3 training step (train.py:201-210 around model.py / loss.py:76-79,114-122; unet128_train.npz: loss, Dice, BCE,
     probabilities, mask, every gradient norm, projections of every parameter gradient, seven full conv-weight gradients) at the bars of
-    test_unet128_train_step_bf16x3_matches_reference_fixture.  No autograd, no second criterion entry in between."""
+    test_unet128_train_step_bf16x3_matches_reference_fixture.  No autograd, no second criterion entry in between.
+    batch4_configs2 (round 6): BASELINE configs[2] ITSELF -- batch 4 x 128^3, the configuration bench.py's headline is quoted on -- against the reference's own
+    step at that batch (unet128_train_b4.npz: loss, Dice, BCE, probabilities, mask, every gradient norm / projection / strided samples, the small tensors in full)."""
     from brats2019_amd import parallel as P
-    g = golden("unet128_train")
+    g = golden(fixture)
     be = P.HipBackend(cfg=O.DEFAULT_CFG)
     assert be.engine.precision == "bf16x3"
     flat = be.new_flat()
     for k, v in be.engine.layout.views(flat).items():
-        v.copy_(T(O.make_params(2024, **O.DEFAULT_CFG)[k]))
-    x = T(O.make_input(2, 128, 128, 128, seed=2024)).cuda()
-    tgt = T(O.make_target(2, 128, 128, 128, seed=2024)).cuda()
+        v.copy_(T(O.make_params(seed, **O.DEFAULT_CFG)[k]))
+    x = T(O.make_input(batch, 128, 128, 128, seed=seed)).cuda()
+    tgt = T(O.make_target(batch, 128, 128, 128, seed=seed)).cuda()
     st = P.DataParallelStep(be, flat)
     assert st.fuse_criterion_grad
     loss, dice, bce = st.loss_and_grads(x, tgt)
