@@ -9,7 +9,7 @@ A "step" is one data-parallel training step on synthetic 128^3 4-modality crops,
 configs[2]/[3]; weak scaling): UNet forward + Dice/BCE criterion + backward + RCCL all-reduce of the criterion
 sums and of the flat gradient buffer + Adam(amsgrad) -- every kernel hand-written HIP behind the C-ABI.  Inputs
 are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=1 it also carries
-  roofline     : the dominant kernel (the 16->16 3x3x3 conv at 4 x 128^3: conv3_sb2_kernel on voxel-major tensors in the default
+  roofline     : the dominant kernel (the 16->16 3x3x3 forward conv at 4 x 128^3: conv3_mx_kernel -- fp16 + MX-fp8 products -- on voxel-major tensors in the default
                  split-bf16 mode, conv3_f32_kernel with --precision f32) timed live with HIP events on the launch stream -- in place, around
                  its launches inside further steps of the timed workload (ru_unet_probe; `hot_loop_ms` = the same kernel in a loop of 20):
                  algorithmic bytes / average launch time vs the HBM peak (split-bf16: the memory side limits, see the comment in
@@ -30,7 +30,9 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   roofline_families : ms per step of every kernel family (3x3x3 conv / weight gradient at the 16-channel level and deeper, GroupNorm passes,
                  1x1 / stride-2 / up-sampling kernels) timed in place, next to the family's algorithmic FLOPs / bytes and its roofline bound
                  (GroupNorm: the achievable-fusion bound -- the passes that cannot ride on a convolution for fp32 tensors),
-  roofline_top : the three largest families of the step, each with launches, average launch time and fraction of its own bound,
+  roofline_top : the three largest families of the step, each with launches, average launch time and fraction of its own bound, followed by the three
+                 largest SINGLE kernel instantiations (rows with "instance": the executor tags their launches, ru_unet_probe_read_families) with algorithmic
+                 FLOPs / bytes, the bytes the kernel really moves (committed counter table) and both fractions,
   whole_step_frac : the step against the per-layer roofline priced on ALGORITHMIC FLOPs (`_executed`: on the three split-bf16 products;
                  `_achievable` / `whole_step_achievable`: plus the bytes no fusion removes for fp32 tensors -- achievable_bounds),
 and at N > 1
@@ -211,6 +213,89 @@ def committed_family_table():
     return {"source": "profiles/%s (rocprofv3 --pmc passes on tools/conv_probe.py, committed; not measured in this run)" % os.path.basename(files[-1]), "rows": rows}
 
 
+def committed_step_traffic():
+    """{kernel name: (calls per step, HBM GB per step)} from the newest profiles/r*_step_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the training
+    step, tools/step_traffic.sh): the bytes a kernel REALLY moves, committed numbers -- not measured in this run.  None when no table is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_traffic.txt")))
+    if not files:
+        return None
+    rows = {}
+    for ln in open(files[-1]):
+        m = re.match(r"^(\S.*?)\s+(\d+\.\d+)\s+(\d+\.\d+)\s+(\d+\.\d+)\s+(\d+\.\d+)\s+(\d+\.\d+)\s*$", ln.rstrip("\n"))
+        if m and not ln.startswith(("#", "TOTAL")):
+            rows[m.group(1).strip()] = (float(m.group(2)), float(m.group(6)))
+    return {"file": os.path.relpath(files[-1], ROOT), "rows": rows}
+
+
+# single kernel instantiations the executor tags (engine.py INSTANCES): kernel name, the rows of the step-traffic table that are this instance, and its
+# algorithmic work per step as (level -> launches per step); level l has 16 * 2^l channels on a (size / 2^l)^3 grid
+INSTANCE_INFO = {
+    "conv16_fwd": ("conv3_mx_kernel (3x3x3 conv 16->16 forward: fp16 + MX-fp8 products; RU_MX=0: conv3_sb2_kernel<4,8,true,true,false,false,false,3,false>)",
+                   (r"^ru::conv3_mx_kernel", r"^ru::conv3_sb2_kernel<4, 8, true, true, false, false, false, 3, false>"), {0: 4}),
+    "conv16_dgrad": ("conv3_sb2_kernel<4,8,true,true,false,BST,ADD,3,false> (3x3x3 data gradient 16->16, split-form input, GroupNorm-backward sums / residual in the epilogue)",
+                     (r"^ru::conv3_sb2_kernel<4, 8, true, true, false, (true, false|true, true|false, true), 3, false>",), {0: 4}),
+    "conv_deep_fwd": ("conv3_wz32_kernel (3x3x3 conv forward, 32-128 channels: Winograd F(2,3) along z on 32x32x16 MFMAs)", (r"^ru::conv3_wz32_kernel",), {1: 6, 2: 6, 3: 8}),
+    "conv_deep_dgrad": ("conv3_sb2_kernel<4,8,true,true,true,BST,ADD,3,false> (3x3x3 data gradient, 32-128 channels)", (r"^ru::conv3_sb2_kernel<4, 8, true, true, true,",), {1: 6, 2: 6, 3: 8}),
+    "wgrad16_fused_apply": ("wgrad3_tz_kernel<1,0,3,3> (3x3x3 weight gradient 16->16 with the GroupNorm-backward apply fused into its dy staging)", (r"^ru::wgrad3_tz_kernel<1, 0, 3, 3>",), {0: 4}),
+    "wgrad16_plain": ("wgrad3_tz_kernel<1,0,...> (3x3x3 weight gradient 16->16, plain dy)", (r"^ru::wgrad3_tz_kernel<1, 0, [012], 3>",), {0: 4}),
+    "wgrad_deep": ("wgrad3_tz_kernel<2,0,1,3> (3x3x3 weight gradient, 32-128 channels)", (r"^ru::wgrad3_tz_kernel<2, 0, 1, 3>",), {1: 6, 2: 6, 3: 8}),
+}
+
+
+def instance_bounds(batch, size):
+    """Algorithmic work per STEP of every tagged instantiation: FLOPs = 2 * 27 * C^2 * voxels per launch; bytes = the two fp32 tensors a launch must touch (input +
+    output of a convolution, x + dy of a weight gradient) -- SURVEY 8(d)'s per-layer figures."""
+    out = {}
+    for name, (_, _, levels) in INSTANCE_INFO.items():
+        gf = gb = 0.0
+        n = 0
+        for lvl, cnt in levels.items():
+            c, vox = 16 << lvl, batch * (size >> lvl) ** 3
+            gf += cnt * 2.0 * 27 * c * c * vox / 1e9
+            gb += cnt * 2.0 * c * vox * 4 / 1e9
+            n += cnt
+        out[name] = {"gflop": gf, "gbytes": gb, "launches": n}
+    return out
+
+
+def instance_rows(inst, names, steps, batch, size, precision):
+    """Rows of `roofline_instances` from {instance: (total ms, launches)} over `steps` steps: the tagged launches priced on their algorithmic work (instance_bounds)
+    AND on the bytes they really move (committed_step_traffic; used only when the table's call count matches the launches seen)."""
+    import re
+    ib, traffic = instance_bounds(batch, size), committed_step_traffic()
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3" else F32_MFMA_PEAK_TFLOPS
+    krows = []
+    for name in names:
+        ms, n = inst[name]
+        if not n:
+            continue
+        ms /= steps
+        kname, pats, _ = INSTANCE_INFO[name]
+        b = ib[name]
+        moved = None
+        if traffic:
+            for p_ in pats:                                  # the first pattern that matches anything wins: conv16_fwd lists the kernel of either product scheme
+                hit = [v for k, v in traffic["rows"].items() if re.search(p_, k)]
+                if hit:
+                    if abs(sum(v[0] for v in hit) - n // steps) < 0.5:
+                        moved = sum(v[1] for v in hit)
+                    break
+        t_flop = b["gflop"] / (peak * 1e3) * 1e3            # ms at the dense MFMA peak
+        t_alg = max(t_flop, b["gbytes"] / HBM_PEAK_GBPS * 1e3)
+        row = {"row": "kernel", "instance": name, "kernel": kname, "launches_per_step": n // steps, "avg_launch_us": round(1e3 * ms / (n // steps), 2), "ms_per_step": round(ms, 3),
+               "algorithmic_gflop_per_step": round(b["gflop"], 1), "algorithmic_gbytes_per_step": round(b["gbytes"], 3), "bound_ms_algorithmic": round(t_alg, 3),
+               "frac_algorithmic": round(t_alg / ms, 4) if ms > 0 else None, "moved_gbytes_per_step": round(moved, 3) if moved is not None else None}
+        if moved is not None:
+            t_mov = max(t_flop, moved / HBM_PEAK_GBPS * 1e3)
+            row["bound_ms_moved"] = round(t_mov, 3)
+            row["frac_moved"] = round(t_mov / ms, 4) if ms > 0 else None
+            row["moved_source"] = traffic["file"] + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of the training step, committed; not measured in this run)"
+        krows.append(row)
+    return krows
+
+
 def synth(n, size, seed, device):
     rng = np.random.default_rng(seed)
     x = torch.from_numpy(rng.standard_normal((n, 4, size, size, size), dtype=np.float32)).to(device)
@@ -295,7 +380,7 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
     for _ in range(steps):
         one_step()
     torch.cuda.synchronize()
-    got = eng.probe_read_families()
+    got, inst = eng.probe_read_families(instances=True)
     eng.probe(False)
     eng.set_fusion(True, True, side_stream=True)
     bounds = family_bounds(batch, size, precision)
@@ -320,7 +405,7 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
             row["frac_algorithmic"] = round(b["bound_ms_algorithmic"] / ms, 4) if ms > 0 else None
             row["frac_executed"] = round(b["bound_ms_executed"] / ms, 4) if ms > 0 else None
         out.append(row)
-    kernels = {"conv3_l0": "conv3_sb2_kernel<4,8,C16,C16,one chunk> + conv3_sb2c4_kernel (3x3x3 fwd / data gradient, 16-channel level)",
+    kernels = {"conv3_l0": "conv3_mx_kernel (16->16 forward) + conv3_sb2_kernel<4,8,C16,C16,one chunk> (data gradient, head) + conv3_sb2c4_kernel (stem, head gradient): 3x3x3 convs of the 16-channel level",
                "conv3_deep": "conv3_wz32_kernel (forward: Winograd-z on 32x32x16 MFMAs) + conv3_sb2_kernel<4,8,C16,C16,MULTI> (data gradient), 32-128 channels",
                "wgrad3_l0": "wgrad3_tz_kernel<1,...> (3x3x3 weight gradient + fused GroupNorm-backward apply, 16-channel level)",
                "wgrad3_deep": "wgrad3_tz_kernel<2,0,1> (3x3x3 weight gradient, 32-128 channels)",
@@ -335,7 +420,12 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
                     "algorithmic_gflop_per_step": row["algorithmic_gflop"], "algorithmic_gbytes_per_step": row["algorithmic_gbytes"],
                     "bound_ms": round(bound, 3), "frac": round(bound / row["ms_per_step"], 4) if row["ms_per_step"] > 0 else None,
                     "bound": "max(algorithmic FLOPs / dense MFMA peak, fp32 in+out bytes / 8 TB/s) summed over the family's passes"})
-    return {"families": out, "top": top, "sum_ms": round(total, 3), "step_ms_unprobed": round(step_ms, 3), "probe_steps": steps,
+    krows = instance_rows(inst, eng.INSTANCES, steps, batch, size, precision)
+    krows.sort(key=lambda r: -r["ms_per_step"])
+    for r in top:
+        r["row"] = "family"
+    top = top + krows[:3]
+    return {"families": out, "top": top, "instances": krows, "sum_ms": round(total, 3), "step_ms_unprobed": round(step_ms, 3), "probe_steps": steps,
             "measured": "HIP event pairs around every launch of ru_unet_forward / ru_unet_backward in %d training steps after the timed region (ru_unet_probe(h, 2)), "
                         "with the side stream switched off so that no two kernels overlap (the timed step runs the deep-level weight gradients beside the chain: "
                         "its ms_per_step is smaller than this sum); criterion, Adam and collectives are outside the executor and not listed" % steps}
@@ -357,7 +447,8 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None, power_index
 
     def launch():
         if precision == "bf16x3":      # the kernel the engine runs: voxel-major (C16) input and output
-            L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3,
+            # flags: voxel-major in and out + bit 5 (the input is an activation tensor) -- what the engine's forward convolutions ask for: conv3_mx_kernel
+            L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3 | 32,
                                         L.ptr(ws), ws.numel(), L.stream()), "conv")
         else:
             L.check(lib.ru_conv3d_fwd_p(L.f32(x), L.f32(w), None, L.f32(y), batch, 16, 16, size, size, size, 3, L.PRECISIONS[precision],
@@ -389,20 +480,25 @@ def roofline_probe(batch, size, precision, launches=20, insitu=None, power_index
     abytes = 2 * 16 * batch * size ** 3 * 4
     gbps = abytes / (ms * 1e-3) / 1e9
     if precision == "bf16x3":
-        # The kernel sits on the ridge: executed MFMA work (3 products x 28/27 tap padding x algorithmic) at the dense bf16
-        # peak is 144 us for batch 4, the fp32 in+out traffic at 8 TB/s is 134 us.  Measured (profiles/r01_sb2_ablation.txt): the
-        # memory side limits -- loads alone 178 us, stores alone 137 us, MFMA loop alone 233-261 us, and doubling the consumer
-        # waves changed nothing -- so the roofline line is the HBM one (algorithmic bytes = input + output, fp32); the MFMA
-        # view is kept beside it (algorithmic flops, so <= 1/3.11 of the peak by construction, and the executed fraction).
-        return {"bound": "hbm", "kernel": "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)" % (batch, size),
+        # The kernel sits on the ridge.  Round 6: the engine's forward 16 -> 16 convolutions run conv3_mx_kernel -- per 27-tap x 16-channel chain 14 fp16 MFMAs
+        # (16x16x32) + 7 MX-fp8 MFMAs (16x16x128 at twice the rate) = 28 bf16-MFMA time units against the 13.5 of the algorithmic count (three bf16 products:
+        # 42); RU_MX=0 keeps conv3_sb2_kernel.  Measured (profiles/r06_notes.txt): the memory side limits -- the staging waves' loads cost the matrix waves
+        # ~75 us of a 322 us launch, their row stores ~50 -- so the roofline line is the HBM one (algorithmic bytes = input + output, fp32); the MFMA view is
+        # kept beside it (algorithmic flops, and the executed time units at the dense bf16 peak).
+        mx = os.environ.get("RU_MX", "1") != "0"
+        units = 28.0 / 13.5 if mx else 3.0 * 28 / 27
+        kname = ("conv3_mx_kernel (3x3x3 conv 16->16 forward, fp16 main product + two MX-fp8 cross products, %d x %d^3, voxel-major tensors)" if mx else
+                 "conv3_sb2_kernel<4,8,C16,C16> (3x3x3 conv 16->16 split-bf16 x3, %d x %d^3, voxel-major tensors)") % (batch, size)
+        return {"bound": "hbm", "kernel": kname,
                 "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "measured": how, "hot_loop_ms": round(hot_ms, 4),
                 "hot_loop_power": hot_power,
                 "algorithmic_bytes_per_launch": int(abytes),
                 "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_algorithmic_tflops": round(achieved, 2),
                 "mfma_algorithmic_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                "executed_mfma_tflops": round(achieved * 3 * 28 / 27, 2),
-                "executed_mfma_frac": round(achieved * 3 * 28 / 27 / BF16_MFMA_PEAK_TFLOPS, 4)}
+                "executed_mfma_tflops": round(achieved * units, 2),
+                "executed_mfma_frac": round(achieved * units / BF16_MFMA_PEAK_TFLOPS, 4),
+                "executed_mfma_note": "bf16-MFMA time units: an MX-fp8 16x16x128 instruction counts as two 16x16x32 ones (twice the K at twice the rate)"}
     return {"bound": "mfma", "kernel": "conv3_f32_kernel<4,8,8,1> (3x3x3 conv 16->16, %d x %d^3)" % (batch, size),
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(ms, 4), "measured": how, "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
@@ -897,7 +993,8 @@ def main():
         backend.engine.freeze_params(False)
         rf = roofline_families(backend, one_step, args.batch, args.size, args.precision, 1e3 * dt / args.steps, steps=min(3, args.probe_steps))
         if rank == 0:
-            out["roofline_top"] = rf.pop("top")       # the three largest kernel families of the step, each against its own roofline
+            out["roofline_top"] = rf.pop("top")       # the three largest kernel families of the step, each against its own roofline, then the three largest single instantiations
+            out["roofline_instances"] = rf.pop("instances")    # every tagged instantiation
             ft = committed_family_table()
             if ft is not None:
                 out["pmc_families"] = ft

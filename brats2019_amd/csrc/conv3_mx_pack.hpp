@@ -37,7 +37,11 @@ __device__ __forceinline__ unsigned mx_cvt4(float a, float b, float c, float d) 
 }
 __device__ __forceinline__ void mx_set_saturating_conversions() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }    // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
 
-// 8 values -> 4 dwords of fp16 (RNE), 2 dwords of e4m3(lo * 2^SX) and 2 dwords of e4m3(v)
+// 8 values -> 4 dwords of fp16 (RNE), 2 dwords of e4m3(lo * 2^SX) and 2 dwords of e4m3(v).  2.5 VALU per value (the bf16 split: 3): per pair one
+// v_cvt_pk_f16_f32, two v_fma_mix_f32 (lo = v - f16(v) straight from the packed half: exact; written as inline assembly because the compiler converts every
+// value a second time on its own -- v_cvt_f16_f32 + v_cvt_f32_f16 + v_sub_f32, 5.5 per value), one v_cvt_scalef32_pk_fp8_f32 (divides by its scale operand: the
+// 2^SX costs no multiply; bit-identical to multiply + v_cvt_pk_fp8_f32 incl. saturation and subnormals, tools/mx_cvt_probe.hip) and one v_cvt_pk_fp8_f32.
+typedef short mx_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mx_split8(const float (&t)[8], u32x4& h16, unsigned (&l8)[2], unsigned (&x8)[2]) {
     float lo[8];
 #pragma unroll
@@ -45,12 +49,19 @@ __device__ __forceinline__ void mx_split8(const float (&t)[8], u32x4& h16, unsig
         mx_f16x2 h;
         h[0] = (_Float16)t[2 * c];
         h[1] = (_Float16)t[2 * c + 1];
-        h16[c] = __builtin_bit_cast(unsigned, h);
-        lo[2 * c] = (t[2 * c] - (float)h[0]) * (float)(1 << MX_SX);
-        lo[2 * c + 1] = (t[2 * c + 1] - (float)h[1]) * (float)(1 << MX_SX);
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        h16[c] = hb;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * c]) : "v"(hb), "v"(t[2 * c]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * c + 1]) : "v"(hb), "v"(t[2 * c + 1]));
     }
-    l8[0] = mx_cvt4(lo[0], lo[1], lo[2], lo[3]); l8[1] = mx_cvt4(lo[4], lo[5], lo[6], lo[7]);
-    x8[0] = mx_cvt4(t[0], t[1], t[2], t[3]);     x8[1] = mx_cvt4(t[4], t[5], t[6], t[7]);
+    constexpr float inv = 1.f / (float)(1 << MX_SX);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(mx_s16x2{0, 0}, lo[4 * d], lo[4 * d + 1], inv, false);
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lo[4 * d + 2], lo[4 * d + 3], inv, true);
+        l8[d] = __builtin_bit_cast(unsigned, w);
+        x8[d] = mx_cvt4(t[4 * d], t[4 * d + 1], t[4 * d + 2], t[4 * d + 3]);
+    }
 }
 
 // ------------------------------------------------------------------ weight fragments (packed behind the direct ones of the same weight)

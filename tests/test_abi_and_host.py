@@ -363,6 +363,14 @@ def test_bench_roofline_bookkeeping():
     assert abs(ab["algorithmic_ms"] - 4.936) < 0.01 and abs(ab["achievable_ms"] - 5.875) < 0.01 and abs(ab["achievable_all_ms"] - 6.882) < 0.01
     assert abs(ab["gbytes_fused_lower_bound"] - 37.91) < 0.05 and abs(ab["gbytes_achievable"] - 45.42) < 0.05 and abs(ab["gbytes_achievable_all"] - 53.48) < 0.05
     assert abs((ab["achievable_ms"] + 4.0 * 16 * 4 * 128 ** 3 / 8e12 * 1e3) / 15.833 - 0.375) < 0.002      # with the last residual pass counted (round 4's dataflow): the round-4 driver line, recomputed by its judge as 0.376
+    # round 6: the largest single instantiations (`roofline_top` rows with "instance").  The 16-channel level's weight gradient with the fused GroupNorm-backward
+    # apply, at the 451 us per launch of profiles/r05_serial_train_step_kernel_stats.txt: 0.30 of its algorithmic bytes (x + dy once), 0.61 of the 2.19 GB it moves
+    ib = bench.instance_bounds(4, 128)
+    assert abs(ib["conv16_fwd"]["gflop"] - 4 * 115.96) < 0.1 and abs(ib["conv16_fwd"]["gbytes"] - 4 * 1.0737) < 0.001 and ib["conv_deep_fwd"]["launches"] == 20
+    rows = bench.instance_rows({"wgrad16_fused_apply": (3 * 4 * 0.451, 12), "conv16_fwd": (0.0, 0)}, ("wgrad16_fused_apply", "conv16_fwd"), 3, 4, 128, "bf16x3")
+    assert len(rows) == 1 and rows[0]["launches_per_step"] == 4 and abs(rows[0]["frac_algorithmic"] - 0.2976) < 0.002
+    if rows[0]["moved_gbytes_per_step"] is not None:         # (the committed step-traffic table names the kernel: true for every round's table so far)
+        assert 0.45 < rows[0]["frac_moved"] < 0.75 and rows[0]["moved_gbytes_per_step"] > 2 * rows[0]["algorithmic_gbytes_per_step"] * 0.9
     ft = bench.committed_family_table()
     assert ft is not None and len(ft["rows"]) >= 8 and {r["channels"] for r in ft["rows"]} == {16, 32, 64, 128}
     assert all(0 < r["mfma_busy_pct"] < 100 and r["avg_us"] > 0 for r in ft["rows"])
