@@ -389,8 +389,15 @@ int pack_down16_launch(const float* w, float* wd, float* wdT, int Cout, int Cin,
 // cb carries fine block cb % NSLOT (NSLOT = fine channel blocks, 1 / 2 / 4) -- the sums and constants are kept per SLOT, not per block
 // (registers: the kernel is a latency-bound stream and lives on occupancy).  The four waves' sums meet in LDS: one partial per
 // (workgroup, channel).
-template <int COB, int S2D, int NSLOT>
-__global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nvt) {
+// PAIR (scatter mode with statistics, COB = 4, NSLOT = fine channel blocks = 1 / 2; round 6): the two x taps of a coarse voxel are stored by ONE instruction.
+// A lane's accumulators hold (coarse voxel r, tap k) for k = 0 and 1 in two different blocks, and the plain epilogue stores each block by itself: 16 pieces of 64
+// bytes, 128 bytes apart, per instruction -- half of every line it touches, like the loads of the residual and of the GroupNorm-backward operand at the same
+// addresses (the level-0 launch ran at 3.7 TB/s where its whole-line siblings stream at 5.4-5.9).  Here the lanes change roles for the epilogue: lane (r', g) of
+// half h takes, through ds_bpermute, tap r' & 1 of coarse voxel 8 h + (r' >> 1) -- 16 consecutive FINE voxels x 64 bytes = 1 KB of whole lines per instruction.
+// Same values at the same addresses (bit-identical output); the statistics are summed in another lane order.
+template <int COB, int S2D, int NSLOT, bool PAIR = false>
+__global__ __launch_bounds__(256, (PAIR || NSLOT > 0) ? 2 : 1) void conv1_16_kernel(const Conv1Args a, int nvt) {
+    static_assert(!PAIR || (S2D == 2 && COB == 4 && (NSLOT == 1 || NSLOT == 2)), "paired stores: the scatter mode with statistics, four blocks per workgroup");
     constexpr bool BST = NSLOT > 0;
     constexpr int NSL = BST ? NSLOT : 1;
     __shared__ float red[BST ? 4 * NSL * 16 * 2 : 1];
@@ -478,6 +485,156 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
     int kb = 0;
     for (; kb + 1 < nkb; kb += 2) { kstep(kb); kstep(kb + 1); }
     if (kb < nkb) kstep(kb);
+    if constexpr (PAIR) {
+        // Two phases per 16-voxel tile t, so that the epilogue's loads travel TOGETHER: with the operand loads inside `if (a.add)` / behind a store, every
+        // load of the plain epilogue was followed by s_waitcnt vmcnt(0) -- 48 dependent memory round trips per wave.  Phase A: roles, addresses, and all eight
+        // operand loads of the tile (residual + GroupNorm-backward operand of the four (half, tap pair) roles), unconditional from valid addresses; phase B:
+        // the lane exchange, the arithmetic, the stores.  (A launch with a LeakyReLU mask takes the plain epilogue: not a launch of the network in this mode.)
+        const int k = r & 1;
+        constexpr int CBf = NSLOT;                                           // fine channel blocks (the launch's nslot)
+        const bool has_add = a.add != nullptr;
+        const float* addp = has_add ? a.add : a.bst_y;                       // (absent: any valid tensor of the same extents, dropped by a select)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            size_t idx[2][2];
+            bool ok[2];
+            int srcl[2];
+            float4 dadd[2][2], dyq[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                srcl[h] = 16 * g + 8 * h + (r >> 1);                         // the lane that computed this role's coarse voxel for channel quad g
+                ok[h] = v0 + 16 * t + 8 * h + (r >> 1) < V;
+                const unsigned flo = __shfl((unsigned)(fv[t] & 0xffffffffu), srcl[h]), fhi = __shfl((unsigned)(fv[t] >> 32), srcl[h]);
+                const size_t fvs = ((size_t)fhi << 32) | flo;               // (of the source lane's CLAMPED voxel: always a valid address)
+#pragma unroll
+                for (int pa = 0; pa < 2; ++pa) {
+                    const int cbA = CBf == 1 ? 2 * pa : pa;
+                    const int cobA = cog * COB + cbA, tapA = cobA / CBf, cbf = cobA - tapA * CBf;      // tapA is even: its x tap is 0, the partner block's 1
+                    const size_t toff = ((size_t)(tapA >> 2) * Hf + ((tapA >> 1) & 1)) * Wf + k;
+                    idx[h][pa] = ((size_t)(n * CBf + cbf) * Vf + fvs + toff) * 16 + 4 * g;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int pa = 0; pa < 2; ++pa) {
+                    dadd[h][pa] = *reinterpret_cast<const float4*>(addp + idx[h][pa]);
+                    dyq[h][pa] = *reinterpret_cast<const float4*>(a.bst_y + idx[h][pa]);
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int pa = 0; pa < 2; ++pa) {
+                    const int cbA = CBf == 1 ? 2 * pa : pa, cbB = CBf == 1 ? 2 * pa + 1 : pa + 2;
+                    f32x4_c16 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float va = __shfl(acc[t][cbA][e], srcl[h]), vb = __shfl(acc[t][cbB][e], srcl[h]);
+                        o4[e] = k ? vb : va;
+                    }
+                    float4 o = make_float4(lrelu(o4[0], a.out_slope), lrelu(o4[1], a.out_slope), lrelu(o4[2], a.out_slope), lrelu(o4[3], a.out_slope));
+                    const float4 d = dadd[h][pa];
+                    if (has_add) { o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+                    if (ok[h]) {
+                        if (nt_out) __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(a.y + idx[h][pa]));
+                        else *reinterpret_cast<float4*>(a.y + idx[h][pa]) = o;
+                    }
+                    const float4 yq = dyq[h][pa];
+                    const float okf = ok[h] ? 1.f : 0.f;                     // (roles beyond the tensor contribute zeros to the sums)
+                    const f32x4_c16 ov = f32x4_c16{o.x, o.y, o.z, o.w} * okf, os = ov * a.bst_slope;
+                    const int sl_ = CBf == 1 ? 0 : pa;                       // slot = fine channel block
+                    static_for_c1<NSL>([&](auto SL) {
+                        constexpr int s_ = decltype(SL)::value;
+                        if (sl_ == s_) {
+                            const f32x4_c16 u = f32x4_c16{yq.x, yq.y, yq.z, yq.w} * bk[s_][0] + bk[s_][1];
+                            f32x4_c16 dh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dh[e] = u[e] > bk[s_][2][e] ? ov[e] : os[e];
+                            bs1[s_] += dh;
+                            bs2[s_] += dh * u;
+                        }
+                    });
+                }
+            }
+        }
+    } else if constexpr (BST) {
+    // two phases per tile, like the paired epilogue above: addresses and ALL operand loads of the tile's COB blocks first (one wave-uniform test per operand
+    // kind, not one per load -- a load inside `if (a.add)` behind a store was followed by s_waitcnt vmcnt(0): up to 3 x COB x 4 dependent round trips per
+    // wave), then the arithmetic and the stores
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const size_t v = v0 + 16 * t + r;
+        const bool vok = v < V;
+        const size_t vc = vok ? v : V - 1;
+        size_t idx[COB];
+        float* ydst[COB];
+        bool second[COB];
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {
+            int cob = cog * COB + cb;
+            if (cob >= CBo) cob = CBo - 1;                  // (clamped: loaded and dropped)
+            ydst[cb] = a.y;
+            second[cb] = false;
+            if constexpr (S2D == 2) {
+                const int tap = cob / CBf_out, cbf = cob - tap * CBf_out;
+                const size_t toff = ((size_t)(tap >> 2) * Hf + ((tap >> 1) & 1)) * Wf + (tap & 1);
+                idx[cb] = ((size_t)(n * CBf_out + cbf) * Vf + fv[t] + toff) * 16 + 4 * g;
+            } else {
+                int cbt = CBo, cl = cob;
+                if (a.y1) {                              // split output: channel blocks >= Cout0/16 belong to the second tensor
+                    const int CB0o = a.Cout0 >> 4;
+                    second[cb] = cob >= CB0o;
+                    cbt = second[cb] ? CBo - CB0o : CB0o;
+                    cl = second[cb] ? cob - CB0o : cob;
+                    ydst[cb] = second[cb] ? a.y1 : a.y;
+                }
+                idx[cb] = ((size_t)(n * cbt + cl) * V + vc) * 16 + 4 * g;
+            }
+        }
+        float4 mq[COB], dq[COB], yq[BST ? COB : 1];
+        if (a.mask) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) mq[cb] = *reinterpret_cast<const float4*>(a.mask + ((second[cb] || !a.y1) ? idx[cb] : 0));
+        }
+        if (a.add) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) dq[cb] = *reinterpret_cast<const float4*>(a.add + idx[cb]);
+        }
+        if constexpr (BST) {
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb) yq[cb] = *reinterpret_cast<const float4*>(a.bst_y + idx[cb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {
+            if (!vok || cog * COB + cb >= CBo) continue;
+            float4 o = make_float4(lrelu(acc[t][cb][0], a.out_slope), lrelu(acc[t][cb][1], a.out_slope),
+                                   lrelu(acc[t][cb][2], a.out_slope), lrelu(acc[t][cb][3], a.out_slope));
+            if (a.mask && (second[cb] || !a.y1)) {
+                const float4 m = mq[cb];
+                o.x = m.x > 0.f ? o.x : o.x * a.mask_slope; o.y = m.y > 0.f ? o.y : o.y * a.mask_slope;
+                o.z = m.z > 0.f ? o.z : o.z * a.mask_slope; o.w = m.w > 0.f ? o.w : o.w * a.mask_slope;
+            }
+            if (a.add) { const float4 d = dq[cb]; o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w; }
+            if (nt_out) __builtin_nontemporal_store(f32x4_c16{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4_c16*>(ydst[cb] + idx[cb]));
+            else *reinterpret_cast<float4*>(ydst[cb] + idx[cb]) = o;
+            if constexpr (BST) {                         // sums of the STORED gradient (sb_out_tile_bst's arithmetic)
+                const f32x4_c16 ov = f32x4_c16{o.x, o.y, o.z, o.w}, os = ov * a.bst_slope;
+                static_for_c1<NSL>([&](auto SL) {        // (compile-time slot: no register array is indexed by a run-time value)
+                    constexpr int s_ = decltype(SL)::value;
+                    if (cb % NSL == s_) {
+                        const f32x4_c16 u = f32x4_c16{yq[cb].x, yq[cb].y, yq[cb].z, yq[cb].w} * bk[s_][0] + bk[s_][1];
+                        f32x4_c16 dh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dh[e] = u[e] > bk[s_][2][e] ? ov[e] : os[e];
+                        bs1[s_] += dh;
+                        bs2[s_] += dh * u;
+                    }
+                });
+            }
+        }
+    }
+    } else {
+    // no statistics: the forward launches, which have no epilogue operand at all -- they live on occupancy, and the batched form costs 24-28 registers
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const size_t v = v0 + 16 * t + r;
@@ -533,6 +690,7 @@ __global__ __launch_bounds__(256) void conv1_16_kernel(const Conv1Args a, int nv
             }
         }
     }
+    }                                                    // !PAIR
     }                                                    // live
     if constexpr (BST) {
         // lanes sharing g hold the same channel quad: fold the 16 voxel lanes, then the four waves -- one partial per (workgroup, channel)
@@ -603,9 +761,14 @@ int conv1_16_launch(const Conv1Args& a, hipStream_t s) {
     RU_REQUIRE(!bst || (a.bst_k && a.stat_partials && a.s2d != 1 && !a.y1 && conv1_16_bst_nblk(a) > 0), "conv1_16: fused GroupNorm-backward statistics need the plain or scatter mode with whole channel blocks per workgroup");
     dim3 grid((unsigned)cdiv(nvt, 4), (unsigned)cdiv(CBo, cob), (unsigned)a.N);
     const int nslot = !bst ? 0 : (a.s2d == 2 ? (CBo >> 3) : cob);          // distinct output channel blocks per workgroup (conv1_16_bst_nblk checked the shape)
+    // paired stores (the scatter mode's two x taps in one whole-line instruction): 8 consecutive coarse voxels of a 64-voxel wave tile must share a row; RU_C1_PAIR=0: off (A/B)
+    static const bool pair_off = [] { const char* e = getenv("RU_C1_PAIR"); return e && *e == '0'; }();
+    const bool pair = a.s2d == 2 && bst && !pair_off && a.Wc % 8 == 0 && cob == 4 && !a.mask;
 #define RU_C1_LAUNCH(COB_)                                                                                          \
     do {                                                                                                           \
         if (a.s2d == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 1, 0>), grid, dim3(256), 0, s, a, nvt);           \
+        else if (a.s2d == 2 && nslot == 1 && pair && COB_ == 4) hipLaunchKernelGGL((conv1_16_kernel<4, 2, 1, true>), grid, dim3(256), 0, s, a, nvt);  \
+        else if (a.s2d == 2 && nslot == 2 && pair && COB_ == 4) hipLaunchKernelGGL((conv1_16_kernel<4, 2, 2, true>), grid, dim3(256), 0, s, a, nvt);  \
         else if (a.s2d == 2 && nslot == 1) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, 1>), grid, dim3(256), 0, s, a, nvt);  \
         else if (a.s2d == 2 && nslot == 2) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, (COB_ >= 2 ? 2 : 1)>), grid, dim3(256), 0, s, a, nvt);  \
         else if (a.s2d == 2 && nslot == 4) hipLaunchKernelGGL((conv1_16_kernel<COB_, 2, (COB_ >= 4 ? 4 : 1)>), grid, dim3(256), 0, s, a, nvt);  \
