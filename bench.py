@@ -205,7 +205,7 @@ def committed_family_table():
             tail = [float(v) for v in f[-8:]]
             i = ln.index("ch")
             ch = int(ln[:i].split()[-1])
-            rows.append({"kind": "wgrad" if ln.startswith("wgrad") else ("conv_fwd_direct_kernel" if ln.startswith("conv dir") else "conv_fwd"), "channels": ch,
+            rows.append({"kind": "wgrad" if ln.startswith("wgrad") else ("conv_fwd_direct_kernel" if ln.startswith("conv dir") else ("conv_fwd_three_products" if ln.startswith("conv 3p") else "conv_fwd")), "channels": ch,
                          "kernel": next((t for t in f if "kernel" in t), None), "avg_us": tail[0], "algorithmic_gb": tail[1],
                          "hbm_frac": tail[3], "counter_gb": tail[4], "mfma_busy_pct": tail[5], "executed_mfma_frac": tail[7]})
         except (ValueError, IndexError):

@@ -20,8 +20,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(PKG, "build")
 LIB = os.path.join(LIBDIR, "libresunet_hip.so")
-SOURCES = ["conv3_f32.hip", "conv3_f32c.hip", "conv3_sb.hip", "conv3_sb2_c16.hip", "conv3_sb2_c16_p1.hip", "conv3_sb2_mixed.hip", "conv3_wz.hip", "conv3_wz32.hip", "conv3_mx.hip", "wgrad_f32.hip", "wgrad_sb.hip", "wgrad_tr.hip", "pointwise.hip", "pointwise_c16.hip", "inference.hip", "engine.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(CSRC, "conv3_epilogue.hpp"), os.path.join(CSRC, "conv3_sb_common.hpp"), os.path.join(CSRC, "pw_helpers.hpp"), os.path.join(CSRC, "fin_tail.hpp"), os.path.join(CSRC, "conv3_wz.hpp"), os.path.join(CSRC, "conv3_wz_pack.hpp"), os.path.join(CSRC, "conv3_wz32.hpp"), os.path.join(CSRC, "conv3_mx.hpp"), os.path.join(CSRC, "conv3_mx_pack.hpp"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
+SOURCES = ["conv3_f32.hip", "conv3_f32c.hip", "conv3_sb.hip", "conv3_sb2_c16.hip", "conv3_sb2_c16_p1.hip", "conv3_sb2_mixed.hip", "conv3_wz.hip", "conv3_wz32.hip", "conv3_mx.hip", "conv3_wz32mx.hip", "wgrad_f32.hip", "wgrad_sb.hip", "wgrad_tr.hip", "pointwise.hip", "pointwise_c16.hip", "inference.hip", "engine.hip", "comm.hip"]
+HEADERS = [os.path.join(CSRC, "ru_common.h"), os.path.join(CSRC, "conv3_epilogue.hpp"), os.path.join(CSRC, "conv3_sb_common.hpp"), os.path.join(CSRC, "pw_helpers.hpp"), os.path.join(CSRC, "fin_tail.hpp"), os.path.join(CSRC, "conv3_wz.hpp"), os.path.join(CSRC, "conv3_wz_pack.hpp"), os.path.join(CSRC, "conv3_wz32.hpp"), os.path.join(CSRC, "conv3_mx.hpp"), os.path.join(CSRC, "conv3_mx_pack.hpp"), os.path.join(CSRC, "conv3_wz32mx.hpp"), os.path.join(os.path.dirname(PKG), "include", "resunet_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 

@@ -10,6 +10,11 @@ bool conv3_mx_enabled() {
     return !(e && *e == '0');
 }
 
+bool conv3_mx_wz_enabled() {                          // RU_MX=1: the 16-channel kernel only (same-box A/B of the Winograd-z form); RU_MX=0: neither
+    const char* e = getenv("RU_MX");
+    return !(e && (*e == '0' || *e == '1'));
+}
+
 bool conv3_mx_shape_ok(int N, int Cin, int Cout, int D, int H, int W) {
     return mx_channels_ok(Cin, Cout) && sb_use_v2(sb_choose(N, Cout, D, H, W));
 }

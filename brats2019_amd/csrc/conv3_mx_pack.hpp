@@ -64,6 +64,27 @@ __device__ __forceinline__ void mx_split8(const float (&t)[8], u32x4& h16, unsig
     }
 }
 
+// 4 values (the Winograd-z staging: a lane owns a channel quad) -> 2 dwords of fp16, one dword of e4m3(lo * 2^SX), one dword of e4m3(v)
+__device__ __forceinline__ void mx_split4(const float (&t)[4], uint2& h16, unsigned& l8, unsigned& x8) {
+    float lo[4];
+    unsigned hb[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        mx_f16x2 h;
+        h[0] = (_Float16)t[2 * c];
+        h[1] = (_Float16)t[2 * c + 1];
+        hb[c] = __builtin_bit_cast(unsigned, h);
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * c]) : "v"(hb[c]), "v"(t[2 * c]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * c + 1]) : "v"(hb[c]), "v"(t[2 * c + 1]));
+    }
+    h16 = make_uint2(hb[0], hb[1]);
+    constexpr float inv = 1.f / (float)(1 << MX_SX);
+    mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(mx_s16x2{0, 0}, lo[0], lo[1], inv, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lo[2], lo[3], inv, true);
+    l8 = __builtin_bit_cast(unsigned, w);
+    x8 = mx_cvt4(t[0], t[1], t[2], t[3]);
+}
+
 // ------------------------------------------------------------------ weight fragments (packed behind the direct ones of the same weight)
 // unit u of 16-cout group cog, lane l (col = l & 15 = output channel, k-group g = l >> 4):
 //   u < 14            fp16 K-step u: 8 x fp16 of W[co][ci = (g&1)*8 + e][sb_tap(u, g>>1)]                       (the direct kernel's fragment in fp16)
@@ -111,6 +132,7 @@ __device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* 
 
 // launch rule and entry (conv3_mx.hip)
 bool conv3_mx_enabled();                                 // RU_MX=0: every forward convolution keeps the three-product kernels (same-box A/B, parity tests)
+bool conv3_mx_wz_enabled();                              // ... and the Winograd-z form of the scheme at 32..128 channels (conv3_wz32mx.hpp); RU_MX=1: the 16-channel kernel only
 bool conv3_mx_shape_ok(int N, int Cin, int Cout, int D, int H, int W);
 int conv3_mx_launch(const Conv3Args& a, const void* mxfrag, hipStream_t s);
 

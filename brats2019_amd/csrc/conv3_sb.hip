@@ -620,7 +620,7 @@ __device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u3
 // forms: bit 0 = the 16x16x32 Winograd-z fragments, bit 1 = the 32x32x16 ones (SB_FORMS_ALL: op-level packs and inference, whose frozen packs must serve
 // every later launch; a training step repacks per forward and packs what that forward's launches take -- sb_pack_forms); bit 2 = the fp16 + MX-fp8 fragments of
 // conv3_mx_kernel (16 input channels, whole 16-channel output blocks: shapes that have neither a Winograd-z nor a head form, so they sit right behind the direct ones)
-constexpr int SB_FORMS_ALL = 7;
+constexpr int SB_FORMS_ALL = 15;                        // (bit 3: the same scheme's Winograd-z fragments, conv3_wz32mx.hpp, behind the two bf16 Winograd-z forms)
 __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int forms, int i) {
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
     if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
@@ -628,28 +628,33 @@ __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4*
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
     if (mx_channels_ok(cin_conv, cout_conv)) { if (forms & 4) mx_pack_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, ncog, i - direct); return; }
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
-    const int wz = (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64;      // (the fragments keep their places whatever `forms` says: a skipped form leaves its bytes as they are)
+    const int wz = WZ16_FORM ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0;      // (the fragments keep their places whatever `forms` says: a skipped form leaves its bytes as they are)
     int r = i - direct;
-    if (forms & 1) {
+    if (WZ16_FORM && (forms & 1)) {
         if (r < wz) { wz_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + (size_t)direct * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r); return; }
         r -= wz;
     }
-    if (forms & 2) wz32_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r);
+    const int wz32 = (cout_conv / 32) * nchunk * 4 * 9 * 64;
+    if (forms & 2) {
+        if (r < wz32) { wz32_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r); return; }
+        r -= wz32;
+    }
+    if (forms & 8) wz32mx_pack_one(w, reinterpret_cast<wz_u32x4*>(wfrag + ((size_t)direct + wz + wz32) * 2), Cin_f, Cout_f, mode, nchunk, cout_conv / 32, r);
 }
 static inline int sb_pack_threads(int cin_conv, int cout_conv, int forms) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((forms & 1) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0)) * 64 : 0)
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((WZ16_FORM && (forms & 1)) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0) + ((forms & 8) ? 4 * WZ32MX_UNITS_XI : 0)) * 64 : 0)
          + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0) + (((forms & 4) && mx_channels_ok(cin_conv, cout_conv)) ? ncog * MX_UNITS * 64 : 0);
 }
-// what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 switches
-// (conv3_sb_uses_wz, conv3_sb_wz_takes_split, conv3_sb_wz_plain_dgrad, conv3_wz32_enabled: read per call, as the launches read them)
+// what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 / RU_MX switches
+// (read per call, as the launches read them; a toggle BETWEEN a forward's pack and a launch that reads it is not supported -- tools and tests toggle between steps)
 static int sb_pack_forms(int mode) {
-    const int mx = (mode == 0 && conv3_mx_enabled()) ? 4 : 0;      // forward convolutions only: gradients never take the fp16 + MX-fp8 scheme
+    if (mode == 1) return 0;                                // data-gradient launches (split-form inputs) take the direct kernels only
+    const bool mxon = conv3_mx_enabled();                   // forward convolutions only: gradients never take the fp16 + MX-fp8 scheme
     const char* e = getenv("RU_WZ");
-    if (e && *e == '0') return mx;
-    const bool dgrad_wz = conv3_sb_wz_takes_split() || conv3_sb_wz_plain_dgrad();
-    if (mode == 1) return dgrad_wz ? 3 : 0;                 // (a data-gradient launch without residual / GroupNorm-backward sums takes the forward form)
-    return (conv3_wz32_enabled() ? 2 : 1) | mx;             // forward launches have neither residual nor GroupNorm-backward sums: ONE Winograd-z form
+    if (e && *e == '0') return mxon ? 4 : 0;
+    if (mxon && conv3_mx_wz_enabled()) return 4 | 8;        // forward launches take the MX kernel of their shape: direct (16 channels) or Winograd-z (32..)
+    return (mxon ? 4 : 0) | (conv3_wz32_enabled() ? 2 : 1); // ... or ONE three-product Winograd-z form
 }
 __global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
     sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, SB_FORMS_ALL, blockIdx.x * blockDim.x + threadIdx.x);
@@ -686,7 +691,7 @@ size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv) {
     return (size_t)cdiv(Cout_conv, 16) * cdiv(Cin_conv, 16) * SB_KSTEPS * 2 * 64 * 16;
 }
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv) {          // direct fragments + (32..: the Winograd-z fragments | <= 4 couts: the head form) behind them
-    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv) + wz32_frag_bytes(Cin_conv, Cout_conv)
+    return conv3_sb_frag_bytes_direct(Cin_conv, Cout_conv) + wz_frag_bytes(Cin_conv, Cout_conv) + wz32_frag_bytes(Cin_conv, Cout_conv) + wz32mx_frag_bytes(Cin_conv, Cout_conv)
          + (sb_head_shape(Cin_conv, Cout_conv) ? (size_t)SB_HEAD_KSTEPS * 2 * 64 * 16 : 0) + mx_frag_bytes(Cin_conv, Cout_conv);
 }
 // The inference head: the last Residual block's output x + lrelu(norm2(conv2)) (model.py:112-116) is formed in the head conv's staging instead of a pass of its
@@ -713,23 +718,10 @@ int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, in
 }
 
 // number of statistics partials per (sample, channel) the kernel chosen for this shape writes
-// The Winograd-z kernel (conv3_wz.hpp) takes the voxel-major three-product convolutions of 32 and more channels whose shape fills the chip;
-// RU_WZ=0 keeps every shape on the direct kernels (same-box A/B).  ONE rule for the launch and for the partial count the engine sizes.
-// Split-form inputs (the data-gradient convolutions: gn_bwd_apply16's hi / lo packets) stay on the direct kernel by default: there the staging is a
-// global -> LDS DMA copy with no VALU work at all, while the z transform has to re-join, transform and re-split every value (7 VALU per element
-// + four dword loads per plane) -- measured 120 / 143 / 104 us against 93 / 107 / 79 (BST / ADD / both, profiles/r05_notes.txt).  RU_WZ=2 sends
-// them through the Winograd-z kernel too (tests hold that path to the direct one).
-bool conv3_sb_wz_takes_split() {
-    const char* e = getenv("RU_WZ");
-    return e && *e == '2';
-}
-// RU_WZ=3: the engine publishes the gradients that enter a Winograd-z-shaped data-gradient convolution as plain float32 (gn_bwd_apply16 without
-// the split), so that convolution takes the kernel with the cheap staging (4 VALU per element) -- and the weight gradient of the same layer
-// converts its dy while staging instead of copying packets.
-bool conv3_sb_wz_plain_dgrad() {
-    const char* e = getenv("RU_WZ");
-    return e && *e == '3';
-}
+// The Winograd-z kernels (conv3_wz32.hpp, conv3_wz32mx.hpp) take the voxel-major FORWARD convolutions of 32 and more channels whose shape fills the chip;
+// RU_WZ=0 keeps every shape on the direct kernels (same-box A/B).  ONE rule for the launch and for the partial count the engine sizes.  Split-form inputs
+// (the data-gradient convolutions: gn_bwd_apply16's hi / lo packets) stay on the direct kernel: there the staging is a global -> LDS DMA copy with no VALU
+// work at all, while the z transform has to re-join, transform and re-split every value -- measured 120 / 143 / 104 us against 93 / 107 / 79 in round 5.
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products) {
     const char* e = getenv("RU_WZ");                    // read per call: tests and tools switch it inside one process
     const bool off = e && *e == '0';
@@ -811,7 +803,7 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
     if ((RU_SB2_DBG & 2048) && !a.stat_partials) c = SBChoice{2, 8};      // tools: time the one-stage kernel on a shape the persistent kernel would take
     if ((RU_SB2_DBG & 4096) && !a.stat_partials) c = SBChoice{2, 4};
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
-    if (a.in_c16 && a.out_c16 && !a.bias && !a.sigmoid && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.in_s16 && !conv3_sb_wz_takes_split() ? 1 : a.products))
+    if (a.in_c16 && a.out_c16 && !a.in_s16 && !a.bias && !a.sigmoid && !a.bst_y && !a.add && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.products))
         return conv3_wz_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
     // Conv3Args::products == 2: the caller's input is an ACTIVATION tensor and it asks for the fp16 + MX-fp8 product scheme where a kernel for the shape exists
     // (conv3_mx.hpp: the 16-channel level); everywhere else the request means three products

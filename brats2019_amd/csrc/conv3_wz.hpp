@@ -28,6 +28,7 @@
 #pragma once
 #include "conv3_sb_common.hpp"
 #include "conv3_wz_pack.hpp"
+#include "conv3_mx_pack.hpp"
 
 namespace ru {
 
@@ -37,9 +38,12 @@ static __device__ unsigned long long wz_prof[8];
 // The staging waves (waves 4..7 of a workgroup) of both Winograd-z kernels (conv3_wz_kernel here, conv3_wz32_kernel in conv3_wz32.hpp): the transformed,
 // split image of item w+1 is written while the matrix waves work on item w; one __syncthreads per item, two closing ones.  `pad_lds`: 1 KB of LDS
 // nobody reads (landing zone of the operand-row prefetch of the BST / ADD variants).
-template <bool BST, bool ADD, int dbg>
+// MX (conv3_wz32mx_kernel, round 6): the image is written in the operand formats of the fp16 + MX-fp8 product scheme (conv3_mx.hpp) -- sections 0 / 1 fp16 halves
+// (the bf16 hi sections' layout), section 2 e4m3(lo * 2^11), section 3 e4m3(value), 16 channels of a position per 16-byte packet -- plain or fused-transform input only.
+template <bool BST, bool ADD, int dbg, bool MX = false>
 __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, float* pad_lds, int rw, int lane, int cog32, int swz, int G, int nitems, int nchunk,
                                                int tiles_per_sample, int nty, int ntx) {
+    if constexpr (MX) mx_set_saturating_conversions();
     constexpr int HX = WZ_HX, HVOLP = WZ_HVOLP, BUF = WZ_BUF;
     const int D = a.D, H = a.H, W = a.W;
     const size_t DHW = (size_t)D * H * W;
@@ -156,7 +160,16 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
                     if (!((okmask >> rd) & 1u)) {                            // outside the volume in (y, x): the ACTIVATED tensor is zero-padded
                         const uint2 z = make_uint2(0u, 0u);
 #pragma unroll
-                        for (int xi = 0; xi < 4; ++xi) { b2[o + xi * WZ_PLANE * 2] = z; b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = z; }
+                        for (int xi = 0; xi < 4; ++xi) {
+                            b2[o + xi * WZ_PLANE * 2] = z;
+                            if constexpr (MX) {
+                                unsigned* b1 = reinterpret_cast<unsigned*>(buf);
+                                b1[(2 * HVOLP + xi * WZ_PLANE + ppos[rd]) * 4 + quad] = 0u;
+                                b1[(3 * HVOLP + xi * WZ_PLANE + ppos[rd]) * 4 + quad] = 0u;
+                            } else {
+                                b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = z;
+                            }
+                        }
                         continue;
                     }
                     const float s[4] = {sc4[rd].x, sc4[rd].y, sc4[rd].z, sc4[rd].w}, t[4] = {sh4[rd].x, sh4[rd].y, sh4[rd].z, sh4[rd].w};
@@ -192,11 +205,21 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         u[c] = xi == 0 ? d[0][c] - d[2][c] : (xi == 1 ? d[1][c] + d[2][c] : (xi == 2 ? d[2][c] - d[1][c] : d[1][c] - d[3][c]));
+                    if constexpr (MX) {
+                        uint2 h16;
+                        unsigned l8, x8;
+                        mx_split4(u, h16, l8, x8);
+                        b2[o + xi * WZ_PLANE * 2] = h16;
+                        unsigned* b1 = reinterpret_cast<unsigned*>(buf);                 // sections 2 / 3: dword `quad` of the position's packet
+                        b1[(2 * HVOLP + xi * WZ_PLANE + ppos[rd]) * 4 + quad] = l8;
+                        b1[(3 * HVOLP + xi * WZ_PLANE + ppos[rd]) * 4 + quad] = x8;
+                    } else {
                     uint2 hi, lo;
                     split_pair(u[0], u[1], hi.x, lo.x);
                     split_pair(u[2], u[3], hi.y, lo.y);
                     b2[o + xi * WZ_PLANE * 2] = hi;
                     b2[o + (2 * HVOLP + xi * WZ_PLANE) * 2] = lo;
+                    }
                 }
             }
         };

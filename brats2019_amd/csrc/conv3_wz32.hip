@@ -5,8 +5,12 @@
 namespace ru {
 
 bool conv3_wz32_enabled() {
-    const char* e = getenv("RU_WZ32");                  // read per call: tests and tools switch it inside one process
+#ifdef RU_SB2_DBG
+    const char* e = getenv("RU_WZ32");                  // devtools builds: RU_WZ32=0 selects the 16x16x32 matrix form (read per call)
     return !(e && *e == '0');
+#else
+    return true;                                        // the product library has this matrix form only
+#endif
 }
 
 int conv3_wz32_launch(const Conv3Args& a, const void* wz32frag, hipStream_t s) {

@@ -3,6 +3,7 @@
 // routine routes by shape) without instantiating the kernel template.
 #pragma once
 #include "conv3_sb_common.hpp"
+#include "conv3_mx_pack.hpp"
 
 namespace ru {
 
@@ -103,8 +104,70 @@ static inline size_t wz32_frag_bytes(int Cin_conv, int Cout_conv) {
     return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ32_UNITS * 64 * 16 : 0;
 }
 
+// ---- the fp16 + MX-fp8 product scheme on the 32x32 matrix form (conv3_wz32mx.hpp): per transformed plane nine fp16 tap units and five CROSS units of two
+// 16-byte halves -- tap pairs (0,0)+(0,1), (0,2)+(1,0), (1,1)+(1,2), (2,0)+(2,1), (2,2)+phantom in the two slots of v_mfma_scale_f32_32x32x64_f8f6f4
+constexpr int WZ32MX_UNITS_XI = 9 + 5 * 2;               // 16-byte x 64-lane units per (32-cout block, 16-cin chunk, transformed plane)
+constexpr int WZ32MX_UNITS = 4 * WZ32MX_UNITS_XI;
+// tap dy*3 + dx (-1: phantom) in slot `slot` of cross pair p
+__host__ __device__ constexpr int wz32mx_pair_tap(int p, int slot) { return 2 * p + slot < 9 ? 2 * p + slot : -1; }
+// thread i of ncog32 * nchunk * 4 * 19 * 64: unit u = ((cog32*nchunk + chunk)*4 + xi)*19 + j.  j < 9: lane l (row = l&31, K half kh = l>>5) holds 8 x fp16 of
+// G_xi[cout = cog32*32 + row][cin = chunk*16 + kh*8 + e][tap j] (wz32_pack_one's fragment in fp16); j = 9 + 2 p + slot: lane l (row, k-group kg = l>>5) holds
+// 16 x e4m3 over cin = chunk*16 + 0..15 of tap wz32mx_pair_tap(p, slot): kg == 0 ? G * 2^8 : (G - f16(G)) * 2^19 (the weight operands of the two cross terms)
+__device__ __forceinline__ void wz32mx_pack_one(const float* __restrict__ w, wz_u32x4* __restrict__ frag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog32, int i) {
+    const int total = ncog32 * nchunk * 4 * WZ32MX_UNITS_XI * 64;
+    if (i >= total) return;
+    mx_set_saturating_conversions();
+    const int lane = i & 63;
+    int u = i >> 6;
+    const int j = u % WZ32MX_UNITS_XI; u /= WZ32MX_UNITS_XI;
+    const int xi = u & 3; u >>= 2;
+    const int chunk = u % nchunk;
+    const int cog32 = u / nchunk;
+    const int co = cog32 * 32 + (lane & 31), kg = lane >> 5;
+    auto gat = [&](int ci, int tap2) -> float {
+        if (tap2 < 0) return 0.f;
+        float gz[3];
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int tap = dz * 9 + tap2;
+            gz[dz] = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+        }
+        return xi == 0 ? gz[0] : (xi == 3 ? gz[2] : (xi == 1 ? 0.5f * ((gz[0] + gz[2]) + gz[1]) : 0.5f * ((gz[0] + gz[2]) - gz[1])));
+    };
+    wz_u32x4 out;
+    if (j < 9) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mx_f16x2 h;
+            h[0] = (_Float16)gat(chunk * 16 + kg * 8 + 2 * c, j);
+            h[1] = (_Float16)gat(chunk * 16 + kg * 8 + 2 * c + 1, j);
+            out[c] = __builtin_bit_cast(unsigned, h);
+        }
+    } else {
+        const int tap2 = wz32mx_pair_tap((j - 9) >> 1, (j - 9) & 1);
+        float v[16];
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+            const float x = gat(chunk * 16 + ci, tap2);
+            v[ci] = kg == 0 ? x * (float)(1 << MX_SWH) : (x - (float)(_Float16)x) * (float)(1 << MX_SWL);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = mx_cvt4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    }
+    frag[(((size_t)(cog32 * nchunk + chunk) * 4 + xi) * WZ32MX_UNITS_XI + j) * 64 + lane] = out;
+}
+static inline size_t wz32mx_frag_bytes(int Cin_conv, int Cout_conv) {
+    return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ32MX_UNITS * 64 * 16 : 0;
+}
+
+// (the 16x16x32 form's fragments -- conv3_wz_kernel -- exist in devtools builds only: the product library neither packs nor reserves them)
+#ifdef RU_SB2_DBG
+constexpr bool WZ16_FORM = true;
+#else
+constexpr bool WZ16_FORM = false;
+#endif
 static inline size_t wz_frag_bytes(int Cin_conv, int Cout_conv) {
-    return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ_UNITS * 64 * 16 : 0;
+    return (WZ16_FORM && wz_channels_ok(Cin_conv, Cout_conv)) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ_UNITS * 64 * 16 : 0;
 }
 
 // shapes the kernel takes: voxel-major in and out, several input chunks, whole 32-channel output blocks, an even number of planes, and at least
@@ -125,6 +188,7 @@ static inline long wz_grid_x(int N, int Cout, int D, int H, int W) {
 
 int conv3_wz_launch(const Conv3Args& a, const void* wzfrag, hipStream_t s);
 int conv3_wz32_launch(const Conv3Args& a, const void* wz32frag, hipStream_t s);      // conv3_wz32.hip: forward form only (no residual, no GroupNorm-backward sums)
-bool conv3_wz32_enabled();                               // RU_WZ32=0 keeps the 16x16x32 matrix form (same-box A/B)
+bool conv3_wz32_enabled();                               // devtools builds: RU_WZ32=0 selects the 16x16x32 matrix form (same-box A/B); always true in the product library
+int conv3_wz32mx_launch(const Conv3Args& a, const void* wz32mxfrag, hipStream_t s);  // conv3_wz32mx.hip: the forward form with fp16 + MX-fp8 products (Conv3Args::products == 2, RU_MX)
 
 }  // namespace ru

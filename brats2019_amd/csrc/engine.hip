@@ -960,11 +960,10 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     // the block is converted, but at 32 channels it costs what it saves: 203 us against 131 us + a 70 us apply pass, same box,
     // profiles/r02_notes.txt -- every input-channel group recomputes the apply while staging, and the producers become the slower side.)
     const bool fa = c16 && h->precision == RU_PREC_BF16X3 && C == 16 && (h->fusion & RU_FUSE_GN_BWD_APPLY);
-    // form of the gradients dy2 / dy1 that enter the two data-gradient convs (and the two weight gradients): split hi / lo packets (default: the
-    // direct conv kernel copies them global -> LDS), or plain float32 where the shape takes the Winograd-z kernel and RU_WZ=3 asks for it
-    const bool wzd = c16 && !fa && h->precision == RU_PREC_BF16X3 && conv3_sb_wz_plain_dgrad() && conv3_sb_uses_wz(N, C, C, D, H, W, h->grad_products());
-    const bool ds16 = c16 && !wzd;
-    const int dgrad_products = wzd ? h->grad_products() : ((c16 && !conv3_sb_wz_takes_split()) ? 1 : h->grad_products());      // (for the kernel choice / partial count only)
+    // form of the gradients dy2 / dy1 that enter the two data-gradient convs (and the two weight gradients): split hi / lo packets -- the direct conv kernel
+    // copies them global -> LDS (the Winograd-z routes for them, RU_WZ=2 / 3 of round 5, were measured slower twice and are retired: profiles/r05_notes.txt)
+    const bool ds16 = c16;
+    const int dgrad_products = c16 ? 1 : h->grad_products();      // (for the kernel choice / partial count only: a split-form input never takes the Winograd-z kernel)
     float *coef2 = nullptr, *coef1 = nullptr;
     int rc = gn_bwd(h, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, sums2,
                     fa ? &coef2 : nullptr, ds16);

@@ -169,8 +169,6 @@ int conv3_sb_tiles_per_sample(int N, int Cin, int Cout, int D, int H, int W, int
 bool conv3_sb_head_form_enabled();                // RU_HEAD_FORM=0 keeps the <= 4-output-channel convolutions on the 16-column kernel (A/B runs, parity tests)
 bool conv3_sb_uses_wz(int N, int Cin, int Cout, int D, int H, int W, int products);
 bool conv3_sb_head_takes_residual(int N, int Cin, int Cout, int D, int H, int W);   // the 16 -> <=4 voxel-major-in / NCDHW-out conv of this shape takes the head-form kernel, which stages Conv3Args::in_res (RU_HEAD_RES=0: never)
-bool conv3_sb_wz_plain_dgrad();                   // RU_WZ=3: gradients entering such a data-gradient convolution are published as plain float32
-bool conv3_sb_wz_takes_split();                   // RU_WZ=2: split-form (data-gradient) inputs take the Winograd-z kernel as well                 // the launch takes the Winograd-z kernel (conv3_wz.hpp)
 int conv3_sb_launch(const Conv3Args& a, hipStream_t s);
 size_t conv3_sb_frag_bytes(int Cin_conv, int Cout_conv);          // direct fragments + the Winograd-z fragments behind them (where the channel counts allow)
 size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv);

@@ -1018,19 +1018,17 @@ def _backward_in_context(L, loss):
         loss.backward()
 
 
-def test_winograd_z_convolutions_agree_with_the_direct_kernels_through_the_network():
-    """conv3_wz32_kernel / conv3_wz_kernel inside the engine, all variants: RU_WZ=1 (default: the forward convolutions of the 32..128-channel levels, fused
-    GroupNorm + LeakyReLU input transform, statistics epilogue), RU_WZ=2 (also the data-gradient convolutions: split-form input, residual add,
-    fused GroupNorm-backward sums), RU_WZ=3 (the same with the incoming gradients published as plain float32 instead of hi / lo packets) against RU_WZ=0 (direct kernels everywhere) on one batch-2 x 128^3 training step: probabilities within
-    1e-4, loss within 1e-5, every parameter gradient within 4e-3 relative L2 (LeakyReLU kinks: a 1e-5 activation difference flips ~1e-5 of the
-    units; the direct kernels against the f32 engine measure 3e-3 .. 9e-3 on the same scale)."""
+def test_forward_convolution_kernels_agree_through_the_network():
+    """The three sets of FORWARD 3x3x3 kernels inside the engine on one batch-2 x 128^3 training step: the default (fp16 + MX-fp8 products: conv3_mx_kernel at
+    16 channels, conv3_wz32mx_kernel = Winograd-z at 32..128), RU_MX=0 (three bf16 products: conv3_sb2_kernel, conv3_wz32_kernel) and RU_MX=0 + RU_WZ=0
+    (three products, direct kernels everywhere: round 4's path).  Against the last: probabilities within 2e-4 (MX) / 1e-4 (Winograd-z), loss within 1e-5, every
+    parameter gradient within 4e-3 relative L2 (LeakyReLU kinks: a 1e-5 activation difference flips ~1e-5 of the units; the direct kernels against the f32
+    engine measure 3e-3 .. 9e-3 on the same scale).  The backward kernels are the same in all three."""
     import os
     from brats2019_amd import loss as L
     res = {}
-    for mode in ("0", "1", "2", "3", "1/16"):            # "1/16": the default routing with the forward form on 16x16x32 MFMAs (RU_WZ32=0; default: conv3_wz32_kernel)
-        os.environ["RU_WZ"] = mode[0]
-        if mode == "1/16":
-            os.environ["RU_WZ32"] = "0"
+    for mode, env in (("direct", {"RU_MX": "0", "RU_WZ": "0"}), ("wz", {"RU_MX": "0"}), ("mx", {})):
+        os.environ.update(env)
         try:
             net, _ = build_model(O.DEFAULT_CFG, 31, "bf16x3")
             x = T(O.make_input(2, 128, 128, 128, seed=31)).cuda()
@@ -1041,17 +1039,14 @@ def test_winograd_z_convolutions_agree_with_the_direct_kernels_through_the_netwo
             loss.backward()
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("RU_WZ", None)
-            os.environ.pop("RU_WZ32", None)
+            for k in env:
+                os.environ.pop(k, None)
         res[mode] = (out[0].detach().clone(), float(loss), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
         del net
-    assert not torch.equal(res["1"][0], res["0"][0]), "the default path did not take the Winograd-z kernel"
-    assert torch.equal(res["2"][0], res["1"][0])                       # same forward
-    assert torch.equal(res["3"][0], res["1"][0])
-    assert not torch.equal(res["1/16"][0], res["1"][0]), "RU_WZ32=0 did not switch the matrix form of the forward convolutions"
-    for mode in ("1", "2", "3", "1/16"):
-        dp = float((res[mode][0] - res["0"][0]).abs().max())
-        worst = max((float((res[mode][2][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)), k) for k, v in res["0"][2].items())
-        print("RU_WZ=%s vs direct: max |dp| %.2e, loss %.7f vs %.7f, worst gradient relative L2 %.2e (%s)" % (mode, dp, res[mode][1], res["0"][1], worst[0], worst[1]))
-        assert dp <= 1e-4 and abs(res[mode][1] - res["0"][1]) <= 1e-5 and worst[0] <= 4e-3, (mode, dp, worst)
-    assert any(not torch.equal(res["2"][2][k], res["1"][2][k]) for k in res["1"][2]), "RU_WZ=2 did not change the backward"
+    assert not torch.equal(res["wz"][0], res["direct"][0]), "RU_MX=0 did not take the Winograd-z kernel"
+    assert not torch.equal(res["mx"][0], res["wz"][0]), "the default path did not take the fp16 + MX-fp8 kernels"
+    for mode, bar in (("wz", 1e-4), ("mx", 2e-4)):
+        dp = float((res[mode][0] - res["direct"][0]).abs().max())
+        worst = max((float((res[mode][2][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)), k) for k, v in res["direct"][2].items())
+        print("%s vs direct three-product kernels: max |dp| %.2e, loss %.7f vs %.7f, worst gradient relative L2 %.2e (%s)" % (mode, dp, res[mode][1], res["direct"][1], worst[0], worst[1]))
+        assert dp <= bar and abs(res[mode][1] - res["direct"][1]) <= 1e-5 and worst[0] <= 4e-3, (mode, dp, worst)

@@ -41,7 +41,10 @@ def main():
              "# kind   shape        kernel                          avg_us  alg_GB  alg_GB/s  hbm_frac  counter_GB (fetch x2 + write)  MFMA_busy%%  exec_MFMA_TF  exec_frac"]
     # "conv fwd": the kernel the engine runs at that shape (round 5: conv3_wz32_kernel -- Winograd F(2,3) along z on 32x32x16 MFMAs -- at 32..128 channels);
     # "conv dir": the direct persistent kernel at the same shapes (RU_WZ=0), kept beside it for comparison
-    for kind, kpats, flags, more_env in (("conv fwd", ("conv3_sb2_kernel", "conv3_wz_kernel", "conv3_wz32_kernel"), "3", {}), ("conv dir", ("conv3_sb2_kernel",), "3", {"RU_WZ": "0"}),
+    # round 6: "conv fwd" = the engine's forward kernels on activations (flags 35: conv3_mx_kernel at 16 channels, conv3_wz32mx_kernel at 32..128: fp16 + MX-fp8 products);
+    # "conv 3p" = the three-bf16-product kernels of the same shapes (flags 3: conv3_sb2_kernel / conv3_wz32_kernel; the data-gradient convolutions run the direct ones)
+    for kind, kpats, flags, more_env in (("conv fwd", ("conv3_mx_kernel", "conv3_wz32mx_kernel", "conv3_sb2_kernel", "conv3_wz32_kernel"), "35", {}),
+                                         ("conv 3p", ("conv3_sb2_kernel", "conv3_wz32_kernel"), "3", {}), ("conv dir", ("conv3_sb2_kernel",), "3", {"RU_WZ": "0"}),
                                          ("wgrad", ("wgrad3_tz_kernel",), "3", {})):
         for c, size in SHAPES:
             if kind == "conv dir" and c < 32:
@@ -64,7 +67,10 @@ def main():
             flops = 2.0 * 27 * c * c * vox
             # executed MFMA products per algorithmic one: direct kernels 3 x 28/27 (one phantom tap); Winograd-z on 16x16x32 MFMAs 3 x 40/54 (four
             # transformed planes x 10 tap slots, one of them phantom, per two output planes); on 32x32x16 MFMAs 3 x 36/54 (one K-step per tap)
-            exec_tf = flops * (3 * 36 / 54 if "conv3_wz32" in name else (3 * 40 / 54 if "conv3_wz" in name else 3 * 28 / 27)) / (us * 1e-6) / 1e12
+            # (round 6, in bf16-MFMA time units: conv3_mx_kernel 28 per 27 taps -- 14 fp16 K-steps of two taps + 7 x 2; conv3_wz32mx_kernel 19 per 9 taps of a
+            # transformed plane, 4 planes per two output planes: 4 x 19 / 54)
+            unit = (28 / 13.5 if "conv3_mx" in name else (4 * 19 / 27.0 if "conv3_wz32mx" in name else (3 * 36 / 54 if "conv3_wz32" in name else (3 * 40 / 54 if "conv3_wz" in name else 3 * 28 / 27))))
+            exec_tf = flops * unit / (us * 1e-6) / 1e12
             counter_gb = (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024 / 1e9
             busy = 100.0 * mean("SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * mean("GRBM_GUI_ACTIVE") / 8.0)
             if kind == "conv fwd" and c == 16 and "--json" in sys.argv:
@@ -74,8 +80,8 @@ def main():
                 hist = old.get("history", {})
                 if "hbm_bytes_per_launch" in old:
                     hist["previous file (%s)" % old.get("source", "?").split(";")[-1].strip()] = {k: old[k] for k in ("FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_bytes_per_launch", "avg_launch_us_in_trace", "mfma_busy_pct") if k in old}
-                json.dump({"kernel": "conv3_sb2_kernel<4,8,C16 in,C16 out,single chunk> (3x3x3 conv 16->16, split-bf16 x3, batch 4 x 128^3, voxel-major tensors)",
-                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 3; %s" % os.environ.get("RU_ROUND_TAG", "round 5"),
+                json.dump({"kernel": name + " (3x3x3 conv 16->16 forward, batch 4 x 128^3, voxel-major tensors)",
+                           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/family_table.py --json) on tools/conv_probe.py fwd bf16x3 4 16 128 6 35; %s" % os.environ.get("RU_ROUND_TAG", "round 6"),
                            "FETCH_SIZE_KB": mean("FETCH_SIZE"), "WRITE_SIZE_KB": mean("WRITE_SIZE"),
                            "correction": "FETCH_SIZE x2 for 16-byte-per-lane streaming reads on gfx950 (guide); WRITE_SIZE uncorrected",
                            "hbm_bytes_per_launch": int((2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024), "algorithmic_bytes_per_launch": int(alg_bytes),
