@@ -623,7 +623,7 @@ __device__ __forceinline__ void sb_pack_head_one(const float* __restrict__ w, u3
 constexpr int SB_FORMS_ALL = 15;                        // (bit 3: the same scheme's Winograd-z fragments, conv3_wz32mx.hpp, behind the two bf16 Winograd-z forms)
 __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int forms, int i) {
     const int direct = ncog * nchunk * SB_KSTEPS * 64;
-    if (i < direct) { sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }
+    if (i < direct) { if (!(forms & 16)) sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }      // (bit 4: the direct fragments are not needed -- conv3_sb_pack_add)
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
     if (mx_channels_ok(cin_conv, cout_conv)) { if (forms & 4) mx_pack_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, ncog, i - direct); return; }
@@ -643,7 +643,7 @@ __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4*
 }
 static inline int sb_pack_threads(int cin_conv, int cout_conv, int forms) {
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((WZ16_FORM && (forms & 1)) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0) + ((forms & 8) ? 4 * WZ32MX_UNITS_XI : 0)) * 64 : 0)
+    return ncog * nchunk * SB_KSTEPS * 64 + (wz_channels_ok(cin_conv, cout_conv) ? (cout_conv / 32) * nchunk * (((WZ16_FORM && (forms & 1)) ? 4 * 2 * WZ_KSTEPS : 0) + ((forms & 2) ? 4 * 9 : 0) + ((forms & 8) ? WZ32MX_UNITS_XI : 0)) * 64 : 0)
          + (sb_head_shape(cin_conv, cout_conv) ? SB_HEAD_KSTEPS * 64 : 0) + (((forms & 4) && mx_channels_ok(cin_conv, cout_conv)) ? ncog * MX_UNITS * 64 : 0);
 }
 // what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 / RU_MX switches
@@ -678,12 +678,16 @@ int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
     b.n = 0;
     return RU_OK;
 }
-int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s) {
+bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W) {
+    if (conv3_sb_uses_wz(N, Cin, Cout, D, H, W, 2)) return true;                    // conv3_wz32mx_kernel or conv3_wz32_kernel
+    return conv3_mx_enabled() && conv3_mx_shape_ok(N, Cin, Cout, D, H, W);          // conv3_mx_kernel
+}
+int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s, bool skip_direct) {
     if (b.n == RU_PACK_BATCH) { const int rc = conv3_sb_pack_batch(b, s); if (rc) return rc; }
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     SbPackEntry& e = b.e[b.n++];
     e.w = w; e.wfrag = wfrag; e.Cin_f = Cin_f; e.Cout_f = Cout_f; e.mode = mode; e.nchunk = cdiv(cin_conv, 16); e.ncog = cdiv(cout_conv, 16);
-    e.forms = all_forms ? SB_FORMS_ALL : sb_pack_forms(mode);
+    e.forms = all_forms ? SB_FORMS_ALL : (sb_pack_forms(mode) | ((skip_direct && mode == 0) ? 16 : 0));
     return RU_OK;
 }
 

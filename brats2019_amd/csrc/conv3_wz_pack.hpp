@@ -110,51 +110,62 @@ constexpr int WZ32MX_UNITS_XI = 9 + 5 * 2;               // 16-byte x 64-lane un
 constexpr int WZ32MX_UNITS = 4 * WZ32MX_UNITS_XI;
 // tap dy*3 + dx (-1: phantom) in slot `slot` of cross pair p
 __host__ __device__ constexpr int wz32mx_pair_tap(int p, int slot) { return 2 * p + slot < 9 ? 2 * p + slot : -1; }
-// thread i of ncog32 * nchunk * 4 * 19 * 64: unit u = ((cog32*nchunk + chunk)*4 + xi)*19 + j.  j < 9: lane l (row = l&31, K half kh = l>>5) holds 8 x fp16 of
+// unit u = ((cog32*nchunk + chunk)*4 + xi)*19 + j.  j < 9: lane l (row = l&31, K half kh = l>>5) holds 8 x fp16 of
 // G_xi[cout = cog32*32 + row][cin = chunk*16 + kh*8 + e][tap j] (wz32_pack_one's fragment in fp16); j = 9 + 2 p + slot: lane l (row, k-group kg = l>>5) holds
-// 16 x e4m3 over cin = chunk*16 + 0..15 of tap wz32mx_pair_tap(p, slot): kg == 0 ? G * 2^8 : (G - f16(G)) * 2^19 (the weight operands of the two cross terms)
+// 16 x e4m3 over cin = chunk*16 + 0..15 of tap wz32mx_pair_tap(p, slot): kg == 0 ? G * 2^8 : (G - f16(G)) * 2^19 (the weight operands of the two cross terms).
+// Thread i of ncog32 * nchunk * 19 * 64 packs its (j, lane) for ALL FOUR transformed planes: the three dz slices of a weight element are loaded once, not once
+// per plane (the pack of a training step is a gather of 27-float-strided elements: with one thread per plane it was half of a 150 us launch).
+constexpr int WZ32MX_PACK_THREADS_PER_CHUNK = WZ32MX_UNITS_XI * 64;
 __device__ __forceinline__ void wz32mx_pack_one(const float* __restrict__ w, wz_u32x4* __restrict__ frag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog32, int i) {
-    const int total = ncog32 * nchunk * 4 * WZ32MX_UNITS_XI * 64;
+    const int total = ncog32 * nchunk * WZ32MX_PACK_THREADS_PER_CHUNK;
     if (i >= total) return;
     mx_set_saturating_conversions();
     const int lane = i & 63;
     int u = i >> 6;
     const int j = u % WZ32MX_UNITS_XI; u /= WZ32MX_UNITS_XI;
-    const int xi = u & 3; u >>= 2;
     const int chunk = u % nchunk;
     const int cog32 = u / nchunk;
     const int co = cog32 * 32 + (lane & 31), kg = lane >> 5;
-    auto gat = [&](int ci, int tap2) -> float {
-        if (tap2 < 0) return 0.f;
-        float gz[3];
+    const bool main_unit = j < 9;
+    const int tap2 = main_unit ? j : wz32mx_pair_tap((j - 9) >> 1, (j - 9) & 1);
+    const int nel = main_unit ? 8 : 16, ci0 = chunk * 16 + (main_unit ? kg * 8 : 0);
+    float gz[16][3];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
 #pragma unroll
         for (int dz = 0; dz < 3; ++dz) {
-            const int tap = dz * 9 + tap2;
-            gz[dz] = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+            float v = 0.f;
+            if (e < nel && tap2 >= 0) {
+                const int tap = dz * 9 + tap2, ci = ci0 + e;
+                v = mode == 0 ? w[((size_t)co * Cin_f + ci) * 27 + tap] : w[((size_t)ci * Cin_f + co) * 27 + (26 - tap)];
+            }
+            gz[e][dz] = v;
         }
-        return xi == 0 ? gz[0] : (xi == 3 ? gz[2] : (xi == 1 ? 0.5f * ((gz[0] + gz[2]) + gz[1]) : 0.5f * ((gz[0] + gz[2]) - gz[1])));
-    };
-    wz_u32x4 out;
-    if (j < 9) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            mx_f16x2 h;
-            h[0] = (_Float16)gat(chunk * 16 + kg * 8 + 2 * c, j);
-            h[1] = (_Float16)gat(chunk * 16 + kg * 8 + 2 * c + 1, j);
-            out[c] = __builtin_bit_cast(unsigned, h);
-        }
-    } else {
-        const int tap2 = wz32mx_pair_tap((j - 9) >> 1, (j - 9) & 1);
-        float v[16];
-#pragma unroll
-        for (int ci = 0; ci < 16; ++ci) {
-            const float x = gat(chunk * 16 + ci, tap2);
-            v[ci] = kg == 0 ? x * (float)(1 << MX_SWH) : (x - (float)(_Float16)x) * (float)(1 << MX_SWL);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) out[c] = mx_cvt4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
     }
-    frag[(((size_t)(cog32 * nchunk + chunk) * 4 + xi) * WZ32MX_UNITS_XI + j) * 64 + lane] = out;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        float g[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            g[e] = xi == 0 ? gz[e][0] : (xi == 3 ? gz[e][2] : (xi == 1 ? 0.5f * ((gz[e][0] + gz[e][2]) + gz[e][1]) : 0.5f * ((gz[e][0] + gz[e][2]) - gz[e][1])));
+        wz_u32x4 out;
+        if (main_unit) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mx_f16x2 h;
+                h[0] = (_Float16)g[2 * c];
+                h[1] = (_Float16)g[2 * c + 1];
+                out[c] = __builtin_bit_cast(unsigned, h);
+            }
+        } else {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = kg == 0 ? g[e] * (float)(1 << MX_SWH) : (g[e] - (float)(_Float16)g[e]) * (float)(1 << MX_SWL);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[c] = mx_cvt4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+        }
+        frag[(((size_t)(cog32 * nchunk + chunk) * 4 + xi) * WZ32MX_UNITS_XI + j) * 64 + lane] = out;
+    }
 }
 static inline size_t wz32mx_frag_bytes(int Cin_conv, int Cout_conv) {
     return wz_channels_ok(Cin_conv, Cout_conv) ? (size_t)(Cout_conv / 32) * (Cin_conv / 16) * WZ32MX_UNITS * 64 * 16 : 0;

@@ -475,17 +475,21 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     SbPackBatch batch;
     batch.n = 0;
     // one 3x3x3 weight -> the layout of the active precision (f32: K-major floats; bf16x3: hi/lo fragments, all in one launch)
-    auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode) -> int {
-        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, !h->training, s));
+    // lvl >= 0 (training, voxel-major flow): the resolution level whose forward convolution reads this weight -- where that launch takes the Winograd-z / MX kernel
+    // of its shape, the direct fragments are not written
+    auto pack3 = [&](int pidx, size_t pk_off, size_t fk_off, int cin_f, int cout_f, int mode, int lvl = -1) -> int {
+        const bool skipd = h->training && h->c16 && mode == 0 && lvl >= 0 &&
+                           conv3_sb_forward_skips_direct(h->N, cin_f, cout_f, h->D >> lvl, h->H >> lvl, h->W >> lvl);
+        if (h->precision == RU_PREC_BF16X3) RU_RUN(conv3_sb_pack_add(batch, P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, !h->training, s, skipd));
         // exact-f32 voxel-major inference: per-lane f32 fragments in the same slot (never larger than the split-bf16 ones)
         if (h->precision == RU_PREC_F32 && h->c16) RU_RUN(conv3_f32c_pack_weights(P(h, params, pidx), h->fpack + fk_off, cin_f, cout_f, mode, s));
         // outside the voxel-major flow the f32 layout is always kept: ragged W falls back to the f32 kernel
         if (!h->c16) RU_RUN(conv3_pack_weights(P(h, params, pidx), pk + pk_off, cin_f, cout_f, mode, s));
         return RU_OK;
     };
-    auto blk = [&](const BlockP& b) -> int {
-        int rc = pack3(b.conv1, b.pk_f1, b.fk_f1, b.c, b.c, 0); if (rc) return rc;
-        rc = pack3(b.conv2, b.pk_f2, b.fk_f2, b.c, b.c, 0); if (rc) return rc;
+    auto blk = [&](const BlockP& b, int lvl) -> int {
+        int rc = pack3(b.conv1, b.pk_f1, b.fk_f1, b.c, b.c, 0, lvl); if (rc) return rc;
+        rc = pack3(b.conv2, b.pk_f2, b.fk_f2, b.c, b.c, 0, lvl); if (rc) return rc;
         if (h->training) {
             rc = pack3(b.conv1, b.pk_d1, b.fk_d1, b.c, b.c, 1); if (rc) return rc;
             rc = pack3(b.conv2, b.pk_d2, b.fk_d2, b.c, b.c, 1); if (rc) return rc;
@@ -499,9 +503,9 @@ static int pack_all(ru_unet* h, const float* params, Arena& A, hipStream_t s) {
     { int rc = pack3(h->conv_in, h->pk_in, h->fk_in, kInCh, h->ch[0], 0); if (rc) return rc; }
     { int rc = pack3(h->conv_out_w, h->pk_out, h->fk_out, h->ch[0], h->nout, 0); if (rc) return rc; }
     if (h->training) { int rc = pack3(h->conv_out_w, h->pk_out_d, h->fk_out_d, h->ch[0], h->nout, 1); if (rc) return rc; }
-    for (auto& b : h->first_blocks) { int rc = blk(b); if (rc) return rc; }
-    for (auto& lv : h->enc_blocks) for (auto& b : lv) { int rc = blk(b); if (rc) return rc; }
-    for (int i = 0; i < h->depth - 1; ++i) for (auto& b : h->dec_blocks[i]) { int rc = blk(b); if (rc) return rc; }
+    for (auto& b : h->first_blocks) { int rc = blk(b, 0); if (rc) return rc; }
+    for (size_t lv = 0; lv < h->enc_blocks.size(); ++lv) for (auto& b : h->enc_blocks[lv]) { int rc = blk(b, (int)lv + 1); if (rc) return rc; }
+    for (int i = 0; i < h->depth - 1; ++i) for (auto& b : h->dec_blocks[i]) { int rc = blk(b, i); if (rc) return rc; }
     for (int i = 0; i < h->depth - 1; ++i) {
         if (h->c16 && !h->training) continue;             // the C16 forward reads the 1x1 weights as stored; the transposes feed its backward only
         RU_RUN(transpose_launch(P(h, params, h->up_w[i]), pk + h->pk_upT[i], h->ch[i], h->ch[i + 1], s));

@@ -180,7 +180,10 @@ int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, in
 constexpr int RU_PACK_BATCH = 64;
 struct SbPackEntry { const float* w; void* wfrag; int Cin_f, Cout_f, mode, nchunk, ncog, forms; };
 struct SbPackBatch { SbPackEntry e[RU_PACK_BATCH]; int n; };
-int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s);   // all_forms false: only the Winograd-z forms a training step launches
+// all_forms false: only the forms a training step launches (sb_pack_forms); skip_direct (training, forward weights): every launch that reads this pack takes the
+// Winograd-z / fp16 + MX-fp8 kernel of its shape, so the direct three-product fragments -- a third of a deep-level weight's bytes -- are not written
+int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s, bool skip_direct = false);
+bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W);     // a forward launch of this shape on activations (products == 2) takes a non-direct kernel under the current switches
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s);
 // pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:
 // the packed conv maps Cout_f input channels to Cin_f output channels).
