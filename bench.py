@@ -85,8 +85,20 @@ def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False):
         flops = 2.0 * taps * cin * cout * vo
         byts = 4.0 * (cin * vi + cout * vo)
         one = max(flops / peak, byts / bw)
-        t += one * (1 if forward_only else (3 if dgrad else 2))
+        # round 6: the FORWARD 3x3x3 convolutions between the stem and the head run the fp16 + MX-fp8 scheme (mx_executed_factor: 2.07 / 1.41 bf16-MFMA time
+        # units per algorithmic product instead of 3); data and weight gradients keep three products
+        fwd = max(flops * mx_executed_factor(cin, cout) / (BF16_MFMA_PEAK_TFLOPS * 1e12), byts / bw) if (taps == 27 and precision == "bf16x3" and mx_executed_factor(cin, cout)) else one
+        t += fwd + (0 if forward_only else one * (2 if dgrad else 1))
     return t * 1e3
+
+
+def mx_executed_factor(cin, cout):
+    """bf16-MFMA time units a forward 3x3x3 convolution executes per algorithmic product under the fp16 + MX-fp8 scheme (0: the layer keeps three bf16 products -- the
+    4-channel stem, the 3-channel head, RU_MX=0): conv3_mx_kernel 14 fp16 K-steps of two taps + 7 scaled MFMAs of twice the time for 27 taps = 28 / 13.5; conv3_wz32mx_kernel
+    (Winograd-z) 4 transformed planes x (9 + 5 x 2) for 2 x 27 taps = 76 / 54."""
+    if os.environ.get("RU_MX", "1") == "0" or cin != cout or cin % 16:
+        return 0.0
+    return 28.0 / 13.5 if cin == 16 else (76.0 / 54.0 if os.environ.get("RU_MX", "") != "1" else 0.0)
 
 
 def family_bounds(batch, size, precision):
@@ -115,8 +127,9 @@ def family_bounds(batch, size, precision):
     def conv3(cin, cout, vox, dgrad=True, count=1):
         lvl = "l0" if cout <= 16 and cin <= 16 else "deep"
         flops, byts = 2.0 * 27 * cin * cout * vox, 4.0 * (cin + cout) * vox
+        mxf = mx_executed_factor(cin, cout) if precision == "bf16x3" else 0.0
         for _ in range(count):
-            add("conv3_" + lvl, flops, byts, p3_alg, p3_exe)                        # forward
+            add("conv3_" + lvl, flops, byts, p3_alg, (bf16 / mxf) if mxf else p3_exe)   # forward (round 6: fp16 + MX-fp8 products between the stem and the head)
             if dgrad:
                 add("conv3_" + lvl, flops, byts, p3_alg, p3_exe)                    # data gradient
             add("wgrad3_" + lvl, flops, byts, p3_alg, p3_exe)                       # weight gradient: reads x and dy
@@ -236,7 +249,8 @@ INSTANCE_INFO = {
                    (r"^ru::conv3_mx_kernel", r"^ru::conv3_sb2_kernel<4, 8, true, true, false, false, false, 3, false>"), {0: 4}),
     "conv16_dgrad": ("conv3_sb2_kernel<4,8,true,true,false,BST,ADD,3,false> (3x3x3 data gradient 16->16, split-form input, GroupNorm-backward sums / residual in the epilogue)",
                      (r"^ru::conv3_sb2_kernel<4, 8, true, true, false, (true, false|true, true|false, true), 3, false>",), {0: 4}),
-    "conv_deep_fwd": ("conv3_wz32_kernel (3x3x3 conv forward, 32-128 channels: Winograd F(2,3) along z on 32x32x16 MFMAs)", (r"^ru::conv3_wz32_kernel",), {1: 6, 2: 6, 3: 8}),
+    "conv_deep_fwd": ("conv3_wz32mx_kernel (3x3x3 conv forward, 32-128 channels: Winograd F(2,3) along z, fp16 + MX-fp8 products on 32x32 MFMA tiles; RU_MX=0: conv3_wz32_kernel)",
+                      (r"^ru::conv3_wz32mx_kernel", r"^ru::conv3_wz32_kernel"), {1: 6, 2: 6, 3: 8}),
     "conv_deep_dgrad": ("conv3_sb2_kernel<4,8,true,true,true,BST,ADD,3,false> (3x3x3 data gradient, 32-128 channels)", (r"^ru::conv3_sb2_kernel<4, 8, true, true, true,",), {1: 6, 2: 6, 3: 8}),
     "wgrad16_fused_apply": ("wgrad3_tz_kernel<1,0,3,3> (3x3x3 weight gradient 16->16 with the GroupNorm-backward apply fused into its dy staging)", (r"^ru::wgrad3_tz_kernel<1, 0, 3, 3>",), {0: 4}),
     "wgrad16_plain": ("wgrad3_tz_kernel<1,0,...> (3x3x3 weight gradient 16->16, plain dy)", (r"^ru::wgrad3_tz_kernel<1, 0, [012], 3>",), {0: 4}),
@@ -406,7 +420,7 @@ def roofline_families(backend, one_step, batch, size, precision, step_ms, steps=
             row["frac_executed"] = round(b["bound_ms_executed"] / ms, 4) if ms > 0 else None
         out.append(row)
     kernels = {"conv3_l0": "conv3_mx_kernel (16->16 forward) + conv3_sb2_kernel<4,8,C16,C16,one chunk> (data gradient, head) + conv3_sb2c4_kernel (stem, head gradient): 3x3x3 convs of the 16-channel level",
-               "conv3_deep": "conv3_wz32_kernel (forward: Winograd-z on 32x32x16 MFMAs) + conv3_sb2_kernel<4,8,C16,C16,MULTI> (data gradient), 32-128 channels",
+               "conv3_deep": "conv3_wz32mx_kernel (forward: Winograd-z, fp16 + MX-fp8 products) + conv3_sb2_kernel<4,8,C16,C16,MULTI> (data gradient, three bf16 products), 32-128 channels",
                "wgrad3_l0": "wgrad3_tz_kernel<1,...> (3x3x3 weight gradient + fused GroupNorm-backward apply, 16-channel level)",
                "wgrad3_deep": "wgrad3_tz_kernel<2,0,1> (3x3x3 weight gradient, 32-128 channels)",
                "groupnorm": "gn_apply16 / gn_bwd_apply16_split / gn_bwd_reduce16 / finalize kernels",
@@ -854,7 +868,9 @@ def main():
                                "%d^3 x 4ch synthetic crops, per-GPU batch %d (BASELINE configs[2], weak-scaled as configs[3])" % (args.size, args.batch),
                    "global_batch": args.batch * world, "per_gpu_batch": args.batch, "volume": [args.size] * 3, "in_channels": 4,
                    "parallelism": "dp%d" % world,
-                   "precision": ("fp32 tensors in HBM; 3x3x3 conv fwd + data gradient + weight gradient on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 accumulate); "
+                   "precision": ("fp32 tensors in HBM; 3x3x3 data gradient + weight gradient (and the 4- / 3-channel ends) on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 "
+                                 "accumulate); 3x3x3 FORWARD convolutions: fp16 main product (v_mfma_f32_*_f16) + both cross terms in OCP e4m3 on the MX-scaled fp8 MFMA "
+                                 "(v_mfma_scale_f32_*_f8f6f4), fp32 accumulate -- the same 2^-16 error class (RU_MX=0: three bf16 products there too); "
                                  "the 1x1 / 2x2x2 convolutions, GroupNorm, trilinear, criterion and Adam in fp32") if args.precision == "bf16x3" else "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
         "final_loss": round(loss, 6),
         "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
