@@ -678,6 +678,10 @@ int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
     b.n = 0;
     return RU_OK;
 }
+int conv3_sb_switch_signature() {
+    const char* e = getenv("RU_WZ");
+    return ((e && *e == '0') ? 0 : 1) | (conv3_wz32_enabled() ? 2 : 0) | (conv3_mx_enabled() ? 4 : 0) | (conv3_mx_wz_enabled() ? 8 : 0);
+}
 bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W) {
     if (conv3_sb_uses_wz(N, Cin, Cout, D, H, W, 2)) return true;                    // conv3_wz32mx_kernel or conv3_wz32_kernel
     return conv3_mx_enabled() && conv3_mx_shape_ok(N, Cin, Cout, D, H, W);          // conv3_mx_kernel

@@ -234,6 +234,7 @@ struct ru_unet {
     const void* packed_base = nullptr;
     int packed_prec = -1;
     bool packed_c16 = false;
+    int pack_sig = -1;                   // conv3_sb_switch_signature() when the packs of the last forward were written
     float *y0 = nullptr, *t0 = nullptr, *probs = nullptr;
     GNSave g0;
     const float* head_in = nullptr;
@@ -789,7 +790,7 @@ static int unet_forward_impl(ru_unet* h, const float* params, const float* x, fl
         a.in_sum_out = head_block->out;                  // (training: the block output, written on the way; null in inference)
     }
     RU_RUN(conv3_launch(a, s));
-    if (!A.dry) { h->packed_params = h->training ? nullptr : params; h->packed_base = h->pack; h->packed_prec = h->precision; h->packed_c16 = h->c16; }   // a training forward is followed by an optimizer step
+    if (!A.dry) { h->packed_params = h->training ? nullptr : params; h->packed_base = h->pack; h->packed_prec = h->precision; h->packed_c16 = h->c16; h->pack_sig = conv3_sb_switch_signature(); }   // a training forward is followed by an optimizer step
     return RU_OK;
 }
 
@@ -1377,6 +1378,10 @@ static int backward_entry(ru_unet_t h, const float* params, const float* dprobs,
     h->red.main.e.clear();
     h->red.side.e.clear();
     ru::t_red = (h->fusion & RU_FUSE_BATCH_WREDUCE) && !trace_on() ? &h->red : nullptr;
+    // a training forward packs only the fragment forms its switches launch (sb_pack_forms): a switch flipped between that forward and this backward would make
+    // a launch read fragments that were never packed -- refused instead (round-5 advisor finding; tools and tests toggle between steps, which is fine)
+    RU_REQUIRE(h->precision != RU_PREC_BF16X3 || h->pack_sig == conv3_sb_switch_signature(),
+               "ru_unet_backward: RU_WZ / RU_MX changed since the forward whose packs this backward reads (signature %d then, %d now)", h->pack_sig, conv3_sb_switch_signature());
     int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream, crit);
     ru::t_red = nullptr;
     ru::t_sink = nullptr;

@@ -183,6 +183,8 @@ struct SbPackBatch { SbPackEntry e[RU_PACK_BATCH]; int n; };
 // all_forms false: only the forms a training step launches (sb_pack_forms); skip_direct (training, forward weights): every launch that reads this pack takes the
 // Winograd-z / fp16 + MX-fp8 kernel of its shape, so the direct three-product fragments -- a third of a deep-level weight's bytes -- are not written
 int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s, bool skip_direct = false);
+int conv3_sb_switch_signature();                   // the kernel-choice switches as the launches read them now (RU_WZ, RU_MX, devtools RU_WZ32): the engine records it with a
+                                                  // training forward's packs and refuses a backward under another signature (packs hold only the forms that signature launches)
 bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W);     // a forward launch of this shape on activations (products == 2) takes a non-direct kernel under the current switches
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s);
 // pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:

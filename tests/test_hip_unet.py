@@ -1018,6 +1018,28 @@ def _backward_in_context(L, loss):
         loss.backward()
 
 
+def test_backward_refuses_switches_flipped_since_its_forward():
+    """round-5 advisor finding: a training forward packs only the fragment forms its kernel switches launch; a switch flipped between that forward and the
+    backward would make a launch read fragments that were never packed.  The engine records the switches' signature with the packs and refuses such a backward
+    loudly; the next forward under the new switches works."""
+    import os
+    from brats2019_amd import loss as L
+    net, _ = build_model(O.DEFAULT_CFG, 5, "bf16x3")
+    x = T(O.make_input(1, 32, 32, 32, seed=5)).cuda()
+    g = T(O.make_target(1, 32, 32, 32, seed=5)).cuda()
+    net.train()
+    loss = L.FusedCriterion()(net([x]), [g])
+    os.environ["RU_MX"] = "0"
+    try:
+        with pytest.raises(RuntimeError, match="RU_WZ / RU_MX changed"):
+            loss.backward()
+        loss = L.FusedCriterion()(net([x]), [g])            # packed under the new switches: fine
+        loss.backward()
+    finally:
+        os.environ.pop("RU_MX", None)
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
 def test_forward_convolution_kernels_agree_through_the_network():
     """The three sets of FORWARD 3x3x3 kernels inside the engine on one batch-2 x 128^3 training step: the default (fp16 + MX-fp8 products: conv3_mx_kernel at
     16 channels, conv3_wz32mx_kernel = Winograd-z at 32..128), RU_MX=0 (three bf16 products: conv3_sb2_kernel, conv3_wz32_kernel) and RU_MX=0 + RU_WZ=0
