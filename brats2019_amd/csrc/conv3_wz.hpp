@@ -35,13 +35,13 @@ namespace ru {
 // devtools bit 128: consumer wave 0 of every workgroup adds s_memtime section sums here (cycles): [0] item setup, [1] rows 0-4, [2] rows 5-9 + row 7's
 // scratch write, [3] barrier, [4] items, [5] tail after the loop, [6] workgroups, [7] staging wave 0: cycles from item barrier to item barrier spent in store + issue
 static __device__ unsigned long long wz_prof[8];
-// The staging waves (waves 4..7 of a workgroup) of both Winograd-z kernels (conv3_wz_kernel here, conv3_wz32_kernel in conv3_wz32.hpp): the transformed,
-// split image of item w+1 is written while the matrix waves work on item w; one __syncthreads per item, two closing ones.  `pad_lds`: 1 KB of LDS
-// nobody reads (landing zone of the operand-row prefetch of the BST / ADD variants).
+// The staging waves (waves 4..7 of a workgroup) of the Winograd-z kernels (conv3_wz32_kernel, conv3_wz32mx_kernel; conv3_wz_kernel here in devtools builds): the
+// transformed, split image of item w+1 is written while the matrix waves work on item w; one __syncthreads per item, two closing ones.  Plain float32 or
+// fused-transform input (the forward convolutions: the split-form / data-gradient routes of round 5 are retired).
 // MX (conv3_wz32mx_kernel, round 6): the image is written in the operand formats of the fp16 + MX-fp8 product scheme (conv3_mx.hpp) -- sections 0 / 1 fp16 halves
 // (the bf16 hi sections' layout), section 2 e4m3(lo * 2^11), section 3 e4m3(value), 16 channels of a position per 16-byte packet -- plain or fused-transform input only.
-template <bool BST, bool ADD, int dbg, bool MX = false>
-__device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, float* pad_lds, int rw, int lane, int cog32, int swz, int G, int nitems, int nchunk,
+template <int dbg, bool MX = false>
+__device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, int rw, int lane, int swz, int G, int nitems, int nchunk,
                                                int tiles_per_sample, int nty, int ntx) {
     if constexpr (MX) mx_set_saturating_conversions();
     constexpr int HX = WZ_HX, HVOLP = WZ_HVOLP, BUF = WZ_BUF;
@@ -58,7 +58,6 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
     };
     // ---------------------------------------------------------------- producers
     const bool xform = a.in_scale != nullptr;
-    const bool s16 = a.in_s16 != 0;
     const float slope = xform ? a.in_slope : 1.f;
     // lane = (position within a block of 16, channel quad): the four lanes of a position load its 64 bytes as ONE contiguous line piece
     // (a first version gave a lane pair half a voxel and two wave-rounds per block: every load touched 32 lines and used half of each,
@@ -74,7 +73,7 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
         pin[rd] = p < WZ_PLANE;
         ppos[rd] = p;
         pyx[rd] = hy | (xc << 8);
-        dlt[rd] = (hy * W + xc) * 64 + (s16 ? hf * 16 + q0 * 8 : quad * 16);
+        dlt[rd] = (hy * W + xc) * 64 + quad * 16;
     }
     // TWO register sets of loads in flight: the loads of item w+3 are issued when item w+1 has been converted, and consumed two item
     // barriers later.  With one set (issue(w+2) right before the barrier, store(w+2) right behind it) the staging waves -- the pole of this
@@ -111,16 +110,7 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
                 constexpr int pz = decltype(PZ)::value;
                 const bool okz = ok & ((unsigned)(zm1 + pz) < (unsigned)D);
                 const unsigned ofs = okz ? (unsigned)(base + dlt[rd] + pz * pstride) : 0x80000000u;
-                if (s16) {                                           // hi dwords at +0, lo dwords at +32 (gn_bwd_apply16's packet layout)
-                    // four dword loads: __builtin_amdgcn_raw_buffer_load_b64 compiles to ONE buffer_load_dword on this toolchain (ROCm 7.2
-                    // hipcc: the second element is never loaded) -- found by tests/test_hip_c16.py::test_conv3_split_form_input
-                    v[rd][pz] = make_float4(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 0, 0)),
-                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 4, 0)),
-                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 32, 0)),
-                                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ofs, 36, 0)));
-                } else {
-                    v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
-                }
+                v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
             });
             if (xform) {
                 const int cofs = n * a.Cin + chunk * 16 + quad * 4;
@@ -150,7 +140,7 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
         uint2* b2 = reinterpret_cast<uint2*>(buf);
         const float mz0 = zok0 ? 1.f : 0.f, mz3 = zok3 ? 1.f : 0.f;
         auto body = [&](auto MODE) __attribute__((always_inline)) {
-            constexpr int mode = decltype(MODE)::value;                      // 0 plain fp32, 1 fused affine + LeakyReLU, 2 split form
+            constexpr int mode = decltype(MODE)::value;                      // 0 plain fp32, 1 fused affine + LeakyReLU
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) {
                 if (!pin[rd]) continue;
@@ -185,16 +175,6 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
                             d[pz][c] = fmaxf(u, u * slope);
                         }
                     }
-                } else if constexpr (mode == 2) {
-#pragma unroll
-                    for (int pz = 0; pz < 4; ++pz) {
-                        const unsigned h0 = __builtin_bit_cast(unsigned, v[rd][pz].x), h1 = __builtin_bit_cast(unsigned, v[rd][pz].y);
-                        const unsigned l0 = __builtin_bit_cast(unsigned, v[rd][pz].z), l1 = __builtin_bit_cast(unsigned, v[rd][pz].w);
-                        d[pz][0] = __builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16);
-                        d[pz][1] = __builtin_bit_cast(float, h0 & 0xffff0000u) + __builtin_bit_cast(float, l0 & 0xffff0000u);
-                        d[pz][2] = __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16);
-                        d[pz][3] = __builtin_bit_cast(float, h1 & 0xffff0000u) + __builtin_bit_cast(float, l1 & 0xffff0000u);
-                    }
                 } else {
 #pragma unroll
                     for (int pz = 0; pz < 4; ++pz) { d[pz][0] = v[rd][pz].x; d[pz][1] = v[rd][pz].y; d[pz][2] = v[rd][pz].z; d[pz][3] = v[rd][pz].w; }
@@ -223,38 +203,8 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
                 }
             }
         };
-        if (s16) body(std::integral_constant<int, 2>{});
-        else if (xform) body(std::integral_constant<int, 1>{});
+        if (xform) body(std::integral_constant<int, 1>{});
         else body(std::integral_constant<int, 0>{});
-    };
-    // Row operands of the epilogue (BST: the forward tensor y; ADD: the residual): the combining waves read them one fragment step ahead of their
-    // use, which hides an L1 / L2 hit but not a trip to HBM -- loaded cold they cost 28-40 us per launch (tools: devtools bit 512).  The staging
-    // waves therefore TOUCH the 32 operand rows of a tile one item before it is combined: LDS-DMA loads (no VGPRs, never dead-code) of one row
-    // (16 voxels x 64 bytes of a 16-channel block = 1 KB = one wave-wide 16-byte load) each, landing in a 1 KB pad nobody reads.
-    auto prefetch_rows = [&](int item) {
-        if constexpr (BST || ADD) {
-            if constexpr ((dbg & 1024) != 0) return;
-            const int step = item / nchunk;
-            int n, z0, y0, x0;
-            tile_origin(swz + step * G, n, z0, y0, x0);
-            auto pad = (__attribute__((address_space(3))) void*)(pad_lds);
-            const int xv = x0 + (lane >> 2);                         // this lane's voxel of the row
-            static_for<(BST ? 1 : 0) + (ADD ? 1 : 0)>([&](auto T) __attribute__((always_inline)) {
-                const float* base = (BST && decltype(T)::value == 0) ? a.bst_y : a.add;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float* blk = base + ((size_t)(n * (a.Cout >> 4) + cog32 * 2 + g) * DHW) * 16;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blk), 0, (int)(DHW * 64), 0x00020000);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {                    // 16 (plane, row) pairs of this group: four per staging wave
-                        const int pr = rw * 4 + q, pzz = pr >> 3, yy = y0 + (pr & 7);
-                        const bool ok = (yy < H) & (xv < W);
-                        const unsigned ofs = ok ? (unsigned)((((z0 + pzz) * H + yy) * W + x0) * 64 + lane * 16) : 0x80000000u;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, pad, 16, ofs, 0, 0, 0);
-                    }
-                }
-            });
-        }
     };
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
@@ -269,7 +219,6 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
     for (int w = 0; w < nitems; w += 2) {            // item w+1 lives in set 1, item w+2 in set 0
         unsigned long long t0 = 0;
         if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
-        if (w % nchunk == nchunk - 1) prefetch_rows(w);      // (the consumers are on item w: its tile is combined during item w+1)
         if (w + 1 < nitems) {
             store(S1, lds + BUF);
             if (w + 3 < nitems) issue(S1, w + 3);
@@ -278,7 +227,6 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, f
         __syncthreads();
         if (w + 1 >= nitems) break;
         if constexpr ((dbg & 128) != 0) t0 = __builtin_readcyclecounter();
-        if ((w + 1) % nchunk == nchunk - 1) prefetch_rows(w + 1);
         if (w + 2 < nitems) {
             store(S0, lds);
             if (w + 4 < nitems) issue(S0, w + 4);
@@ -320,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz_kernel(const Conv3Args a, con
     const int nitems = nsteps * nchunk;
 
     if (producer) {
-        wz_stage_waves<BST, ADD, dbg>(a, lds, stat_lds + SB_STAT_LDS_FLOATS, rw, lane, cog32, swz, G, nitems, nchunk, tiles_per_sample, nty, ntx);
+        wz_stage_waves<dbg>(a, lds, rw, lane, swz, G, nitems, nchunk, tiles_per_sample, nty, ntx);
     } else {
         // ---------------------------------------------------------------- consumers
         const int xi = rw;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wz32mx_kernel(const Conv3Args a,
     const int nitems = nsteps * nchunk;
 
     if (producer) {
-        wz_stage_waves<false, false, dbg, true>(a, lds, nullptr, rw, lane, cog32, swz, G, nitems, nchunk, tiles_per_sample, nty, ntx);
+        wz_stage_waves<dbg, true>(a, lds, rw, lane, swz, G, nitems, nchunk, tiles_per_sample, nty, ntx);
     } else {
         // ---------------------------------------------------------------- matrix waves: wave xi owns transformed plane xi
         const int xi = rw;

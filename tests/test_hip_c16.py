@@ -120,7 +120,7 @@ def test_conv3_winograd_z_against_float64(shape):
     assert e_mx <= 1.2e-4 and e_mx <= 4 * res["direct"][0] + 1e-6, (e_mx, res)
 
 
-MX_SHAPES = [(2, 16, 16, 64, 64, 64), (1, 16, 16, 40, 60, 72), (3, 16, 32, 32, 32, 48), (1, 16, 16, 128, 128, 128)]
+MX_SHAPES = [(2, 16, 16, 64, 64, 64), (1, 16, 16, 40, 60, 72), (3, 16, 32, 32, 32, 48), (1, 16, 16, 128, 128, 128), (2, 16, 16, 30, 44, 40)]
 
 
 @pytest.mark.parametrize("shape", MX_SHAPES, ids=["%dx%d-%d_%dx%dx%d" % s for s in MX_SHAPES])
