@@ -41,19 +41,31 @@ static __device__ unsigned long long wz_prof[8];
 // MX (conv3_wz32mx_kernel, round 6): the image is written in the operand formats of the fp16 + MX-fp8 product scheme (conv3_mx.hpp) -- sections 0 / 1 fp16 halves
 // (the bf16 hi sections' layout), section 2 e4m3(lo * 2^11), section 3 e4m3(value), 16 channels of a position per 16-byte packet -- plain or fused-transform input only.
 template <int dbg, bool MX = false>
+// zcol_ntz > 0: the COLUMN walk -- workgroup swz owns the tiles q in [swz * nsteps, (swz + 1) * nsteps) of the z-fastest order q = ((n * nty + ty) * ntx + tx) * ntz + tz, so
+// consecutive tiles of a workgroup are z neighbours (the two input planes they share were loaded by the same CU nchunk items earlier: L2 hits) and the workgroups of an XCD
+// cover adjacent columns; 0: tile swz + step * G of the x-fastest order (a step's tiles form z slabs, the z neighbour belongs to another XCD: both fetch the planes).
 __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, int rw, int lane, int swz, int G, int nitems, int nchunk,
-                                               int tiles_per_sample, int nty, int ntx) {
+                                               int tiles_per_sample, int nty, int ntx, int zcol_ntz = 0) {
     if constexpr (MX) mx_set_saturating_conversions();
     constexpr int HX = WZ_HX, HVOLP = WZ_HVOLP, BUF = WZ_BUF;
     const int D = a.D, H = a.H, W = a.W;
     const size_t DHW = (size_t)D * H * W;
-    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-        int b = tile;
-        n = b / tiles_per_sample;
-        b -= n * tiles_per_sample;
-        const int tx = b % ntx; b /= ntx;
-        const int ty = b % nty;
-        const int tz = b / nty;
+    const int nsteps_wg = nitems / nchunk;
+    auto tile_origin = [&](int step, int& n, int& z0, int& y0, int& x0) {
+        int tz, ty, tx;
+        if (zcol_ntz > 0) {
+            int b = swz * nsteps_wg + step;
+            tz = b % zcol_ntz; b /= zcol_ntz;
+            tx = b % ntx; b /= ntx;
+            ty = b % nty; n = b / nty;
+        } else {
+            int b = swz + step * G;
+            n = b / tiles_per_sample;
+            b -= n * tiles_per_sample;
+            tx = b % ntx; b /= ntx;
+            ty = b % nty;
+            tz = b / nty;
+        }
         z0 = tz * 2; y0 = ty * 8; x0 = tx * 16;
     };
     // ---------------------------------------------------------------- producers
@@ -93,7 +105,7 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, i
         if constexpr ((dbg & 2) != 0) return;
         const int step = item / nchunk, chunk = item - step * nchunk;
         int n, z0, y0, x0;
-        tile_origin(swz + step * G, n, z0, y0, x0);
+        tile_origin(step, n, z0, y0, x0);
         const float* xb = a.x + ((size_t)(n * nchunk + chunk) * DHW) * 16;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)(DHW * 64), 0x00020000);
         const int zm1 = z0 - 1, ym1 = y0 - 1, xm1 = x0 - 1;
