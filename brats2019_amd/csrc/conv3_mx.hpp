@@ -112,6 +112,22 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
             pk[r] = hz | (hy << 8) | (xc << 16);
             dlt[r] = ((hz * H + hy) * W + xc) * 64 + (int)lofs;
         }
+        // devtools bit 2048 (results wrong): the two loads of a round take whole 64-byte voxels -- lane = (position, 16-byte quarter), first load positions
+        // [32 w, 32 w + 16) of the round's 128, second [32 w + 16, 32 w + 32) -- instead of half a voxel per lane: what does the access shape of the loads cost?
+        int pkq[(dbg & 2048) ? NR : 1][2], dltq[(dbg & 2048) ? NR : 1][2];
+        if constexpr ((dbg & 2048) != 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    int p = r * 128 + (ptid >> 6) * 32 + j * 16 + ((ptid & 63) >> 2);
+                    if (p >= NPOS) p = NPOS - 1;
+                    const int row = p / HX, xc = p - row * HX;
+                    const int hz = row / HY, hy = row - hz * HY;
+                    pkq[r][j] = hz | (hy << 8) | (xc << 16);
+                    dltq[r][j] = ((hz * H + hy) * W + xc) * 64 + (ptid & 3) * 16;
+                }
+        }
         const bool plast = (NR - 1) * 128 + pslot < NPOS;
         constexpr int CR = (2 * HY * HX) / 128;
         bool st_chain = false;
@@ -133,6 +149,15 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                 if constexpr ((r + 1) * 128 > NPOS) ok = ok & plast;
                 const unsigned ofs = ok ? (unsigned)(base + dlt[r]) : 0x80000000u;       // out of range: the load returns the zero padding
                 vmask |= ok ? (1u << r) : 0u;
+                if constexpr ((dbg & 2048) != 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int qz = zm1 + (pkq[r][j] & 0xff), qy = ym1 + ((pkq[r][j] >> 8) & 0xff), qx = xm1 + ((pkq[r][j] >> 16) & 0xff);
+                        const bool qok = ((unsigned)qz < (unsigned)D) & ((unsigned)qy < (unsigned)H) & ((unsigned)qx < (unsigned)W);
+                        v16[r][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, qok ? (unsigned)(base + dltq[r][j]) : 0x80000000u, 0, 0));
+                    }
+                    return;
+                }
                 v16[r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
                 v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 16, 0));
             };
