@@ -21,7 +21,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  package limit -- the 3x3x3 kernels run AT the limit, which is what bounds them,
   cpu_baseline : the CPU oracle (the reference's op sequence on torch CPU) timed on this host on a bounded sample (median of 3),
   train_bf16_grad : the same training step with the opt-in gradient precision RU_PREC_BF16 (one MFMA product in the gradient convolutions),
-  fwd          : forward-only volumes/s at batch 1 in the precision of the run (at every N: N independent replicas),
+  fwd          : forward-only volumes/s at batch 1 in the precision of the run (at every N: N independent replicas); `roofline_frac` keeps the yardstick of rounds
+                 1-5 (three bf16 products per 3x3x3 product), `roofline_frac_executed` / `_algorithmic` price this build's executed units / one product,
   fwd_batch    : forward-only volumes/s at the per-GPU batch of the training configuration (batch 4),
   fwd_f32      : the batch-1 forward in exact-f32 arithmetic (BASELINE configs[1]: fp32 forward, batch 1),
   trainer_step : the same training step driven through the reference surface (train.Trainer._train_one_epoch set up as main.py:126-142),
@@ -33,7 +34,8 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
   roofline_top : the three largest families of the step, each with launches, average launch time and fraction of its own bound, followed by the three
                  largest SINGLE kernel instantiations (rows with "instance": the executor tags their launches, ru_unet_probe_read_families) with algorithmic
                  FLOPs / bytes, the bytes the kernel really moves (committed counter table) and both fractions,
-  whole_step_frac : the step against the per-layer roofline priced on ALGORITHMIC FLOPs (`_executed`: on the three split-bf16 products;
+  whole_step_frac : the step against the per-layer roofline priced on ALGORITHMIC FLOPs (`_executed`: on the matrix time units this build executes -- three split-bf16
+                 products, forward convolutions 2.07 / 1.41 under the fp16 + MX-fp8 scheme; `_three_products`: the yardstick of rounds 1-5;
                  `_achievable` / `whole_step_achievable`: plus the bytes no fusion removes for fp32 tensors -- achievable_bounds),
 and at N > 1
   allreduce_ms : the two collectives of a step timed in place (HIP event pairs on the kernels' stream, max over ranks), `step_ms_per_rank`,
@@ -58,14 +60,18 @@ FWD_GFLOP_PER_VOL = 299.37        # algorithmic conv FLOPs per 128^
 FWDBWD_GFLOP_PER_VOL = 890.87     # forward + backward
 
 
-def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False):
+def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False, pricing="executed"):
     """Per-layer roofline of one step (SURVEY 8(d) / BASELINE.md section 4): sum over the convolutions of
     max(executed FLOPs / MFMA peak, compulsory fp32 bytes / HBM peak), forward + data gradient + weight gradient.  3x3x3 convs:
     split-bf16 executes 3 products per algorithmic one at the dense bf16 peak (f32 mode: exact-f32 MFMA peak); 1x1 / 2x2x2 convs run
     on the f32 MFMA in both modes.  Bytes = input + output tensor (weight gradient: x + dy), fp32 -- the fused lower bound where
     GroupNorm / LeakyReLU / residual / up-sampling ride on the convolutions' traffic."""
+    # pricing of the 3x3x3 convolutions in bf16x3 mode: "executed" = the matrix time units the kernels of THIS build execute (three bf16 products; forward convolutions
+    # between the stem and the head: the fp16 + MX-fp8 scheme, mx_executed_factor); "three" = three bf16 products everywhere (the yardstick of rounds 1-5: keeps
+    # `roofline_frac` of the forward legs comparable across rounds); "algorithmic" = one product at the dense bf16 peak (implementation independent)
     ch, enc = [16, 32, 64, 128], [1, 2, 2, 4]
-    peak3 = (BF16_MFMA_PEAK_TFLOPS / 3.0 if precision == "bf16x3" else F32_MFMA_PEAK_TFLOPS) * 1e12     # algorithmic FLOP/s of a 3^3 conv
+    per3 = 1.0 if pricing == "algorithmic" else 3.0
+    peak3 = (BF16_MFMA_PEAK_TFLOPS / per3 if precision == "bf16x3" else F32_MFMA_PEAK_TFLOPS) * 1e12     # algorithmic FLOP/s of a 3^3 conv
     peak1 = F32_MFMA_PEAK_TFLOPS * 1e12
     bw = HBM_PEAK_GBPS * 1e9
     v = [float(batch) * (size >> i) ** 3 for i in range(4)]
@@ -87,7 +93,7 @@ def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False):
         one = max(flops / peak, byts / bw)
         # round 6: the FORWARD 3x3x3 convolutions between the stem and the head run the fp16 + MX-fp8 scheme (mx_executed_factor: 2.07 / 1.41 bf16-MFMA time
         # units per algorithmic product instead of 3); data and weight gradients keep three products
-        fwd = max(flops * mx_executed_factor(cin, cout) / (BF16_MFMA_PEAK_TFLOPS * 1e12), byts / bw) if (taps == 27 and precision == "bf16x3" and mx_executed_factor(cin, cout)) else one
+        fwd = max(flops * mx_executed_factor(cin, cout) / (BF16_MFMA_PEAK_TFLOPS * 1e12), byts / bw) if (pricing == "executed" and taps == 27 and precision == "bf16x3" and mx_executed_factor(cin, cout)) else one
         t += fwd + (0 if forward_only else one * (2 if dgrad else 1))
     return t * 1e3
 
@@ -634,7 +640,7 @@ def predict_case_probe(backend, flat, precision, reps=3):
         fwd()
         dtf = time_region(fwd, reps, False) / reps
     vox = float(padded[0] * padded[1] * padded[2])
-    bound = step_roofline_ms(4, 128, precision, forward_only=True) * vox / 128.0 ** 3
+    bound = step_roofline_ms(4, 128, precision, forward_only=True, pricing="three") * vox / 128.0 ** 3        # (the yardstick of rounds 1-5: three bf16 products)
     del net
     return {"value": round(1.0 / dt, 3), "unit": "cases/s", "ms_per_case": round(dt * 1e3, 2), "case": list(shape), "padded_crop": list(padded), "tta_flips": 4,
             "precision": precision, "roofline_ms_forward": round(bound, 3), "roofline_frac": round(bound / (dt * 1e3), 4),
@@ -885,6 +891,9 @@ def main():
     out["whole_step_roofline_ms_executed"] = round(exe_ms, 3)
     out["whole_step_frac_executed"] = round(exe_ms / (1e3 * dt / args.steps), 4)
     out["whole_step_frac_algorithmic"] = out["whole_step_frac"]       # (the key earlier rounds carried it under)
+    # (`_executed` prices what THIS build executes: since round 6 the forward 3x3x3 convolutions cost 28/13.5 and 76/54 bf16-MFMA time units per algorithmic product
+    # instead of 3; the figure of rounds 1-5 -- three products everywhere -- stays available for comparison)
+    out["whole_step_frac_three_products"] = round(step_roofline_ms(args.batch, args.size, args.precision, pricing="three") / (1e3 * dt / args.steps), 4)
     # ... and against the bound that counts the passes NO fusion removes for fp32 tensors (family_bounds / achievable_bounds): the third figure
     ab = achievable_bounds(fb)
     out["whole_step_frac_achievable"] = round(ab["achievable_ms"] / (1e3 * dt / args.steps), 4)
@@ -951,7 +960,9 @@ def main():
         backend.engine.freeze_params(False)
         out["fwd"] = {"value": round(world * it / dtf, 3), "unit": "volumes/s", "batch": 1, "replicas": world, "ms": round(1e3 * dtf / it, 3), "precision": args.precision,
                       "algorithmic_tflops": round(world * it / dtf * FWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),
-                      "roofline_frac": round(step_roofline_ms(1, args.size, args.precision, forward_only=True) / (1e3 * dtf / it), 4)}
+                      "roofline_frac": round(step_roofline_ms(1, args.size, args.precision, forward_only=True, pricing="three") / (1e3 * dtf / it), 4),
+                      "roofline_frac_executed": round(step_roofline_ms(1, args.size, args.precision, forward_only=True) / (1e3 * dtf / it), 4),
+                      "roofline_frac_algorithmic": round(step_roofline_ms(1, args.size, args.precision, forward_only=True, pricing="algorithmic") / (1e3 * dtf / it), 4)}
     if not args.no_extras:
         backend.engine.freeze_params(True)
         # forward throughput at the batch of the training configuration (BASELINE configs[2]: batch 4): the same kernels with the deep
@@ -962,7 +973,9 @@ def main():
         dtb = time_region(fwdb, it, distributed)
         out["fwd_batch"] = {"value": round(world * args.batch * it / dtb, 3), "unit": "volumes/s", "batch": args.batch, "replicas": world, "ms": round(1e3 * dtb / it, 3),
                             "precision": args.precision,
-                            "roofline_frac": round(step_roofline_ms(args.batch, args.size, args.precision, forward_only=True) / (1e3 * dtb / it), 4)}
+                            "roofline_frac": round(step_roofline_ms(args.batch, args.size, args.precision, forward_only=True, pricing="three") / (1e3 * dtb / it), 4),
+                      "roofline_frac_executed": round(step_roofline_ms(args.batch, args.size, args.precision, forward_only=True) / (1e3 * dtb / it), 4),
+                      "roofline_frac_algorithmic": round(step_roofline_ms(args.batch, args.size, args.precision, forward_only=True, pricing="algorithmic") / (1e3 * dtb / it), 4)}
         backend.engine.freeze_params(False)
     if rank == 0 and world == 1 and not args.no_extras:
         backend.engine.freeze_params(True)
