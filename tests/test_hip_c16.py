@@ -154,6 +154,20 @@ def test_conv3_mx_against_float64(shape):
     assert e_mx <= 1.2e-4 and e_mx <= 4 * e_sb + 1e-6, (e_mx, e_sb)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16, 16, 16, 16), (1, 32, 32, 8, 16, 16), (2, 16, 3, 32, 32, 32)], ids=["small16", "small32", "head"])
+def test_conv3_activation_flag_falls_back_to_three_products(shape):
+    """Shapes that have no fp16 + MX-fp8 kernel (grids below one persistent workgroup per CU: the one-stage kernel; the 3-channel head form) must ignore the
+    activation flag: bit-identical to the launch without it."""
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = shape
+    x = _rand(n, cin, d, h, w, seed=31)
+    wt = _rand(cout, cin, 3, 3, 3, seed=32) * 0.05
+    out16 = cout % 16 == 0
+    a = ops.conv3d_layout(ops.to_c16(x), wt, in_c16=True, out_c16=out16, activations=True)
+    b = ops.conv3d_layout(ops.to_c16(x), wt, in_c16=True, out_c16=out16)
+    assert torch.equal(a, b)
+
+
 def test_conv3_mx_saturates_instead_of_nan():
     """Activations beyond the e4m3 range of the cross terms (|x| > 448, and residuals beyond 448 / 2^11) must degrade the cross terms, never poison the output:
     the staging waves run with MODE.FP16_OVFL, under which v_cvt_pk_fp8_f32 / v_cvt_pk_f16_f32 saturate (tools/mx_ovfl_probe.hip; without it the e4m3
