@@ -31,7 +31,8 @@ __host__ __device__ constexpr int mx_ninth_tap(int j, int slot) {
 
 // two floats -> two e4m3 bytes in the low / high half of a dword (round to nearest even; saturating under MODE.FP16_OVFL)
 __device__ __forceinline__ unsigned mx_cvt4(float a, float b, float c, float d) {
-    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    // (the first conversion's pass-through operand is `a` itself: its other half is overwritten by the second one, and a zero would cost a v_mov per dword)
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, __builtin_bit_cast(int, a), false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
     return (unsigned)v;
 }
@@ -57,7 +58,7 @@ __device__ __forceinline__ void mx_split8(const float (&t)[8], u32x4& h16, unsig
     constexpr float inv = 1.f / (float)(1 << MX_SX);
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(mx_s16x2{0, 0}, lo[4 * d], lo[4 * d + 1], inv, false);
+        mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(mx_s16x2, lo[4 * d]), lo[4 * d], lo[4 * d + 1], inv, false);
         w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lo[4 * d + 2], lo[4 * d + 3], inv, true);
         l8[d] = __builtin_bit_cast(unsigned, w);
         x8[d] = mx_cvt4(t[4 * d], t[4 * d + 1], t[4 * d + 2], t[4 * d + 3]);
@@ -79,7 +80,7 @@ __device__ __forceinline__ void mx_split4(const float (&t)[4], uint2& h16, unsig
     }
     h16 = make_uint2(hb[0], hb[1]);
     constexpr float inv = 1.f / (float)(1 << MX_SX);
-    mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(mx_s16x2{0, 0}, lo[0], lo[1], inv, false);
+    mx_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(mx_s16x2, lo[0]), lo[0], lo[1], inv, false);
     w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lo[2], lo[3], inv, true);
     l8 = __builtin_bit_cast(unsigned, w);
     x8 = mx_cvt4(t[0], t[1], t[2], t[3]);

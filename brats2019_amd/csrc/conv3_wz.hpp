@@ -91,7 +91,7 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, i
     // barriers later.  With one set (issue(w+2) right before the barrier, store(w+2) right behind it) the staging waves -- the pole of this
     // kernel: ~400 VALU instructions per item beside a wave that issues 240 MFMAs -- sat out a full L2 / HBM round trip every item.
     float4 vv[2][3][4];
-    float4 sc4s[2][3], sh4s[2][3];
+    float4 sc4s[2] = {}, sh4s[2] = {};                                      // the item's scale / shift of this lane's channel quad (one copy per register set)
     unsigned okmasks[2] = {0u, 0u};                                  // bit rd: (y, x) of this lane's position is inside the volume
     bool zok0s[2] = {true, true}, zok3s[2] = {true, true};           // planes z0-1 / z0+2 inside the volume (wave-uniform)
     auto issue = [&](auto SET, int item) {
@@ -124,12 +124,12 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, i
                 const unsigned ofs = okz ? (unsigned)(base + dlt[rd] + pz * pstride) : 0x80000000u;
                 v[rd][pz] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
             });
-            if (xform) {
-                const int cofs = n * a.Cin + chunk * 16 + quad * 4;
-                sc4[rd] = *reinterpret_cast<const float4*>(a.in_scale + cofs);
-                sh4[rd] = *reinterpret_cast<const float4*>(a.in_shift + cofs);
-            }
         });
+        if (xform) {
+            const int cofs = n * a.Cin + chunk * 16 + quad * 4;
+            sc4 = *reinterpret_cast<const float4*>(a.in_scale + cofs);
+            sh4 = *reinterpret_cast<const float4*>(a.in_shift + cofs);
+        }
     };
     auto store = [&](auto SET, u32x4* buf) {
         constexpr int set = decltype(SET)::value;
@@ -151,6 +151,8 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, i
         }
         uint2* b2 = reinterpret_cast<uint2*>(buf);
         const float mz0 = zok0 ? 1.f : 0.f, mz3 = zok3 ? 1.f : 0.f;
+        const float s[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, t[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        const float t0[4] = {t[0] * mz0, t[1] * mz0, t[2] * mz0, t[3] * mz0}, t3[4] = {t[0] * mz3, t[1] * mz3, t[2] * mz3, t[3] * mz3};
         auto body = [&](auto MODE) __attribute__((always_inline)) {
             constexpr int mode = decltype(MODE)::value;                      // 0 plain fp32, 1 fused affine + LeakyReLU
 #pragma unroll
@@ -174,16 +176,13 @@ __device__ __forceinline__ void wz_stage_waves(const Conv3Args& a, u32x4* lds, i
                         }
                         continue;
                     }
-                    const float s[4] = {sc4[rd].x, sc4[rd].y, sc4[rd].z, sc4[rd].w}, t[4] = {sh4[rd].x, sh4[rd].y, sh4[rd].z, sh4[rd].w};
 #pragma unroll
                     for (int pz = 0; pz < 4; ++pz) {
                         const float f[4] = {v[rd][pz].x, v[rd][pz].y, v[rd][pz].z, v[rd][pz].w};
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            // planes 0 / 3 outside the volume (wave-uniform): scale and shift become zero, so does the activated value
-                            const float sc = pz == 0 ? s[c] * mz0 : (pz == 3 ? s[c] * mz3 : s[c]);
-                            const float sh = pz == 0 ? t[c] * mz0 : (pz == 3 ? t[c] * mz3 : t[c]);
-                            const float u = fmaf(f[c], sc, sh);
+                            // planes 0 / 3 outside the volume (wave-uniform): their loads returned zeros and the shift is masked, so the activated value is zero
+                            const float u = fmaf(f[c], s[c], pz == 0 ? t0[c] : (pz == 3 ? t3[c] : t[c]));
                             d[pz][c] = fmaxf(u, u * slope);
                         }
                     }
