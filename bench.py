@@ -94,7 +94,9 @@ def step_roofline_ms(batch, size, precision, cfg=None, forward_only=False, prici
         # round 6: the FORWARD 3x3x3 convolutions between the stem and the head run the fp16 + MX-fp8 scheme (mx_executed_factor: 2.07 / 1.41 bf16-MFMA time
         # units per algorithmic product instead of 3); data and weight gradients keep three products
         fwd = max(flops * mx_executed_factor(cin, cout) / (BF16_MFMA_PEAK_TFLOPS * 1e12), byts / bw) if (pricing == "executed" and taps == 27 and precision == "bf16x3" and mx_executed_factor(cin, cout)) else one
-        t += fwd + (0 if forward_only else one * (2 if dgrad else 1))
+        # ... and the data gradients of the 16-channel level the gradient-operand form of the scheme (mxg_executed_factor); weight gradients keep three products
+        dg = max(flops * mxg_executed_factor(cin, cout) / (BF16_MFMA_PEAK_TFLOPS * 1e12), byts / bw) if (pricing == "executed" and taps == 27 and precision == "bf16x3" and mxg_executed_factor(cin, cout)) else one
+        t += fwd + (0 if forward_only else one + (dg if dgrad else 0))
     return t * 1e3
 
 
@@ -105,6 +107,12 @@ def mx_executed_factor(cin, cout):
     if os.environ.get("RU_MX", "1") == "0" or cin != cout or cin % 16:
         return 0.0
     return 28.0 / 13.5 if cin == 16 else (76.0 / 54.0 if os.environ.get("RU_MX", "") != "1" else 0.0)
+
+
+def mxg_executed_factor(cin, cout):
+    """... of a 3x3x3 DATA-GRADIENT convolution under the gradient-operand form of the scheme (conv3_mx_kernel<GRAD>: bf16 main term + two e4m3 cross terms with a
+    per-voxel exponent): the 16 -> 16 convolutions only, 28 / 13.5 units as the forward kernel; RU_MXG=0: three products."""
+    return 28.0 / 13.5 if (os.environ.get("RU_MXG", "1") != "0" and cin == 16 and cout == 16) else 0.0
 
 
 def family_bounds(batch, size, precision):
@@ -137,7 +145,8 @@ def family_bounds(batch, size, precision):
         for _ in range(count):
             add("conv3_" + lvl, flops, byts, p3_alg, (bf16 / mxf) if mxf else p3_exe)   # forward (round 6: fp16 + MX-fp8 products between the stem and the head)
             if dgrad:
-                add("conv3_" + lvl, flops, byts, p3_alg, p3_exe)                    # data gradient
+                mxg = mxg_executed_factor(cin, cout) if precision == "bf16x3" else 0.0
+                add("conv3_" + lvl, flops, byts, p3_alg, (bf16 / mxg) if mxg else p3_exe)   # data gradient (16 channels: the gradient-operand form of the scheme)
             add("wgrad3_" + lvl, flops, byts, p3_alg, p3_exe)                       # weight gradient: reads x and dy
             # GroupNorm passes the engine runs per 3x3x3 conv with a norm behind it (unfused compulsory bytes, fp32): forward apply
             # (read + write, second conv of a block only -- the first one's is fused into the next conv's staging), backward reduce + apply
@@ -252,13 +261,13 @@ def committed_step_traffic():
 # algorithmic work per step as (level -> launches per step); level l has 16 * 2^l channels on a (size / 2^l)^3 grid
 INSTANCE_INFO = {
     "conv16_fwd": ("conv3_mx_kernel (3x3x3 conv 16->16 forward: fp16 + MX-fp8 products; RU_MX=0: conv3_sb2_kernel<4,8,true,true,false,false,false,3,false>)",
-                   (r"^ru::conv3_mx_kernel", r"^ru::conv3_sb2_kernel<4, 8, true, true, false, false, false, 3, false>"), {0: 4}),
-    "conv16_dgrad": ("conv3_sb2_kernel<4,8,true,true,false,BST,ADD,3,false> (3x3x3 data gradient 16->16, split-form input, GroupNorm-backward sums / residual in the epilogue)",
-                     (r"^ru::conv3_sb2_kernel<4, 8, true, true, false, (true, false|true, true|false, true), 3, false>",), {0: 4}),
+                   (r"^ru::conv3_mx_kernel(<false, false, false>)?$", r"^ru::conv3_sb2_kernel<4, 8, true, true, false, false, false, 3, false>"), {0: 4}),
+    "conv16_dgrad": ("conv3_mx_kernel<true,BST,ADD> (3x3x3 data gradient 16->16: gradient-operand input -- bf16 main + two e4m3 cross products, per-voxel exponent --, GroupNorm-backward sums / residual in the epilogue; RU_MXG=0: conv3_sb2_kernel<4,8,true,true,false,BST,ADD,3,false>)",
+                     (r"^ru::conv3_mx_kernel<true,", r"^ru::conv3_sb2_kernel<4, 8, true, true, false, (true, false|true, true|false, true), 3, false>"), {0: 4}),
     "conv_deep_fwd": ("conv3_wz32mx_kernel (3x3x3 conv forward, 32-128 channels: Winograd F(2,3) along z, fp16 + MX-fp8 products on 32x32 MFMA tiles; RU_MX=0: conv3_wz32_kernel)",
                       (r"^ru::conv3_wz32mx_kernel", r"^ru::conv3_wz32_kernel"), {1: 6, 2: 6, 3: 8}),
     "conv_deep_dgrad": ("conv3_sb2_kernel<4,8,true,true,true,BST,ADD,3,false> (3x3x3 data gradient, 32-128 channels)", (r"^ru::conv3_sb2_kernel<4, 8, true, true, true,",), {1: 6, 2: 6, 3: 8}),
-    "wgrad16_fused_apply": ("wgrad3_tz_kernel<1,0,3,3> (3x3x3 weight gradient 16->16 with the GroupNorm-backward apply fused into its dy staging)", (r"^ru::wgrad3_tz_kernel<1, 0, 3, 3>",), {0: 4}),
+    "wgrad16_fused_apply": ("wgrad3_tz_kernel<1,0,4,3> (3x3x3 weight gradient 16->16 with the GroupNorm-backward apply fused into its dy staging; publishes the gradient in the operand form of the MX scheme; RU_MXG=0: <1,0,3,3>, split form)", (r"^ru::wgrad3_tz_kernel<1, 0, [34], 3>",), {0: 4}),
     "wgrad16_plain": ("wgrad3_tz_kernel<1,0,...> (3x3x3 weight gradient 16->16, plain dy)", (r"^ru::wgrad3_tz_kernel<1, 0, [012], 3>",), {0: 4}),
     "wgrad_deep": ("wgrad3_tz_kernel<2,0,1,3> (3x3x3 weight gradient, 32-128 channels)", (r"^ru::wgrad3_tz_kernel<2, 0, 1, 3>",), {1: 6, 2: 6, 3: 8}),
 }
@@ -877,6 +886,8 @@ def main():
                    "precision": ("fp32 tensors in HBM; 3x3x3 data gradient + weight gradient (and the 4- / 3-channel ends) on v_mfma_f32_16x16x32_bf16 with split operands (hi+lo, 3 products, fp32 "
                                  "accumulate); 3x3x3 FORWARD convolutions: fp16 main product (v_mfma_f32_*_f16) + both cross terms in OCP e4m3 on the MX-scaled fp8 MFMA "
                                  "(v_mfma_scale_f32_*_f8f6f4), fp32 accumulate -- the same 2^-16 error class (RU_MX=0: three bf16 products there too); "
+                                 "the 16-channel level's 3x3x3 DATA gradients: bf16 main product + both cross terms in e4m3 with one E8M0 exponent per voxel (2^-12 class, between one "
+                                 "bf16 product's 2^-8 and three products' 2^-16; RU_MXG=0: three products); "
                                  "the 1x1 / 2x2x2 convolutions, GroupNorm, trilinear, criterion and Adam in fp32") if args.precision == "bf16x3" else "fp32 storage, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)"},
         "final_loss": round(loss, 6),
         "algorithmic_tflops": round(value * FWDBWD_GFLOP_PER_VOL / 1e3 * (args.size / 128.0) ** 3, 2),

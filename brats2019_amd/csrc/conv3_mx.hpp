@@ -43,6 +43,14 @@ constexpr int MX_NMAIN = 50;                        // (halo row) x (4 families 
 static __device__ unsigned long long mx_prof[8];   // devtools bit 64: section cycle counters of consumer wave 0 (layout of sb2_prof)
 #endif
 
+// GRAD (round 6, late): the same kernel for a GRADIENT input -- the data-gradient convolutions of the 16-channel level (model.py:89-91 backward).  The input arrives in
+// the gradient operand form (Conv3Args::in_g16; conv3_mx_pack.hpp MXG_*): [bf16 hi | bf16 hi | e4m3(lo / 2^(e-8)) | e4m3(g / 2^e)] per voxel with ONE exponent e per voxel,
+// so the staging is a copy (conv3_sb2_kernel's split-form mode) plus the voxel's exponent byte, recomputed from the hi packets (the largest 15-bit pattern of the
+// voxel's 16 bf16 values: ~19 VALU per position, no byte stored or loaded), the main term runs on v_mfma_f32_16x16x32_bf16 (a gradient needs bf16's
+// range), and each scaled MFMA takes its data-side scale from the exponent plane: lane group b supplies block b's scale and a block is one voxel's 16 channels x
+// {lo, value} (tools/mx_scale_probe3.hip), so lane (n, g) reads the byte of the voxel at tap (j, slot) = (g & 1, g >> 1) of its fragment.  bf16 residual 2^-8, e4m3 on it
+// 2^-4: a 2^-12 class product (one bf16 product: 2^-8; three: 2^-16).  BST / ADD: conv3_sb2_kernel's data-gradient epilogues (GroupNorm-backward sums, residual).
+template <bool GRAD = false, bool BST = false, bool ADD = false>
 __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, const u32x4* __restrict__ wfrag, int ntz, int nty, int ntx) {
 #ifdef RU_SB2_DBG
     constexpr int dbg = RU_SB2_DBG;                 // 1 = staging waves skip convert + LDS stores, 2 = skip their loads, 4 = consumers skip the MFMAs, 8 = skip the row stores, 64 = section counters
@@ -55,6 +63,8 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
     constexpr int BUF = 4 * HVOLP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     u32x4* lds = reinterpret_cast<u32x4*>(smem);
+    constexpr int EPL = (HVOLP + 15) & ~15;             // GRAD: exponent plane of a buffer (one byte per halo position), behind the images and the statistics rows
+    unsigned char* elds = reinterpret_cast<unsigned char*>(smem) + 2 * BUF * 16 + SB_STAT_LDS_FLOATS * 4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
         float4 v16[NR][2];
         float4 sc4[2], sh4[2];
         unsigned vmask = 0;
-        const unsigned lofs = hsel * 32u;
+        const unsigned lofs = GRAD ? hsel * 16u : hsel * 32u;    // GRAD: packets hsel (bf16 hi of this half) and 2 + hsel (hsel 0: the e4m3 lo packet, 1: the e4m3 value packet)
         int pk[NR], dlt[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                     return;
                 }
                 v16[r][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 0, 0));
-                v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, 16, 0));
+                v16[r][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ofs, GRAD ? 32 : 16, 0));
             };
             if (st_chain) static_for<NR - CR>([&](auto R) { ld_round(std::integral_constant<int, decltype(R)::value + CR>{}); });
             else static_for<NR>(ld_round);
@@ -199,6 +209,17 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                     buf[hsel * HVOLP + p] = ch[r][0];
                     buf[(2 + hsel) * HVOLP + p] = ch[r][1];
                 }
+                if constexpr (GRAD) {
+                    if (hsel == 0) {
+                        const unsigned char* eprev = elds + (buf == lds ? EPL : 0);
+                        unsigned char* ecur = elds + (buf == lds ? 0 : EPL);
+                        unsigned char eb[CR > 0 ? CR : 1];
+#pragma unroll
+                        for (int r = 0; r < CR; ++r) eb[r] = eprev[r * 128 + pslot + 4 * HY * HX];
+#pragma unroll
+                        for (int r = 0; r < CR; ++r) ecur[r * 128 + pslot] = eb[r];
+                    }
+                }
             }
             auto body = [&](auto MODE, auto R0) {
                 constexpr int mode = decltype(MODE)::value;
@@ -207,6 +228,24 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                     constexpr int r = r0 + decltype(RI)::value;
                     const int p = r * 128 + pslot;
                     if ((r + 1) * 128 > NPOS && p >= NPOS) return;
+                    if constexpr (GRAD) {                 // the operand form is the LDS image: a copy (positions outside the volume were loaded as zeros)
+                        buf[hsel * HVOLP + p] = __builtin_bit_cast(u32x4, v16[r][0]);
+                        buf[(2 + hsel) * HVOLP + p] = __builtin_bit_cast(u32x4, v16[r][1]);
+                        // the voxel's exponent: largest |bf16 hi| of its 16 channels (this half's packet, then the partner lane's), as the writer took it (mxg_hi8)
+                        const u32x4 hq = __builtin_bit_cast(u32x4, v16[r][0]);
+                        unsigned mo = hq[0] & 0x7fff0000u, me = hq[0] & 0x7fffu;
+#pragma unroll
+                        for (int c = 1; c < 4; ++c) {
+                            const unsigned o = hq[c] & 0x7fff0000u, e = hq[c] & 0x7fffu;
+                            mo = o > mo ? o : mo;
+                            me = e > me ? e : me;
+                        }
+                        unsigned m = (mo >> 16) > me ? (mo >> 16) : me;
+                        const unsigned mp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, true);     // row_ror:8 = lane ^ 8: the partner half (hsel = bit 3 of ptid)
+                        m = mp > m ? mp : m;
+                        if (hsel == 0) (elds + (buf == lds ? 0 : EPL))[p] = (unsigned char)mxg_exponent_byte((m >> 7) & 0xffu);
+                        return;
+                    }
                     uint2* l8p = reinterpret_cast<uint2*>(buf + 2 * HVOLP + p) + hsel;
                     uint2* x8p = reinterpret_cast<uint2*>(buf + 3 * HVOLP + p) + hsel;
                     const float f[8] = {v16[r][0].x, v16[r][0].y, v16[r][0].z, v16[r][0].w, v16[r][1].x, v16[r][1].y, v16[r][1].z, v16[r][1].w};
@@ -279,6 +318,18 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
             }
         nbase[0] = (2 + (kg & 1)) * HVOLP + ((mz + 2) * HY + 2 * (kg >> 1)) * HX + 2 + (lane & 15);
         nbase[1] = (2 + (kg & 1)) * HVOLP + ((mz + 2) * HY + ((kg >> 1) ? 2 : 1)) * HX + 2 + (lane & 15);       // (1, 1): phantom, any valid row
+        // GRAD: byte offsets in the exponent plane.  Block b of a scaled MFMA = bytes 0-15 (b < 2) / 16-31 of lane groups 2 (b & 1), 2 (b & 1) + 1 = tap pair j = b & 1,
+        // slot b >> 1, and its scale comes from lane group b: this lane supplies the exponent of the voxel its column meets at (j, slot) = (kg & 1, kg >> 1)
+        int ebase[2] = {0, 0}, enb = 0;
+        if constexpr (GRAD) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = mx_cross_tap(h, kg & 1, kg >> 1, 0);
+                ebase[h] = ((mz + t / 9) * HY) * HX + t % 3 + (lane & 15);
+            }
+            const int dyn = 2 * (kg & 1) + (kg >> 1);     // ninth chain: (j, slot) is row tap dy = 2 j + slot; (1, 1) is the phantom (zero weights: any valid byte)
+            enb = ((mz + 2) * HY + (dyn < 3 ? dyn : 2)) * HX + 2 + (lane & 15);
+        }
         u32x4 wm[SB_KSTEPS];
         mx_i32x8 wx[2][3], wn;
         {
@@ -298,10 +349,27 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
         f32x4 acc[MT];
         // operands swapped (voxel-major output): D[m = cout][n = voxel], a lane owns 4 consecutive couts of one voxel
         auto mm16 = [](const u32x4& av, const u32x4& wv, const f32x4& c) -> f32x4 {
-            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_f16x8, wv), __builtin_bit_cast(mx_f16x8, av), c, 0, 0, 0);
+            if constexpr (GRAD) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, av), c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mx_f16x8, wv), __builtin_bit_cast(mx_f16x8, av), c, 0, 0, 0);
         };
-        auto mm8 = [](const mx_i32x8& av, const mx_i32x8& wv, const f32x4& c) -> f32x4 {
-            return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, MX_SCALE_W, 0, MX_SCALE_ACT);
+        auto mm8 = [](const mx_i32x8& av, const mx_i32x8& wv, const f32x4& c, int esc) -> f32x4 {       // esc (GRAD): byte 0 = the E8M0 exponent of this lane's block
+            if constexpr (GRAD) return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, MXG_SCALE_W, 0, esc);
+            else return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, MX_SCALE_W, 0, MX_SCALE_ACT);
+        };
+        f32x4 kc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // BST: (k1, k2, thr) of this lane's 4 channels for sample kc_n
+        int kc_n = -1;
+        auto need_kc = [&](int n) __attribute__((always_inline)) {
+            if constexpr (BST) {
+                if (n != kc_n) {
+                    const float* kp = a.bst_k + (size_t)n * 3 * a.Cout + cog * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const float4 q = *reinterpret_cast<const float4*>(kp + (size_t)t * a.Cout);
+                        kc[t] = f32x4{q.x, q.y, q.z, q.w};
+                    }
+                    kc_n = n;
+                }
+            }
         };
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         const int stat_blk = blockIdx.x, stat_nblk = G;
@@ -355,12 +423,18 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                 if (n_acc >= 0) flush_stats(n_acc);
                 n_acc = n;
             }
+            need_kc(n);
+            const unsigned char* ebuf = elds + (w & 1) * EPL;
+            float4 radd[3], rbst[3];                     // per-row operands (residual / BST forward tensor): tile i uses slot i % 3, loaded at row i + 1, consumed at row i + 3
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { radd[j] = make_float4(0.f, 0.f, 0.f, 0.f); rbst[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
 #ifdef RU_SB2_DBG
             if (prof) { t1 = __builtin_readcyclecounter(); pt[0] += t1 - t0; t0 = t1; }
 #endif
             // fragment rings: fp16 steps two ahead in a ring of three (12 registers), cross steps one ahead in a ring of two (32 registers)
             u32x4 fm[3];
             mx_i32x8 fx[2];
+            int fe[2] = {0, 0};
             auto main_ofs = [&](auto MI) __attribute__((always_inline)) {
                 constexpr int r = decltype(MI)::value / 5, f = decltype(MI)::value % 5;
                 return fbase[f < 4 ? f : (r < 8 ? 4 : 5)] + r * HX;
@@ -383,6 +457,10 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                     const u32x4 p1 = buf[o1];
                     __builtin_amdgcn_sched_barrier(0);
                     fx[xi % 2] = mx_i32x8{(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+                    if constexpr (GRAD) {
+                        fe[xi % 2] = ebuf[c.q < 2 ? ebase[c.q & 1] + c.r * HX : enb + (c.r - 2) * HX];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             };
             fetch_main(std::integral_constant<int, 0>{});
@@ -391,7 +469,8 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
             auto store_tile = [&](auto I) __attribute__((always_inline)) {
                 constexpr int i = decltype(I)::value;
                 if constexpr ((dbg & 8) != 0) dbg_sink += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-                else sb2_out_row<true, false, true>(a, so, ybase + i, acc[i], make_float4(0.f, 0.f, 0.f, 0.f), s1, s2);
+                else if constexpr (BST) sb_out_tile_bst<true>(a, so, ybase + i, acc[i], rbst[i % 3], kc, a.bst_slope, s1, s2, ADD ? &radd[i % 3] : nullptr);
+                else sb2_out_row<true, ADD, true>(a, so, ybase + i, acc[i], radd[i % 3], s1, s2);
             };
             // one fp16 step: fragment F(f, r) feeds tiles r-2 (dy 2), r-1 (dy 1), r (dy 0); f == 4: the ninth chain's K-steps 13 (tile r-2) and 12 (tile r)
             auto main_step = [&](auto MI) __attribute__((always_inline)) {
@@ -423,11 +502,19 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                     }
                 }
                 if (!fetched) fetch_main(std::integral_constant<int, mi + 2>{});
+                if constexpr ((BST || ADD) && f == 0 && r >= 1 && r <= MT) {     // epilogue operands of tile r-1, two rows ahead of its store (unconditional, clamped address)
+                    const int yy = ybase + r - 1;
+                    const size_t ri = (so.ok && yy < H) ? sb_out_index<true>(a, so, yy) : 0;
+                    if constexpr (ADD) radd[(r - 1) % 3] = *reinterpret_cast<const float4*>(a.add + ri);
+                    if constexpr (BST) rbst[(r - 1) % 3] = *reinterpret_cast<const float4*>(a.bst_y + ri);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             };
             auto cross_step = [&](auto XI) __attribute__((always_inline)) {
                 constexpr int xi = decltype(XI)::value;
                 constexpr MxCross c = mx_cross_of(xi);
                 const mx_i32x8 av = fx[xi % 2];
+                const int esc = fe[xi % 2];
                 bool fetched = false;
                 auto after = [&]() __attribute__((always_inline)) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -438,12 +525,12 @@ __global__ __launch_bounds__(512, 2) void conv3_mx_kernel(const Conv3Args a, con
                         static_for<3>([&](auto E) {
                             constexpr int dy = 2 - decltype(E)::value, i = c.r - dy;
                             if constexpr (i >= 0 && i < MT) {
-                                acc[i] = mm8(av, wx[c.q & 1][dy], acc[i]);
+                                acc[i] = mm8(av, wx[c.q & 1][dy], acc[i], esc);
                                 after();
                             }
                         });
                     } else {
-                        acc[c.r - 2] = mm8(av, wn, acc[c.r - 2]);
+                        acc[c.r - 2] = mm8(av, wn, acc[c.r - 2], esc);
                         after();
                     }
                 }

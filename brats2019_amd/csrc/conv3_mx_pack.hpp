@@ -9,6 +9,12 @@ constexpr int MX_SX = 11, MX_SWH = 8, MX_SWL = 19;
 static_assert(MX_SX + MX_SWH == MX_SWL, "one pair of hardware scales serves both cross terms");
 constexpr int MX_SCALE_ACT = (127 - MX_SX) * 0x01010101;       // E8M0 2^-11 in every byte (op_sel 0 reads byte 0)
 constexpr int MX_SCALE_W = (127 - MX_SWH) * 0x01010101;        // 2^-8
+// Gradient operands (conv3_mx_kernel<GRAD>, round 6 late): bf16 main term (a gradient's range needs bf16's exponent), cross terms e4m3(lo * 2^(8-e)) * e4m3(w * 2^8) +
+// e4m3(g * 2^-e) * e4m3(w_lo * 2^16) (packets 2 / 3 of a voxel: both planes of channels 0-7 / 8-15, so that each channel half is written by one thread) with ONE exponent e per voxel (its 16 channels, both planes: a scale block of the instruction), carried as the E8M0 byte 127 + e
+// in a byte plane beside the tensor; lo = g - bf16(g) <= 2^-8 of the voxel's largest value, which e puts into [128, 256).
+constexpr int MXG_SX = 8, MXG_SWH = 8, MXG_SWL = 16;
+static_assert(MXG_SX + MXG_SWH == MXG_SWL, "one weight-side scale serves both cross terms");
+constexpr int MXG_SCALE_W = (127 - MXG_SWL) * 0x01010101;      // 2^-16; the data side's byte is 127 + e per voxel
 constexpr int MX_UNITS = 28;                                   // 16-byte x 64-lane units per 16-cout group: 14 fp16 K-steps, 2 x 3 x 2 cross, 2 ninth chain
 
 typedef _Float16 mx_f16x8 __attribute__((ext_vector_type(8)));
@@ -91,7 +97,8 @@ __device__ __forceinline__ void mx_split4(const float (&t)[4], uint2& h16, unsig
 //   u < 14            fp16 K-step u: 8 x fp16 of W[co][ci = (g&1)*8 + e][sb_tap(u, g>>1)]                       (the direct kernel's fragment in fp16)
 //   u = 14 + (3h+dy)*2 + slot   cross: 16 x e4m3 over ci = 0..15 of tap mx_cross_tap(h, g>>1, slot, dy): (g&1) == 0 ? w * 2^8 : (w - f16(w)) * 2^19
 //   u = 26 + slot     ninth chain: the same at tap mx_ninth_tap(g>>1, slot)
-__device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* __restrict__ mxfrag, int Cin_f, int Cout_f, int mode, int ncog, int i) {
+// grad: the fragments of the gradient-operand form -- units < 14 hold bf16(w) (the direct kernel's hi fragments), the cross units w * 2^8 | (w - bf16(w)) * 2^16
+__device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* __restrict__ mxfrag, int Cin_f, int Cout_f, int mode, int ncog, int i, bool grad = false) {
     if (i >= ncog * MX_UNITS * 64) return;
     mx_set_saturating_conversions();
     const int lane = i & 63, unit = (i >> 6) % MX_UNITS, cog = (i >> 6) / MX_UNITS;
@@ -106,10 +113,16 @@ __device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* 
         const int tap = sb_tap(unit, g >> 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            mx_f16x2 h;
-            h[0] = (_Float16)wat((g & 1) * 8 + 2 * c, tap);
-            h[1] = (_Float16)wat((g & 1) * 8 + 2 * c + 1, tap);
-            out[c] = __builtin_bit_cast(unsigned, h);
+            const float w0 = wat((g & 1) * 8 + 2 * c, tap), w1 = wat((g & 1) * 8 + 2 * c + 1, tap);
+            if (grad) {
+                ru_bf16x2 h;
+                h[0] = (__bf16)w0; h[1] = (__bf16)w1;
+                out[c] = __builtin_bit_cast(unsigned, h);
+            } else {
+                mx_f16x2 h;
+                h[0] = (_Float16)w0; h[1] = (_Float16)w1;
+                out[c] = __builtin_bit_cast(unsigned, h);
+            }
         }
     } else {
         int tap;
@@ -120,10 +133,19 @@ __device__ __forceinline__ void mx_pack_one(const float* __restrict__ w, u32x4* 
             tap = mx_ninth_tap(g >> 1, unit - 26);
         }
         float v[16];
+        if (grad) {                                        // the operand's packet 2 + (g & 1) holds e4m3(lo) | e4m3(value) of channels 8 (g & 1) .. + 7: w * 2^8 | w_lo * 2^16 of the same channels
 #pragma unroll
-        for (int ci = 0; ci < 16; ++ci) {
-            const float x = wat(ci, tap);
-            v[ci] = (g & 1) == 0 ? x * (float)(1 << MX_SWH) : (x - (float)(_Float16)x) * (float)(1 << MX_SWL);
+            for (int k = 0; k < 8; ++k) {
+                const float x = wat((g & 1) * 8 + k, tap);
+                v[k] = x * (float)(1 << MXG_SWH);
+                v[8 + k] = (x - (float)(__bf16)x) * (float)(1 << MXG_SWL);
+            }
+        } else {
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+                const float x = wat(ci, tap);
+                v[ci] = (g & 1) == 0 ? x * (float)(1 << MX_SWH) : (x - (float)(_Float16)x) * (float)(1 << MX_SWL);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) out[c] = mx_cvt4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
@@ -136,5 +158,5 @@ bool conv3_mx_enabled();                                 // RU_MX=0: every forwa
 bool conv3_mx_wz_enabled();                              // ... and the Winograd-z form of the scheme at 32..128 channels (conv3_wz32mx.hpp); RU_MX=1: the 16-channel kernel only
 bool conv3_mx_shape_ok(int N, int Cin, int Cout, int D, int H, int W);
 int conv3_mx_launch(const Conv3Args& a, const void* mxfrag, hipStream_t s);
-
+// (conv3_mxg_enabled / conv3_mxg_usable / conv3_mxg_split_launch: ru_common.h -- the engine and the weight gradient use them)
 }  // namespace ru

@@ -626,7 +626,7 @@ __device__ __forceinline__ void sb_pack_both(const float* __restrict__ w, u32x4*
     if (i < direct) { if (!(forms & 16)) sb_pack_one(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, i); return; }      // (bit 4: the direct fragments are not needed -- conv3_sb_pack_add)
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     if (sb_head_shape(cin_conv, cout_conv)) { sb_pack_head_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, i - direct); return; }
-    if (mx_channels_ok(cin_conv, cout_conv)) { if (forms & 4) mx_pack_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, ncog, i - direct); return; }
+    if (mx_channels_ok(cin_conv, cout_conv)) { if (forms & 4) mx_pack_one(w, wfrag + (size_t)direct * 2, Cin_f, Cout_f, mode, ncog, i - direct, (forms & 32) != 0); return; }     // (bit 5: the gradient-operand variant in the same place)
     if (!wz_channels_ok(cin_conv, cout_conv)) return;
     const int wz = WZ16_FORM ? (cout_conv / 32) * nchunk * 4 * 2 * WZ_KSTEPS * 64 : 0;      // (the fragments keep their places whatever `forms` says: a skipped form leaves its bytes as they are)
     int r = i - direct;
@@ -649,15 +649,15 @@ static inline int sb_pack_threads(int cin_conv, int cout_conv, int forms) {
 // what the launches of a TRAINING forward + backward read of a weight packed in `mode` (0: forward, 1: data gradient) under the RU_WZ / RU_WZ32 / RU_MX switches
 // (read per call, as the launches read them; a toggle BETWEEN a forward's pack and a launch that reads it is not supported -- tools and tests toggle between steps)
 static int sb_pack_forms(int mode) {
-    if (mode == 1) return 0;                                // data-gradient launches (split-form inputs) take the direct kernels only
+    if (mode == 1) return conv3_mxg_enabled() ? (4 | 32) : 0;   // data-gradient launches (split-form inputs) take the direct kernels; 16 -> 16: the gradient-operand MX form beside them
     const bool mxon = conv3_mx_enabled();                   // forward convolutions only: gradients never take the fp16 + MX-fp8 scheme
     const char* e = getenv("RU_WZ");
     if (e && *e == '0') return mxon ? 4 : 0;
     if (mxon && conv3_mx_wz_enabled()) return 4 | 8;        // forward launches take the MX kernel of their shape: direct (16 channels) or Winograd-z (32..)
     return (mxon ? 4 : 0) | (conv3_wz32_enabled() ? 2 : 1); // ... or ONE three-product Winograd-z form
 }
-__global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog) {
-    sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, SB_FORMS_ALL, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void conv3_sb_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wfrag, int Cin_f, int Cout_f, int mode, int nchunk, int ncog, int forms) {
+    sb_pack_both(w, wfrag, Cin_f, Cout_f, mode, nchunk, ncog, forms, blockIdx.x * blockDim.x + threadIdx.x);
 }
 // all 3x3x3 weights of a network in ONE launch (blockIdx.y = entry): the ~50 pack launches of a training step were 4.5 us each,
 // almost all of it launch latency (5 % of a batch-1 forward)
@@ -680,7 +680,7 @@ int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s) {
 }
 int conv3_sb_switch_signature() {
     const char* e = getenv("RU_WZ");
-    return ((e && *e == '0') ? 0 : 1) | (conv3_wz32_enabled() ? 2 : 0) | (conv3_mx_enabled() ? 4 : 0) | (conv3_mx_wz_enabled() ? 8 : 0);
+    return ((e && *e == '0') ? 0 : 1) | (conv3_wz32_enabled() ? 2 : 0) | (conv3_mx_enabled() ? 4 : 0) | (conv3_mx_wz_enabled() ? 8 : 0) | (conv3_mxg_enabled() ? 16 : 0);
 }
 bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W) {
     if (conv3_sb_uses_wz(N, Cin, Cout, D, H, W, 2)) return true;                    // conv3_wz32mx_kernel or conv3_wz32_kernel
@@ -716,11 +716,12 @@ bool conv3_sb_head_form_enabled() {
     return !(e && e[0] == '0');
 }
 
-int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s) {
+int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s, bool grad_operand) {
     const int cin_conv = mode == 0 ? Cin_f : Cout_f, cout_conv = mode == 0 ? Cout_f : Cin_f;
     const int nchunk = cdiv(cin_conv, 16), ncog = cdiv(cout_conv, 16);
-    const int total = sb_pack_threads(cin_conv, cout_conv, SB_FORMS_ALL);
-    hipLaunchKernelGGL(conv3_sb_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, (u32x4*)wfrag, Cin_f, Cout_f, mode, nchunk, ncog);
+    const int forms = SB_FORMS_ALL | (grad_operand ? 32 : 0);    // (the MX fragments of a weight exist in ONE variant: activation or gradient operand)
+    const int total = sb_pack_threads(cin_conv, cout_conv, forms);
+    hipLaunchKernelGGL(conv3_sb_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, (u32x4*)wfrag, Cin_f, Cout_f, mode, nchunk, ncog, forms);
     RU_CHECK_LAUNCH("conv3_sb_pack_kernel");
     return RU_OK;
 }
@@ -813,6 +814,12 @@ int conv3_sb_launch(const Conv3Args& a, hipStream_t s) {
 #endif      // (no engine path: the persistent kernel has the bias for NCDHW output only)
     if (a.in_c16 && a.out_c16 && !a.in_s16 && !a.bias && !a.sigmoid && !a.bst_y && !a.add && conv3_sb_uses_wz(a.N, a.Cin, a.Cout, a.D, a.H, a.W, a.products))
         return conv3_wz_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
+    // Conv3Args::in_g16: the input is a gradient in the operand form of the MX scheme (the caller asked conv3_mxg_usable before it wrote the tensor that way)
+    if (a.in_g16) {
+        RU_REQUIRE(a.in_s16 && a.out_c16 && !a.bias && !a.sigmoid && !a.in_res && conv3_mxg_usable(a.N, a.Cin, a.Cout, a.D, a.H, a.W),
+                   "conv3_sb: a gradient-operand input is taken by conv3_mx_kernel<GRAD> only (16 -> 16 channels, persistent-kernel shapes)");
+        return conv3_mx_launch(a, static_cast<const char*>(a.wfrag) + conv3_sb_frag_bytes_direct(a.Cin, a.Cout), s);
+    }
     // Conv3Args::products == 2: the caller's input is an ACTIVATION tensor and it asks for the fp16 + MX-fp8 product scheme where a kernel for the shape exists
     // (conv3_mx.hpp: the 16-channel level); everywhere else the request means three products
     if (a.products == 2 && a.in_c16 && a.out_c16 && !a.in_s16 && !a.bias && !a.sigmoid && !a.add && !a.bst_y && !a.in_res && conv3_mx_enabled() &&

@@ -836,7 +836,7 @@ static int gn_bwd(ru_unet* h, Arena& A, hipStream_t s, const float* yraw, const 
 }
 
 // GroupNorm-backward apply fused into the weight gradient's dy staging (Wgrad3Args::gb_*): dy is OUTPUT (split form) then
-struct GbApply { const float* y; const float* d; const GNSave* g; const float* coef; };
+struct GbApply { const float* y; const float* d; const GNSave* g; const float* coef; bool g16 = false; };     // g16: publish the gradient-operand form of the MX scheme (conv3_mxg_usable)
 static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const GNSave* xg, const float* dy, float* dw, int N, int Cin, int Cout, int D, int H, int W,
                       bool x_c16 = false, bool dy_c16 = false, const float* few4 = nullptr, bool dy_s16 = false, const GbApply* gb = nullptr) {
     const int products = (mode & kOneProduct) ? 1 : 3;
@@ -881,7 +881,7 @@ static int wgrad3_run(Arena& A, hipStream_t s, int mode, const float* x, const G
     w.N = N; w.Cin = Cin; w.Cout = Cout; w.D = D; w.H = H; w.W = W;
     if (gb) {
         w.gb_y = gb->y; w.gb_d = gb->d; w.gb_scale = gb->g->scale; w.gb_shift = gb->g->shift; w.gb_coef = gb->coef; w.gb_slope = kSlope;
-        w.gb_out = const_cast<float*>(dy); w.dy_s16 = 0;
+        w.gb_out = const_cast<float*>(dy); w.dy_s16 = 0; w.gb_g16 = gb->g16 ? 1 : 0;
     }
     t_hint_inst = (x_c16 && dy_c16) ? (Cin == 16 && Cout == 16 ? (gb ? INST_WGRAD16_FUSED : INST_WGRAD16_PLAIN) : (Cin >= 32 ? INST_WGRAD_DEEP : -1)) : -1;
     RU_RUN(wgrad3_launch(w, s));
@@ -973,7 +973,10 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     int rc = gn_bwd(h, A, s, sv.y2, dout, sv.g2, P(h, params, bp.n2w), kSlope, dy2, G(h, grads, bp.n2w), G(h, grads, bp.n2b), N, C, V, sums2,
                     fa ? &coef2 : nullptr, ds16);
     if (rc) return rc;
-    const GbApply gb2{sv.y2, dout, &sv.g2, coef2};
+    // the published gradients of the 16-channel level have ONE reader each, the data-gradient conv that follows: where conv3_mx_kernel<GRAD> takes the shape they are
+    // written in the gradient-operand form of the MX scheme (bf16 main + e4m3 cross terms, a per-voxel exponent; RU_MXG=0 or one-product gradients: the split form)
+    const bool g16 = fa && h->grad_products() == 3 && conv3_mxg_usable(N, C, C, D, H, W);
+    const GbApply gb2{sv.y2, dout, &sv.g2, coef2, g16};
     // weight gradients whose dy has no other producer role (no fused apply: dy2 / dy1 are complete when gn_bwd returns) leave the chain:
     // on the side stream they run beside the data-gradient convs and the GroupNorm passes of the chain (a 188-register weight-gradient
     // workgroup leaves a third wave's registers free on its CU: the memory-bound passes fit beside it)
@@ -984,7 +987,7 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     if (rc) return rc;
     float* da1 = A.alloc((size_t)N * C * V);
     Conv3Args d2{};
-    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.products = h->grad_products(); d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = ds16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
+    d2.x = dy2; d2.wp = h->pack + bp.pk_d2; d2.y = da1; d2.mode = h->precision; d2.products = h->grad_products(); d2.wfrag = h->fpack + bp.fk_d2; d2.in_c16 = c16; d2.out_c16 = c16; d2.in_s16 = ds16; d2.in_g16 = g16; d2.N = N; d2.Cin = C; d2.Cout = C; d2.D = D; d2.H = H; d2.W = W;
     // the data-gradient conv of conv2 takes the GroupNorm-backward sums of norm1 in its epilogue (its output IS the gradient w.r.t.
     // LeakyReLU(norm1(y1))): no separate reduce pass over (y1, da1)
     const bool fuse1 = c16 && h->precision == RU_PREC_BF16X3 && conv3_sb_bst_usable(N, C, D, H, W) && (h->fusion & RU_FUSE_GN_BWD_STATS);
@@ -1005,14 +1008,14 @@ static int block_bwd(ru_unet* h, const float* params, float* grads, Arena& A, hi
     rc = gn_bwd(h, A, s, sv.y1, da1, sv.g1, P(h, params, bp.n1w), kSlope, dy1, G(h, grads, bp.n1w), G(h, grads, bp.n1b), N, C, V, fuse1 ? &sums1 : nullptr,
                 fa ? &coef1 : nullptr, ds16);
     if (rc) return rc;
-    const GbApply gb1{sv.y1, da1, &sv.g1, coef1};
+    const GbApply gb1{sv.y1, da1, &sv.g1, coef1, g16};
     if (aside) { rc = side_fork(h, s); if (rc) return rc; }
     rc = wgrad3_run(A, sw, h->wgrad_mode(), sv.x, sv.xg, dy1, G(h, grads, bp.conv1), N, C, C, D, H, W, c16, c16, nullptr, ds16, fa ? &gb1 : nullptr);
     if (rc) return rc;
     float* dx = A.alloc((size_t)N * C * V);
     Conv3Args d1{};
     d1.x = dy1; d1.wp = h->pack + bp.pk_d1; d1.y = dx; d1.add = dout; d1.mode = h->precision; d1.products = h->grad_products(); d1.wfrag = h->fpack + bp.fk_d1;       // skip path: dx = dout + dgrad(conv1)
-    d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = ds16;
+    d1.in_c16 = c16; d1.out_c16 = c16; d1.in_s16 = ds16; d1.in_g16 = g16;
     d1.N = N; d1.Cin = C; d1.Cout = C; d1.D = D; d1.H = H; d1.W = W;
     if (nx) nx->out = FusedSums();
     if (nx && fuse1 && bp.down < 0) {                   // same shape and kernel choice as d2: dx = dout + dgrad(conv1) IS the gradient entering nx
@@ -1735,13 +1738,24 @@ extern "C" int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias
     const bool f32 = (flags & 16) != 0;                          // exact-f32 arithmetic on voxel-major tensors (conv3_f32c_kernel)
     a.products = (flags & 32) ? 2 : 0;                           // the input is an activation tensor: fp16 + MX-fp8 products where the shape has that kernel (conv3_mx.hpp)
     RU_REQUIRE(!f32 || ((flags & 3) != 0 && !(flags & (4 | 8))), "ru_conv3d_fwd_l: the exact-f32 form needs a voxel-major side and takes neither the 4-channel copy nor a split-form input");
-    int rc = f32 ? conv3_f32c_pack_weights(w, wf, Cin, Cout, 0, s) : conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s);
+    // flag bit 6: x (float32, voxel-major) is a GRADIENT -- where conv3_mx_kernel<GRAD> takes the shape it is converted to the gradient-operand form of the MX scheme
+    // (conv3_mxg_split_launch; in a training step wgrad3_tz<1,0,3,3> writes that form) and convolved with bf16 main + MX cross products; elsewhere the bit is ignored
+    const bool gop = (flags & 64) && !f32 && (flags & 3) == 3 && !(flags & (4 | 8)) && !bias && conv3_mxg_usable(N, Cin, Cout, D, H, W);
+    int rc = f32 ? conv3_f32c_pack_weights(w, wf, Cin, Cout, 0, s) : conv3_sb_pack_weights(w, wf, Cin, Cout, 0, s, gop);
     if (rc) return rc;
     a.mode = f32 ? RU_PREC_F32 : RU_PREC_BF16X3; a.wfrag = wf;
     a.in_c16 = flags & 1; a.out_c16 = (flags >> 1) & 1;
     a.in_s16 = (flags >> 3) & 1;                                 // x is voxel-major in SPLIT form (hi / lo bf16 packets, as gn_bwd_apply16 publishes it)
     RU_REQUIRE(!a.in_s16 || a.in_c16, "ru_conv3d_fwd_l: the split form is a voxel-major layout");
     a.x = x; a.bias = bias; a.y = y; a.N = N; a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W;
+    if (gop) {
+        const size_t nvox = (size_t)N * D * H * W;
+        float* g16 = C.take(nvox * 16);
+        RU_WS_OK(C);
+        rc = conv3_mxg_split_launch(x, g16, nvox, s);
+        if (rc) return rc;
+        a.x = g16; a.in_s16 = 1; a.in_g16 = 1; a.products = 0;
+    }
     if (flags & 4) {                                             // x NCDHW with Cin <= 4: 4-channel copy + tap-pair kernel
         RU_REQUIRE(!(flags & 1) && conv3_sb4_usable(N, Cin, Cout, D, H, W), "ru_conv3d_fwd_l: shape does not fit the 4-channel kernel");
         const size_t V = (size_t)D * H * W;

@@ -31,6 +31,47 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hb, unsig
     l[1] = (__bf16)(b - h1);
     lb = __builtin_bit_cast(unsigned, l);
 }
+// ---- gradient operand form of the MX product scheme (conv3_mx_pack.hpp, MXG_*): one exponent per voxel (16 channels), DERIVED from the voxel's bf16 hi values --
+// the reader recomputes it from the hi packets it stages (conv3_mx_kernel<GRAD>), so it is stored nowhere.
+// amax = the largest |bf16 hi| of the voxel (both channel halves).  byte = E8M0 of 2^e with amax / 2^e in [128, 256); sc = 2^e, sc8 = 2^(e-8) as floats.
+__device__ __forceinline__ unsigned mxg_exponent_byte(unsigned biased_exponent_of_amax) {
+    const int b = (int)biased_exponent_of_amax - 7;
+    return (unsigned)(b < 9 ? 9 : b);                    // (voxels below 2^-118: the scale stops following them -- their values still convert, to smaller codes)
+}
+typedef short ru_s16x2 __attribute__((ext_vector_type(2)));
+// step 1: 8 values of a voxel half -> 4 dwords bf16 hi (RNE, split_pair's), the exact residuals, and the largest |hi| of the half
+template <class V>
+__device__ __forceinline__ float mxg_hi8(const float (&t)[8], V& hi, float (&lo)[8]) {
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ru_bf16x2 h;
+        h[0] = (__bf16)t[2 * c];
+        h[1] = (__bf16)t[2 * c + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        hi[c] = hb;
+        const float h0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(hb, hb, 0x01000c0cu)), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+        lo[2 * c] = t[2 * c] - h0;
+        lo[2 * c + 1] = t[2 * c + 1] - h1;
+        m = fmaxf(m, fmaxf(fabsf(h0), fabsf(h1)));
+    }
+    return m;
+}
+// step 2 (amax16 = the larger of the two halves' maxima): 2 dwords e4m3(lo / 2^(e-8)), 2 dwords e4m3(g / 2^e).  v_cvt_scalef32_pk_fp8_f32 divides by its scale operand
+// (tools/mx_cvt_probe.hip); the caller has set MODE.FP16_OVFL so that the conversions saturate
+__device__ __forceinline__ void mxg_cvt8(const float (&t)[8], const float (&lo)[8], float amax16, unsigned (&l8)[2], unsigned (&x8)[2]) {
+    const unsigned b = mxg_exponent_byte((__builtin_bit_cast(unsigned, amax16) >> 23) & 0xffu);
+    const float sc = __builtin_bit_cast(float, b << 23), sc8 = __builtin_bit_cast(float, (b - 8u) << 23);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        ru_s16x2 w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(ru_s16x2, lo[4 * d]), lo[4 * d], lo[4 * d + 1], sc8, false);
+        w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, lo[4 * d + 2], lo[4 * d + 3], sc8, true);
+        l8[d] = __builtin_bit_cast(unsigned, w);
+        ru_s16x2 v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(ru_s16x2, t[4 * d]), t[4 * d], t[4 * d + 1], sc, false);
+        v = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(v, t[4 * d + 2], t[4 * d + 3], sc, true);
+        x8[d] = __builtin_bit_cast(unsigned, v);
+    }
+}
 template <int NP, class V>
 __device__ __forceinline__ void split_n(const float (&t)[2 * NP], V& hi, V& lo) {       // 2*NP floats -> NP packed dwords of hi and of lo
 #pragma unroll
@@ -126,6 +167,9 @@ struct Conv3Args {
     // in_c16: x (and in_scale/in_shift semantics unchanged); out_c16: y, add.  0 = NCDHW.
     int in_c16, out_c16;
     int in_s16;              // x is C16 in SPLIT form (see gn_bwd_apply16_launch): the staging copies hi/lo packets, no conversion, no transform
+    // with in_s16: x is in the GRADIENT OPERAND form of the MX scheme instead (conv3_mx_pack.hpp: [bf16 hi | hi | e4m3 (lo, value) ch 0-7 | ch 8-15] per voxel, same 64 bytes, the
+    // voxel's exponent implied by its hi values): conv3_mx_kernel<GRAD> (16 -> 16 channels; written by wgrad3_tz<1,0,3,3> or conv3_mxg_split_launch)
+    int in_g16;
     int in_c4;               // x is a [N][D][H][W][4] copy (pad_to_c4) of a tensor with Cin <= 4: conv3_sb2c4_kernel, wfrag from conv3_sb4_pack_weights
     // Fused GroupNorm-BACKWARD statistics (persistent split-bf16 kernel, C16 in and out, no bias / sigmoid; a residual `add` is part of the
     // output and therefore of the sums): this conv's output is
@@ -175,7 +219,7 @@ size_t conv3_sb_frag_bytes_direct(int Cin_conv, int Cout_conv);
 size_t conv3_sb4_frag_bytes(int Cout_conv);
 int conv3_sb4_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);
 bool conv3_sb4_usable(int N, int Cin, int Cout, int D, int H, int W);                                   // shape fits the 4-channel kernel
-int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s);   // mode 0 fwd, 1 data-gradient
+int conv3_sb_pack_weights(const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, hipStream_t s, bool grad_operand = false);   // mode 0 fwd, 1 data-gradient; grad_operand: the MX fragments in the gradient-operand variant
 // the same for many weights in one launch: add entries, then flush (add flushes by itself when the table is full)
 constexpr int RU_PACK_BATCH = 64;
 struct SbPackEntry { const float* w; void* wfrag; int Cin_f, Cout_f, mode, nchunk, ncog, forms; };
@@ -185,6 +229,12 @@ struct SbPackBatch { SbPackEntry e[RU_PACK_BATCH]; int n; };
 int conv3_sb_pack_add(SbPackBatch& b, const float* w, void* wfrag, int Cin_f, int Cout_f, int mode, bool all_forms, hipStream_t s, bool skip_direct = false);
 int conv3_sb_switch_signature();                   // the kernel-choice switches as the launches read them now (RU_WZ, RU_MX, devtools RU_WZ32): the engine records it with a
                                                   // training forward's packs and refuses a backward under another signature (packs hold only the forms that signature launches)
+// the gradient-operand form of the MX product scheme (conv3_mx.hip; conv3_mx_pack.hpp MXG_*)
+bool conv3_mxg_enabled();                                // RU_MXG=0: the data-gradient convolutions of the 16-channel level keep three bf16 products
+bool conv3_mxg_usable(int N, int Cin, int Cout, int D, int H, int W);      // ... and the shape is one conv3_mx_kernel<GRAD> takes: the producer of the gradient asks before it writes the operand form
+// fp32 voxel-major [N][1][D][H][W][16] -> the gradient operand form: per voxel 64 bytes [bf16 hi ch 0-7 | hi ch 8-15 | e4m3(lo * 2^(8-e)), e4m3(g * 2^-e) ch 0-7 | the same ch 8-15],
+// e from the voxel's largest |hi| (what wgrad3_tz<1,0,3,3> publishes in the step; this launch serves the op-level entry and the tests)
+int conv3_mxg_split_launch(const float* x, void* g16, size_t nvox, hipStream_t s);
 bool conv3_sb_forward_skips_direct(int N, int Cin, int Cout, int D, int H, int W);     // a forward launch of this shape on activations (products == 2) takes a non-direct kernel under the current switches
 int conv3_sb_pack_batch(SbPackBatch& b, hipStream_t s);
 // pack [Cout][Cin][27] -> wp.  mode 0: forward; mode 1: data-gradient (taps flipped, in/out swapped:
@@ -221,6 +271,7 @@ struct Wgrad3Args {
     const float* gb_coef;
     float gb_slope;
     float* gb_out;
+    int gb_g16;              // gb_out is written in the gradient-operand form of the MX scheme (mxg_hi8 / mxg_cvt8) instead of the split form: its reader is conv3_mx_kernel<GRAD>
     int products;            // wgrad_tr only: 0 / 3 = three split-bf16 products, 1 = hi*hi only (gradient precision RU_PREC_BF16), where such a variant exists
     // wgrad_tr only: the operands are EXCHANGED -- `x` (with its halo) is the convolution's OUTPUT gradient, `dy` (tile centres) its input:
     //     T[t][o'][c'] = sum_v dy[v][o'] * x[v + t][c'] = dW[26 - t][cout = c'][cin = o']

@@ -148,6 +148,8 @@ template <int OT, int XS, int DS, int NP = 3>
 __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, float* __restrict__ partials, int ntz, int nty, int ntx, int ncg, int CoP, int CiP) {
     using P = WTZ<OT>;
     constexpr int HX = P::HX, PPOS = P::PPOS, DPOS = P::DPOS, TY = P::TY;
+    constexpr bool FA = DS == 3 || DS == 4, G16 = DS == 4;      // fused GroupNorm-backward apply; ... publishing the gradient-operand form of the MX scheme (compile time: a run-time
+                                                                // branch in the unrolled store loop cost what the form's reader gains)
     extern __shared__ __attribute__((aligned(256))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
     };
 
     if (producer) {
+        if constexpr (G16) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);      // MODE.FP16_OVFL: the e4m3 conversions of the published gradient saturate
         // x units: (plane of the new set, halo position, channel half); dy units: (o-block, position, half)
         constexpr int NRX = (4 * PPOS + 127) / 128, NR2 = (2 * PPOS + 127) / 128, NRD = OT * ((DPOS + 127) / 128);     // first step of a column: 4 planes
         const int hsel = ptid & 1, pslot = ptid >> 1;
         float4 vx[NRX][2], vd[NRD][2];
-        float4 vg[DS == 3 ? NRD : 1][2], gc4[DS == 3 ? 10 : 1];       // DS == 3: the gradient stream and (scale, shift, coefficients) of this thread's 8 channels
+        float4 vg[FA ? NRD : 1][2], gc4[FA ? 10 : 1];       // DS == 3: the gradient stream and (scale, shift, coefficients) of this thread's 8 channels
         int st_n = 0, st_y0 = 0, st_x0 = 0;
         float4 sc4[2], sh4[2];
         unsigned mx = 0, md = 0, mx2 = 0;                // (mx2: XS == 2, validity of the second 4-channel group of this half)
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
         // once per column, not with four integer divisions per item in this wave's VALU stream
         int is_k = 0, is_n = 0, is_y0 = 0, is_x0 = 0, is_ring0 = 0;
         auto load_gc = [&](int n, int q) __attribute__((always_inline)) {          // (scale, shift, 3 coefficients) of this thread's 8 channels of output block q
-            if constexpr (DS == 3) {
+            if constexpr (FA) {
                 const size_t go = (size_t)n * a.Cout + (og * OT + q) * 16 + hsel * 8;
                 gc4[0] = *reinterpret_cast<const float4*>(a.gb_scale + go); gc4[1] = *reinterpret_cast<const float4*>(a.gb_scale + go + 4);
                 gc4[2] = *reinterpret_cast<const float4*>(a.gb_shift + go); gc4[3] = *reinterpret_cast<const float4*>(a.gb_shift + go + 4);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
 #else
                 const size_t ofs = ok ? (size_t)((gz * H + gy) * W + gx) * 16 : 0;
 #endif
-                if constexpr (DS == 3) {                 // GroupNorm-backward apply on the fly: forward tensor y and gradient d
+                if constexpr (FA) {                 // GroupNorm-backward apply on the fly: forward tensor y and gradient d
                     md |= ok ? (1u << r) : 0u;
                     const size_t cb = ((size_t)(n * CBo + og * OT + q) * DHW) * 16 + ofs + hsel * 8;
                     vd[r][0] = *reinterpret_cast<const float4*>(a.gb_y + cb);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     vd[r][1] = *reinterpret_cast<const float4*>(db + ofs + 4);
                 }
             }
-            if constexpr (DS == 3) {
+            if constexpr (FA) {
                 if constexpr (OT == 1) load_gc(n, 0);    // one output block: its constants travel with the loads (two blocks: fetched per block
                 st_n = n; st_y0 = y0; st_x0 = x0;        // in store(), 40 registers live instead of 80 held across the whole item)
             }
@@ -355,13 +358,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
             for (int r = 0; r < NRD; ++r) {
                 constexpr int RPB = (DPOS + 127) / 128;
                 const int q = r / RPB, p = (r - q * RPB) * 128 + pslot;
-                if constexpr (DS == 3 && OT > 1) {
+                if constexpr (FA && OT > 1) {
                     if (r % RPB == 0) load_gc(st_n, q);  // (r is a compile-time constant after unrolling)
                 }
                 const bool ok = (md >> r) & 1u;
                 const float f[8] = {vd[r][0].x, vd[r][0].y, vd[r][0].z, vd[r][0].w, vd[r][1].x, vd[r][1].y, vd[r][1].z, vd[r][1].w};
                 float t[8];
-                if constexpr (DS == 3) {                 // the expression of gn_bwd_apply16_split_kernel, term for term
+                if constexpr (FA) {                 // the expression of gn_bwd_apply16_split_kernel, term for term
                     const float g[8] = {vg[r][0].x, vg[r][0].y, vg[r][0].z, vg[r][0].w, vg[r][1].x, vg[r][1].y, vg[r][1].z, vg[r][1].w};
                     const float ga[8] = {gc4[0].x, gc4[0].y, gc4[0].z, gc4[0].w, gc4[1].x, gc4[1].y, gc4[1].z, gc4[1].w};
                     const float gb[8] = {gc4[2].x, gc4[2].y, gc4[2].z, gc4[2].w, gc4[3].x, gc4[3].y, gc4[3].z, gc4[3].w};
@@ -377,24 +380,40 @@ __global__ __launch_bounds__(512, 2) void wgrad3_tz_kernel(const Wgrad3Args a, f
                     for (int c = 0; c < 8; ++c) t[c] = ok ? f[c] : 0.f;
                 }
                 u32x4 hi, lo = u32x4{0u, 0u, 0u, 0u};
+                float lof[FA ? 8 : 1], amax = 0.f;  // DS == 3: the exact residuals and the largest |hi| of this half (the gradient-operand form of the published tensor)
                 if constexpr (DS == 1) {
                     const u32x4 z = u32x4{0u, 0u, 0u, 0u};
                     hi = ok ? __builtin_bit_cast(u32x4, vd[r][0]) : z;
                     if constexpr (NP == 3) lo = ok ? __builtin_bit_cast(u32x4, vd[r][1]) : z;
-                } else if constexpr (NP == 3 || DS == 3) {
-                    wt_split8(t, hi, lo);                // (fused apply: the published gradient keeps its lo half whatever this kernel multiplies)
+                } else if constexpr (FA) {          // wt_split8's hi / lo (fused apply: the published gradient keeps its lo half whatever this kernel multiplies)
+                    amax = mxg_hi8(t, hi, lof);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ru_bf16x2 l2;
+                        l2[0] = (__bf16)lof[2 * c]; l2[1] = (__bf16)lof[2 * c + 1];
+                        lo[c] = __builtin_bit_cast(unsigned, l2);
+                    }
+                } else if constexpr (NP == 3) {
+                    wt_split8(t, hi, lo);
                 } else {
                     wt_hi8(t, hi);
                 }
                 *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + p * 32 + hsel * 16) = hi;
                 if constexpr (NP == 3) *reinterpret_cast<u32x4*>(dbuf + q * 2 * P::DPLANE + P::DPLANE + p * 32 + hsel * 16) = lo;
-                if constexpr (DS == 3) {                 // publish dy in split form (every position is staged once by input-channel group 0)
+                if constexpr (FA) {                 // publish dy in split form (every position is staged once by input-channel group 0)
                     if (ok && cgp == 0 && a.gb_out) {    // (no output tensor: nobody but this weight gradient consumes the gradient, e.g. the stem)
                         const int row = p >> 4, z = row / TY;
                         const size_t vox = (size_t)((2 * std_k + z) * H + st_y0 + (row - z * TY)) * W + st_x0 + (p & 15);
                         u32x4* op = reinterpret_cast<u32x4*>(a.gb_out) + ((size_t)(st_n * CBo + og * OT + q) * DHW + vox) * 4;
                         op[hsel] = hi;
-                        op[2 + hsel] = lo;
+                        if constexpr (G16) {             // [hi ch 0-7 | hi ch 8-15 | e4m3 (lo, g) ch 0-7 | e4m3 (lo, g) ch 8-15], e from the voxel's largest |hi| (partner lane: the other half)
+                            const float m = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0xb1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+                            unsigned l8[2], x8[2];
+                            mxg_cvt8(t, lof, m, l8, x8);
+                            op[2 + hsel] = u32x4{l8[0], l8[1], x8[0], x8[1]};      // this half's e4m3(lo) and e4m3(value): ONE 16-byte store, as in the split form
+                        } else {
+                            op[2 + hsel] = lo;
+                        }
                     }
                 }
             }
@@ -534,7 +553,7 @@ int wgrad3_tr_launch(const Wgrad3Args& a, hipStream_t s) {
         }
         if (p1 && c.ot == 1) return wtz_cfg<1, 0, 3, 1>(a, c, s);
         if (c.ot == 2) return wtz_cfg<2, 0, 3>(a, c, s);   // two output blocks per workgroup: the constants of a block are fetched when it is converted
-        return wtz_cfg<1, 0, 3>(a, c, s);
+        return a.gb_g16 ? wtz_cfg<1, 0, 4>(a, c, s) : wtz_cfg<1, 0, 3>(a, c, s);
     }
     const int xs = a.x_c4 ? 1 : 0, ds = a.dy_c4 ? 2 : (a.dy_s16 ? 1 : 0);
     if (c.ot == 2) {

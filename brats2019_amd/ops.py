@@ -395,10 +395,11 @@ def to_split_c16(x_c16):
     return torch.cat([hi, lo], dim=-1).contiguous().view(torch.float32)
 
 
-def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False, in_split=False, exact_f32=False, activations=False):
+def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=False, in_split=False, exact_f32=False, activations=False, gradient=False):
     """3x3x3 split-bf16 convolution on tensors in NCDHW or C16 storage (x: 5-D NCDHW or 6-D C16); few_channels: NCDHW input
     with Cin <= 4 through the 4-channel tap-pair kernel; activations: x is an activation tensor (a forward convolution), which lets the
-    shapes that have the kernel take the fp16 + MX-fp8 product scheme (conv3_mx.hpp), as the engine's forward convolutions do."""
+    shapes that have the kernel take the fp16 + MX-fp8 product scheme (conv3_mx.hpp), as the engine's forward convolutions do; gradient: x is a
+    gradient tensor -- 16 -> 16 voxel-major shapes take the gradient-operand form of the scheme, as the engine's 16-channel data-gradient convolutions do."""
     x, w, bias = _prep(x), _prep(w), _prep(bias)
     if in_c16:
         n, cb, d, h, wd, _ = (int(v) for v in x.shape)
@@ -408,9 +409,10 @@ def conv3d_layout(x, w, bias=None, in_c16=False, out_c16=False, few_channels=Fal
     cout = int(w.shape[0])
     y = torch.empty((n, cout // 16, d, h, wd, 16) if out_c16 else (n, cout, d, h, wd), dtype=torch.float32, device=x.device)
     lib = L.load()
-    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3) + (n * d * h * wd * 16 + 65536 if few_channels else 0), x.device)
+    ws = L.workspace(lib.ru_conv3d_workspace_bytes(n, cin, cout, d, h, wd, 3) + (n * d * h * wd * 16 + 65536 if few_channels else 0)
+                     + (n * d * h * wd * 64 + 65536 if gradient else 0), x.device)
     L.check(lib.ru_conv3d_fwd_l(L.f32(x), L.f32(w), L.ptr(bias, True), L.f32(y), n, cin, cout, d, h, wd,
-                                int(in_c16) | (int(out_c16) << 1) | (int(few_channels) << 2) | (int(in_split) << 3) | (int(exact_f32) << 4) | (int(activations) << 5),
+                                int(in_c16) | (int(out_c16) << 1) | (int(few_channels) << 2) | (int(in_split) << 3) | (int(exact_f32) << 4) | (int(activations) << 5) | (int(gradient) << 6),
                                 L.ptr(ws), ws.numel(), L.stream()), "ru_conv3d_fwd_l")
     return y
 

@@ -323,7 +323,10 @@ int ru_paste_labels(const unsigned char* lab, unsigned char* full, int D, int H,
  * tap-pair kernel (needs extra workspace: 16 bytes per input voxel); bit 3 = x is voxel-major in SPLIT form (hi / lo bf16 packets); bit 4 = exact-f32
  * arithmetic (v_mfma_f32_16x16x4_f32 on voxel-major tensors: the exact-f32 inference forward of the engine; not with bits 2 / 3); bit 5 = x is an
  * ACTIVATION tensor (a forward convolution, model.py:72-73): shapes that have the kernel (16 input channels, voxel-major both sides, a grid that fills the
- * chip) take the fp16 + MX-fp8 product scheme the engine's forward convolutions take (f16*f16 + two e4m3 cross terms, RU_MX=0: off); never set for gradients.  k = 3. */
+ * chip) take the fp16 + MX-fp8 product scheme the engine's forward convolutions take (f16*f16 + two e4m3 cross terms, RU_MX=0: off); never set for gradients;
+ * bit 6 = x (float32, voxel-major both sides, 16 -> 16 channels) is a GRADIENT: where the kernel takes the shape it is converted to the gradient-operand form (bf16 + two
+ * e4m3 planes + one exponent byte per voxel) and convolved with bf16 main + MX-fp8 cross products, as the engine's 16-channel data-gradient convolutions are (RU_MXG=0:
+ * off; needs 64 more workspace bytes per input voxel); ignored elsewhere.  k = 3. */
 int ru_layout_convert(const float* src, float* dst, int N, int C, size_t V, int to_c16, ru_stream_t stream);
 int ru_conv3d_fwd_l(const float* x, const float* w, const float* bias, float* y,
                     int N, int Cin, int Cout, int D, int H, int W, int flags,

@@ -154,6 +154,43 @@ def test_conv3_mx_against_float64(shape):
     assert e_mx <= 1.2e-4 and e_mx <= 4 * e_sb + 1e-6, (e_mx, e_sb)
 
 
+MXG_SHAPES = [(2, 16, 16, 64, 64, 64), (1, 16, 16, 40, 60, 72), (1, 16, 16, 128, 128, 128), (2, 16, 16, 30, 44, 40)]
+
+
+@pytest.mark.parametrize("shape", MXG_SHAPES, ids=["%dx%d-%d_%dx%dx%d" % s for s in MXG_SHAPES])
+def test_conv3_gradient_operand_against_float64(shape):
+    """conv3_mx_kernel<GRAD> (the 16-channel level's data-gradient convolutions: bf16 * bf16 main term, both cross terms in e4m3 with ONE exponent per voxel
+    carried beside the tensor) against a float64 convolution of the same fp32 operands.  The input is a gradient-like tensor: magnitudes around 1e-6 that change by
+    decades from voxel to voxel and from channel to channel -- what a fixed scale could not cover.  Relative L2 error within 2.5e-4 (CPU emulation: 8e-5; one bf16
+    product 2.3e-3, three 4e-6), max error within 5e-4 of the largest output (the outputs span decades too); RU_MXG=0 keeps the three-product kernel bit for bit; an all-zero input gives zeros."""
+    import os
+    from brats2019_amd import ops
+    n, cin, cout, d, h, w = shape
+    g = torch.Generator().manual_seed(41)
+    mag = torch.exp(2.5 * torch.randn(n, 1, d, h, w, generator=g)) * 1e-6
+    chan = torch.exp(1.5 * torch.randn(1, cin, 1, 1, 1, generator=g))
+    x = (torch.randn(n, cin, d, h, w, generator=g) * mag * chan).float().cuda()
+    wt = _rand(cout, cin, 3, 3, 3, seed=42) * float((2.0 / (cin * 27)) ** 0.5)
+    ref = torch.nn.functional.conv3d(x.double().cpu(), wt.double().cpu(), padding=1)
+    x16 = ops.to_c16(x)
+    y_g = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True, gradient=True))
+    y_sb = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True))
+    os.environ["RU_MXG"] = "0"
+    try:
+        y_off = ops.from_c16(ops.conv3d_layout(x16, wt, in_c16=True, out_c16=True, gradient=True))
+    finally:
+        os.environ.pop("RU_MXG", None)
+    rel = lambda y: float((y.double().cpu() - ref).norm() / ref.norm())
+    e_g, e_sb = rel(y_g), rel(y_sb)
+    e_max = float((y_g.double().cpu() - ref).abs().max() / ref.abs().max())
+    print("  %s: relative L2 error  bf16 + MX-fp8 (per-voxel exponent) %.2e  three bf16 products %.2e;  max error / max |y| %.2e" % (shape, e_g, e_sb, e_max))
+    assert torch.equal(y_off, y_sb), "RU_MXG=0 did not keep the three-product kernel"
+    assert not torch.equal(y_g, y_sb), "the shape did not take conv3_mx_kernel<GRAD>"
+    assert e_g <= 2.5e-4 and e_max <= 5e-4, (e_g, e_max)
+    z = ops.conv3d_layout(torch.zeros_like(x16), wt, in_c16=True, out_c16=True, gradient=True)
+    assert float(z.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 16, 16, 16, 16), (1, 32, 32, 8, 16, 16), (2, 16, 3, 32, 32, 32)], ids=["small16", "small32", "head"])
 def test_conv3_activation_flag_falls_back_to_three_products(shape):
     """Shapes that have no fp16 + MX-fp8 kernel (grids below one persistent workgroup per CU: the one-stage kernel; the 3-channel head form) must ignore the

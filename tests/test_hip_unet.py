@@ -845,7 +845,9 @@ def test_tail_finalize_and_batched_reduce_match_the_separate_launches():
     worst_pw = max(float(torch.linalg.vector_norm(res["nopw"][1][k].double() - res["batch"][1][k].double()) / torch.linalg.vector_norm(res["batch"][1][k].double()))
                    for k in res["batch"][1])
     print("fused 1x1 data gradient vs the conv1_16 launch: worst relative L2 gradient difference %.2e" % worst_pw)
-    assert worst_pw <= 1e-5, worst_pw
+    # (3e-5 since the 16-channel data gradients run bf16 + e4m3 cross terms: a last-bit difference upstream can flip an e4m3 rounding of a correction term, 2^-12 of one
+    # product; with RU_MXG=0 the two runs agree to 1e-5)
+    assert worst_pw <= 3e-5, worst_pw
 
 
 @pytest.mark.parametrize("cfgname,precision", [("small", "f32"), ("small", "bf16x3"), ("wide", "bf16x3")])
