@@ -1384,7 +1384,7 @@ static int backward_entry(ru_unet_t h, const float* params, const float* dprobs,
     // a training forward packs only the fragment forms its switches launch (sb_pack_forms): a switch flipped between that forward and this backward would make
     // a launch read fragments that were never packed -- refused instead (round-5 advisor finding; tools and tests toggle between steps, which is fine)
     RU_REQUIRE(h->precision != RU_PREC_BF16X3 || h->pack_sig == conv3_sb_switch_signature(),
-               "ru_unet_backward: RU_WZ / RU_MX changed since the forward whose packs this backward reads (signature %d then, %d now)", h->pack_sig, conv3_sb_switch_signature());
+               "ru_unet_backward: RU_WZ / RU_MX / RU_MXG changed since the forward whose packs this backward reads (signature %d then, %d now)", h->pack_sig, conv3_sb_switch_signature());
     int rc = unet_backward_impl(h, params, dprobs, grads, dx, A, (hipStream_t)stream, crit);
     ru::t_red = nullptr;
     ru::t_sink = nullptr;

@@ -1033,13 +1033,47 @@ def test_backward_refuses_switches_flipped_since_its_forward():
     loss = L.FusedCriterion()(net([x]), [g])
     os.environ["RU_MX"] = "0"
     try:
-        with pytest.raises(RuntimeError, match="RU_WZ / RU_MX changed"):
+        with pytest.raises(RuntimeError, match="RU_WZ / RU_MX / RU_MXG changed"):
             loss.backward()
         loss = L.FusedCriterion()(net([x]), [g])            # packed under the new switches: fine
         loss.backward()
     finally:
         os.environ.pop("RU_MX", None)
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+def test_gradient_operand_convolutions_agree_through_the_network():
+    """The data-gradient convolutions of the 16-channel level inside the engine on one batch-2 x 128^3 training step: the default (conv3_mx_kernel<GRAD>: bf16 main
+    product + both cross terms in e4m3 with one exponent per voxel, the gradient published in that operand form by wgrad3_tz<1,0,4,3>) against RU_MXG=0 (three bf16
+    products on the split form).  The forward is the same bit for bit; every parameter gradient agrees within 5e-4 relative L2 (the scheme leaves 1e-4 per
+    convolution, test_conv3_gradient_operand_against_float64; four of them sit in the chain) and differs somewhere (the kernel ran); the 16-channel WEIGHT gradients,
+    whose own operands are unchanged, agree as closely as the data gradients that reach them."""
+    import os
+    from brats2019_amd import loss as L
+    res = {}
+    for mode, env in (("three", {"RU_MXG": "0"}), ("mxg", {})):
+        os.environ.update(env)
+        try:
+            net, _ = build_model(O.DEFAULT_CFG, 37, "bf16x3")
+            x = T(O.make_input(2, 128, 128, 128, seed=37)).cuda()
+            g = T(O.make_target(2, 128, 128, 128, seed=37)).cuda()
+            net.train()
+            out = net([x])
+            loss = L.FusedCriterion()(out, [g])
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        res[mode] = (out[0].detach().clone(), float(loss), {k: q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None})
+        del net
+    assert torch.equal(res["mxg"][0], res["three"][0]) and res["mxg"][1] == res["three"][1], "RU_MXG must not touch the forward"
+    rel = {k: float((res["mxg"][2][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)) for k, v in res["three"][2].items()}
+    worst = max((v, k) for k, v in rel.items())
+    print("gradient-operand data gradients vs three products: worst parameter-gradient relative L2 %.2e (%s); %d of %d gradients differ" %
+          (worst[0], worst[1], sum(1 for v in rel.values() if v > 0), len(rel)))
+    assert worst[0] <= 5e-4, worst
+    assert sum(1 for v in rel.values() if v > 0) > len(rel) // 2, "the default path did not take conv3_mx_kernel<GRAD>"
 
 
 def test_forward_convolution_kernels_agree_through_the_network():
