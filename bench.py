@@ -35,7 +35,7 @@ are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; at N=
                  largest SINGLE kernel instantiations (rows with "instance": the executor tags their launches, ru_unet_probe_read_families) with algorithmic
                  FLOPs / bytes, the bytes the kernel really moves (committed counter table) and both fractions,
   whole_step_frac : the step against the per-layer roofline priced on ALGORITHMIC FLOPs (`_executed`: on the matrix time units this build executes -- three split-bf16
-                 products, forward convolutions 2.07 / 1.41 under the fp16 + MX-fp8 scheme; `_three_products`: the yardstick of rounds 1-5;
+                 products, forward convolutions 2.07 / 1.41 and the 16-channel data gradients 2.07 under the MX-fp8 schemes; `_three_products`: the yardstick of rounds 1-5;
                  `_achievable` / `whole_step_achievable`: plus the bytes no fusion removes for fp32 tensors -- achievable_bounds),
 and at N > 1
   allreduce_ms : the two collectives of a step timed in place (HIP event pairs on the kernels' stream, max over ranks), `step_ms_per_rank`,
