@@ -1020,7 +1020,8 @@ def _backward_in_context(L, loss):
         loss.backward()
 
 
-def test_backward_refuses_switches_flipped_since_its_forward():
+@pytest.mark.parametrize("switch", ["RU_MX", "RU_MXG"])
+def test_backward_refuses_switches_flipped_since_its_forward(switch):
     """round-5 advisor finding: a training forward packs only the fragment forms its kernel switches launch; a switch flipped between that forward and the
     backward would make a launch read fragments that were never packed.  The engine records the switches' signature with the packs and refuses such a backward
     loudly; the next forward under the new switches works."""
@@ -1031,14 +1032,14 @@ def test_backward_refuses_switches_flipped_since_its_forward():
     g = T(O.make_target(1, 32, 32, 32, seed=5)).cuda()
     net.train()
     loss = L.FusedCriterion()(net([x]), [g])
-    os.environ["RU_MX"] = "0"
+    os.environ[switch] = "0"
     try:
         with pytest.raises(RuntimeError, match="RU_WZ / RU_MX / RU_MXG changed"):
             loss.backward()
         loss = L.FusedCriterion()(net([x]), [g])            # packed under the new switches: fine
         loss.backward()
     finally:
-        os.environ.pop("RU_MX", None)
+        os.environ.pop(switch, None)
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in net.parameters())
 
 
