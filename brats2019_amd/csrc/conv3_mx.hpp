@@ -44,7 +44,8 @@ static __device__ unsigned long long mx_prof[8];   // devtools bit 64: section c
 #endif
 
 // GRAD (round 6, late): the same kernel for a GRADIENT input -- the data-gradient convolutions of the 16-channel level (model.py:89-91 backward).  The input arrives in
-// the gradient operand form (Conv3Args::in_g16; conv3_mx_pack.hpp MXG_*): [bf16 hi | bf16 hi | e4m3(lo / 2^(e-8)) | e4m3(g / 2^e)] per voxel with ONE exponent e per voxel,
+// the gradient operand form (Conv3Args::in_g16; conv3_mx_pack.hpp MXG_*): [bf16 hi ch 0-7 | hi ch 8-15 | e4m3(lo / 2^(e-8)), e4m3(g / 2^e) ch 0-7 | the same ch 8-15] per voxel with ONE exponent e per voxel
+// (LDS planes 2 / 3 then hold a channel half's two correction planes each, and the gradient variant of the weight fragments is packed in that order),
 // so the staging is a copy (conv3_sb2_kernel's split-form mode) plus the voxel's exponent byte, recomputed from the hi packets (the largest 15-bit pattern of the
 // voxel's 16 bf16 values: ~19 VALU per position, no byte stored or loaded), the main term runs on v_mfma_f32_16x16x32_bf16 (a gradient needs bf16's
 // range), and each scaled MFMA takes its data-side scale from the exponent plane: lane group b supplies block b's scale and a block is one voxel's 16 channels x
